@@ -1,0 +1,167 @@
+"""The CPU oracle (oracle/) against the golden vectors taken from the reference's own Python.
+
+These tests pin the oracle; the oracle then is the checker for the HIP path (tests/test_gpu_*.py).
+No GPU needed.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+BASES = "ACGT"
+
+
+def fdec(h):
+    return float.fromhex(h)
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+def same_float(a, b):
+    return (a == b) or (np.isnan(a) and np.isnan(b))
+
+
+# ------------------------------------------------------------------------------ beam search, no LM
+def test_beam_nolm_strings(oracle, golden_dir):
+    cases = _load(golden_dir, "beam_nolm_cases.json")["cases"]
+    mats = np.load(os.path.join(golden_dir, "beam_nolm_mats.npz"))
+    assert len(cases) >= 100
+    for c in cases:
+        mat = mats[c["mat"]]
+        got = oracle.beam_search(mat, BASES, c["W"])
+        assert got == c["seq"], (c["mat"], c["T"], c["kind"], c["W"])
+
+
+def test_beam_nolm_final_scores_bit_exact(oracle, golden_dir):
+    cases = _load(golden_dir, "beam_nolm_cases.json")["cases"]
+    mats = np.load(os.path.join(golden_dir, "beam_nolm_mats.npz"))
+    n = 0
+    for c in cases:
+        if "final" not in c:
+            continue
+        mat = mats[c["mat"]]
+        _, final = oracle.beam_search_labels(mat, c["W"], max_final=30)
+        assert len(final) == len(c["final"])
+        for got, exp in zip(final, c["final"]):
+            assert got[0] == exp["labeling"], (c["mat"], c["W"])
+            assert same_float(got[1], fdec(exp["pr_total"]))
+            assert same_float(got[2], fdec(exp["pr_blank"]))
+            assert same_float(got[3], fdec(exp["pr_non_blank"]))
+        n += 1
+    assert n >= 40
+
+
+# ------------------------------------------------------------------------------ beam search with LM
+def test_beam_lm_strings_and_scores(oracle, golden_dir):
+    g = _load(golden_dir, "beam_lm_cases.json")
+    mats = np.load(os.path.join(golden_dir, "beam_lm_mats.npz"))
+    assert len(g["cases"]) >= 200
+    for c in g["cases"]:
+        mat = mats[c["mat"]]
+        lm = mats[c["lm"]]
+        s_thr, r_thr = fdec(c["s_thr"]), fdec(c["r_thr"])
+        labels, final = oracle.beam_search_labels(mat, c["W"], lm, s_thr, r_thr, c["k"], max_final=30)
+        got = "".join(BASES[x] for x in labels)
+        assert got == c["seq"], (c["mat"], c["k"], c["W"], s_thr, r_thr)
+        if "final" in c:
+            assert len(final) == len(c["final"])
+            for gf, exp in zip(final, c["final"]):
+                assert gf[0] == exp["labeling"]
+                assert same_float(gf[1], fdec(exp["pr_total"]))
+                assert same_float(gf[2], fdec(exp["pr_blank"]))
+                assert same_float(gf[3], fdec(exp["pr_non_blank"]))
+
+
+def test_lm_gate_pairs(oracle, golden_dir):
+    g = _load(golden_dir, "beam_lm_cases.json")
+    mats = np.load(os.path.join(golden_dir, "beam_lm_mats.npz"))
+    lm = mats["lm_pairs_k3"]
+    for p in g["pairs"]:
+        s = np.array([fdec(x) for x in p["s"]], dtype=np.float64)
+        ctx = p["ctx"][0] * 16 + p["ctx"][1] * 4 + p["ctx"][2]
+        assert oracle.row_entropy(s) == fdec(p["s_entropy"])
+        out = oracle.apply_rna_model(s, ctx, lm, fdec(p["s_entropy"]), fdec(p["r_thr"]), fdec(p["s_thr"]))
+        exp = np.array([fdec(x) for x in p["out"]])
+        assert np.array_equal(out, exp, equal_nan=True)
+
+
+# ------------------------------------------------------------------------------ assembly
+def test_assemble(oracle, golden_dir):
+    g = _load(golden_dir, "assemble_cases.json")
+    arr = np.load(os.path.join(golden_dir, "assemble.npz"))
+    for c in g["cases"]:
+        probs = arr["probs_" + c["tag"]]
+        exp = arr["out_" + c["tag"]]
+        got = oracle.assemble_matrices(probs, c["pad"], c["step"])
+        assert str(got.dtype) == c["out_dtype"], c["tag"]
+        assert got.shape == tuple(c["out_shape"]), c["tag"]
+        assert np.array_equal(got, exp), c["tag"]
+
+
+# ------------------------------------------------------------------------------ preprocess
+def test_preprocess(oracle, golden_dir):
+    g = _load(golden_dir, "preprocess_cases.json")
+    arr = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    for c in g["cases"]:
+        sig = arr["sig_" + c["name"]]
+        if "error" in c:
+            with pytest.raises(ValueError) as ei:
+                oracle.mad_normalise(sig, c["clip"])
+            assert ei.value.args[0] == c["error"]
+            continue
+        norm = oracle.mad_normalise(sig, c["clip"])
+        assert str(norm.dtype) == c["norm_dtype"], c["name"]
+        assert np.array_equal(norm, arr["norm_" + c["name"]]), c["name"]
+        win, pad = oracle.get_windows(norm, c["chunk"], c["step"])
+        assert pad == c["pad"]
+        assert str(win.dtype) == c["win_dtype"]
+        assert np.array_equal(win, arr["win_" + c["name"]])
+    for e in g["window_errors"]:
+        with pytest.raises(ValueError) as ei:
+            oracle.get_windows(np.zeros(100), e["chunk"], e["step"])
+        assert ei.value.args[0] == e["error"]
+
+
+# ------------------------------------------------------------------------------ chunk stitch
+def test_seq_assembly(oracle, golden_dir):
+    g = _load(golden_dir, "seq_assembly_cases.json")
+    for c in g["cases"]:
+        cons = oracle.simple_assembly(c["fragments"])
+        assert list(cons.shape) == c["consensus_shape"]
+        assert np.array_equal(cons.astype(np.int64), np.array(c["consensus"], dtype=np.int64).reshape(cons.shape))
+        assert oracle.chunk_consensus(c["fragments"]) == c["seq"]
+
+
+# ------------------------------------------------------------------------------ decode side of basecall.py
+def test_pipeline_decode_side(oracle, golden_dir):
+    g = _load(golden_dir, "pipeline_cases.json")
+    arr = np.load(os.path.join(golden_dir, "pipeline.npz"))
+    lm = arr["lm_k3"]
+    for c in g["cases"]:
+        probs = arr[c["probs"]]
+        nW, chunk, _ = probs.shape
+        mat = oracle.assemble_matrices(probs, c["pad"], c["step"])
+        assert str(mat.dtype) == c["global_matrix_dtype"]
+        assert oracle.beam_search(mat, BASES, c["W"], lm, 0.5, 0.5, c["k"]) == c["global_seq"]
+        frags = []
+        for i in range(nW):
+            m = probs[i] if i < nW - 1 else probs[i][: chunk - c["pad"]]
+            frags.append(oracle.beam_search(m, BASES, c["W"]))
+        assert frags == c["chunk_fragments"]
+        assert oracle.chunk_consensus(frags) == c["chunk_seq"]
+
+
+def test_logaddexp_matches_numpy_scalar(oracle):
+    rng = np.random.default_rng(3)
+    xs = rng.normal(scale=30, size=2000)
+    ys = xs + rng.normal(scale=5, size=2000)
+    for x, y in zip(xs, ys):
+        assert oracle.logaddexp(x, y) == float(np.logaddexp(float(x), float(y)))
+    ninf = float("-inf")
+    assert oracle.logaddexp(ninf, ninf) == ninf
+    assert oracle.logaddexp(ninf, -3.5) == -3.5
+    assert oracle.logaddexp(-3.5, ninf) == -3.5
