@@ -1,0 +1,152 @@
+/*
+ * radian_hip.h -- C ABI of libradian_hip.so: the MI355X (gfx950) backend for RADIAN's
+ * inference + decode hot path.
+ *
+ * The reference (comprna/radian) has no FFI; the seam is five in-process Python calls made by
+ * radian/basecall.py.  Each entry point below names the reference call it replaces (file:line under
+ * the reference tree).  INTEGRATION.md shows the ctypes binding a maintainer adds to basecall.py.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative RD_ERR_* code; rd_last_error() then returns
+ *     a thread-local human-readable message.  Nothing is thrown, nothing calls back into the host.
+ *   - all pointers are caller-owned HOST memory unless the parameter name starts with d_ (device
+ *     memory obtained from rd_dev_alloc).  Plain pointers and sizes only; no framework types.
+ *   - one rd_ctx per process and per GPU rank; calls on one context are not thread-safe.
+ *   - class order of probability rows is A, C, G, T, blank (radian/models/sig2seq.yaml:2;
+ *     radian/decode.py:124); labels are 0..3 = A,C,G,T and are NOT reversed (basecall.py:129
+ *     reverses the string on the host).
+ *   - there is no CPU fallback: without a GPU rd_create fails.
+ */
+#ifndef RADIAN_HIP_H
+#define RADIAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RD_OK 0
+#define RD_ERR_ARG (-1)   /* bad argument */
+#define RD_ERR_HIP (-2)   /* HIP runtime error */
+#define RD_ERR_STATE (-3) /* call order (e.g. forward before weights) */
+#define RD_ERR_NOMEM (-4) /* device allocation failed */
+#define RD_ERR_RCCL (-5)  /* RCCL error / librccl not loadable */
+
+typedef struct rd_ctx rd_ctx;
+
+/* ---- library ------------------------------------------------------------------------------- */
+const char* rd_last_error(void);
+int rd_version(void);                 /* ABI version, currently 1 */
+int rd_device_count(int* n);          /* number of visible HIP devices */
+int rd_decode_max_width(void);        /* largest supported --beam-width (51) */
+
+/* ---- context ------------------------------------------------------------------------------- */
+int rd_create(int device_id, rd_ctx** out);
+int rd_destroy(rd_ctx* ctx);
+int rd_sync(rd_ctx* ctx);             /* wait for the context's stream */
+
+/* ---- model artefacts ----------------------------------------------------------------------- */
+/* Replaces model.load_weights(checkpoint) -- radian/model.py:42-45.
+ * blob = rd_weights_header followed by float32 tensors in Keras load_weights order and layouts:
+ *   block0: conv0.kernel[K][1][C], conv0.bias[C], conv1.kernel[K][C][C], conv1.bias[C],
+ *           matching.kernel[1][1][C], matching.bias[C];
+ *   block i>0: conv0.kernel[K][C][C], bias[C], conv1.kernel[K][C][C], bias[C];
+ *   dense.kernel[C][H], dense.bias[H]; dense_1.kernel[H][5], dense_1.bias[5].
+ * Geometry is fixed to radian/models/sig2seq.yaml:34-49 (C=256, K=3, H=128, 5 classes); the number
+ * of blocks and their dilations come from the header. */
+typedef struct rd_weights_header {
+    uint32_t magic;      /* 'RDNW' = 0x574e4452 */
+    uint32_t version;    /* 1 */
+    uint32_t nb_filters; /* 256 */
+    uint32_t kernel_size;/* 3 */
+    uint32_t relu_units; /* 128 */
+    uint32_t n_classes;  /* 5 */
+    uint32_t n_blocks;   /* len(dilations) * nb_stacks, <= 16 */
+    uint32_t dilations[16];
+    uint32_t n_floats;   /* number of float32 values that follow */
+} rd_weights_header;
+int rd_load_weights(rd_ctx* ctx, const void* blob, size_t nbytes);
+
+/* Replaces the RNA-model dict built at radian/basecall.py:48-57 and read at decode.py:83.
+ * table[ctx][4] doubles, ctx = base-4 number of the k context labels, oldest label most
+ * significant (the JSON key string read left to right).  k = --context-len, 1..13.
+ * Passing table == NULL unloads the LM. */
+int rd_load_lm(rd_ctx* ctx, const double* table, int k);
+
+/* ---- the five seams, host-pointer form ----------------------------------------------------- */
+/* sig_model.predict(windows) -- radian/basecall.py:91,93.
+ * windows [n_windows][chunk_len] float32 (MAD-normalised) -> probs [n_windows][chunk_len][5] float32. */
+int rd_forward(rd_ctx* ctx, const float* windows, int n_windows, int chunk_len, float* probs);
+
+/* assemble_matrices(matrices, step_size) after matrices[-1] = matrices[-1][:-pad]
+ * -- radian/basecall.py:96,100; radian/matrix_assembly.py:6-53.
+ * probs [n_windows][chunk_len][5] float32 of ONE read; out receives [*n_rows][5] float64
+ * (capacity out_cap rows); *is_f64 reports the reference's result dtype (float64 when any time step
+ * is covered by more than one window, else float32 -- the values are exact either way). */
+int rd_assemble(rd_ctx* ctx, const float* probs, int n_windows, int chunk_len, int pad, int step, double* out,
+                int64_t out_cap, int64_t* n_rows, int* is_f64);
+
+/* beam_search(mat, 'ACGT', beam_width, lm, s_threshold, r_threshold, len_context, cache)
+ * -- radian/basecall.py:102-109 (global) and :113-120 (chunk); radian/decode.py:100-212.
+ * A batch of independent sequences over concatenated probability rows:
+ *   probs      rows [*][5], float32 (prob_is_f64=0) or float64 (1)
+ *   seq_off[i] first row of sequence i, seq_len[i] its number of rows (0 allowed)
+ *   use_lm     0: lm=None (chunk mode); 1: use the table from rd_load_lm with thresholds s_thr/r_thr
+ *   labels_out receives sequence i's labels at labels_out + label_off[i] (capacity >= seq_len[i]),
+ *   label_len[i] its length; best_score (nullable) the winner's log pr_total. */
+int rd_decode_batch(rd_ctx* ctx, const void* probs, int prob_is_f64, const int64_t* seq_off, const int32_t* seq_len,
+                    int n_seq, int beam_width, int use_lm, double s_thr, double r_thr, uint8_t* labels_out,
+                    const int64_t* label_off, int32_t* label_len, double* best_score);
+
+/* ---- fused paths (probabilities never leave HBM) ------------------------------------------- */
+/* chunk mode, radian/basecall.py:86-96,110-121 for a batch of windows that may span many reads:
+ * forward, then an LM-free beam search of each window over its first valid_len[i] rows
+ * (chunk_len, or chunk_len - pad for the last window of a read).  Labels of window i are written
+ * at labels_out + i*chunk_len.  simple_assembly (basecall.py:122-123) stays on the host. */
+int rd_basecall_chunk(rd_ctx* ctx, const float* windows, int n_windows, int chunk_len, const int32_t* valid_len,
+                      int beam_width, uint8_t* labels_out, int32_t* label_len);
+
+/* global mode, radian/basecall.py:86-109 for a batch of reads: forward over all windows, per-read
+ * assembly, one LM-gated beam search per read.
+ *   read_win_off[r] first window of read r (n_reads+1 entries), pad[r] the zero padding of its last
+ *   window, step the window step; labels of read r at labels_out + label_off[r]
+ *   (capacity >= assembled length = (nW_r-1)*step + chunk_len - pad[r]). */
+int rd_basecall_global(rd_ctx* ctx, const float* windows, int chunk_len, int step, const int32_t* read_win_off,
+                       const int32_t* pad, int n_reads, int beam_width, int use_lm, double s_thr, double r_thr,
+                       uint8_t* labels_out, const int64_t* label_off, int32_t* label_len);
+
+/* ---- device-resident form (inputs already in HBM; used by bench.py and by pipelined hosts) -- */
+int rd_dev_alloc(rd_ctx* ctx, size_t bytes, void** d_ptr);
+int rd_dev_free(rd_ctx* ctx, void* d_ptr);
+int rd_memcpy_h2d(rd_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int rd_memcpy_d2h(rd_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+/* same contract as rd_forward / rd_basecall_chunk with d_windows resident; d_probs may be NULL
+ * (internal workspace).  Asynchronous on the context stream except for the label copy-out. */
+int rd_forward_resident(rd_ctx* ctx, const float* d_windows, int n_windows, int chunk_len, float* d_probs);
+int rd_basecall_chunk_resident(rd_ctx* ctx, const float* d_windows, int n_windows, int chunk_len,
+                               const int32_t* valid_len, int beam_width, uint8_t* labels_out, int32_t* label_len);
+int rd_decode_resident(rd_ctx* ctx, const float* d_probs, int n_windows, int chunk_len, const int32_t* valid_len,
+                       int beam_width, uint8_t* labels_out, int32_t* label_len);
+
+/* ---- kernel timing on the launch stream (HIP events) --------------------------------------- */
+#define RD_TIMER_CONV 0   /* dilated conv 256->256 (MFMA), the dominant kernel */
+#define RD_TIMER_DECODE 1 /* beam search */
+#define RD_TIMER_HEAD 2   /* dense head + softmax */
+#define RD_TIMER_IN 3     /* block-0 first conv (C_in = 1) */
+int rd_timer_enable(rd_ctx* ctx, int which, int max_launches); /* 0 disables */
+int rd_timer_read(rd_ctx* ctx, int which, double* total_ms, int* launches, double* flops, double* bytes);
+
+/* ---- multi-GPU start-up: one RCCL broadcast of weights + LM table over xGMI ------------------- */
+int rd_rccl_unique_id(uint8_t id_out[128]);                       /* rank 0, then shared out of band */
+int rd_rccl_init(rd_ctx* ctx, int rank, int nranks, const uint8_t id[128]);
+int rd_rccl_bcast_model(rd_ctx* ctx, int root);                   /* weights (+ LM when loaded on root) */
+int rd_rccl_allreduce_max(rd_ctx* ctx, double* inout, int n);     /* host values, max over ranks */
+int rd_rccl_barrier(rd_ctx* ctx);
+int rd_rccl_finalize(rd_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADIAN_HIP_H */

@@ -1,0 +1,70 @@
+"""ctypes binding of libradian_hip.so (include/radian_hip.h).  Fails loudly when the library is missing."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libradian_hip.so")
+
+c_i = ctypes.c_int
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64 = ctypes.c_int64
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_d = ctypes.c_double
+c_dp = ctypes.POINTER(ctypes.c_double)
+c_fp = ctypes.POINTER(ctypes.c_float)
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_vp = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+
+# every symbol include/radian_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "rd_last_error": (ctypes.c_char_p, []),
+    "rd_version": (c_i, []),
+    "rd_device_count": (c_i, [ctypes.POINTER(c_i)]),
+    "rd_decode_max_width": (c_i, []),
+    "rd_create": (c_i, [c_i, ctypes.POINTER(c_vp)]),
+    "rd_destroy": (c_i, [c_vp]),
+    "rd_sync": (c_i, [c_vp]),
+    "rd_load_weights": (c_i, [c_vp, c_vp, c_sz]),
+    "rd_load_lm": (c_i, [c_vp, c_vp, c_i]),
+    "rd_forward": (c_i, [c_vp, c_vp, c_i, c_i, c_vp]),
+    "rd_assemble": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_i64, c_i64p, ctypes.POINTER(c_i)]),
+    "rd_decode_batch": (c_i, [c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp, c_vp]),
+    "rd_basecall_chunk": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_i, c_vp, c_vp]),
+    "rd_basecall_global": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_vp, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp]),
+    "rd_dev_alloc": (c_i, [c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "rd_dev_free": (c_i, [c_vp, c_vp]),
+    "rd_memcpy_h2d": (c_i, [c_vp, c_vp, c_vp, c_sz]),
+    "rd_memcpy_d2h": (c_i, [c_vp, c_vp, c_vp, c_sz]),
+    "rd_forward_resident": (c_i, [c_vp, c_vp, c_i, c_i, c_vp]),
+    "rd_basecall_chunk_resident": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_i, c_vp, c_vp]),
+    "rd_decode_resident": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_i, c_vp, c_vp]),
+    "rd_timer_enable": (c_i, [c_vp, c_i, c_i]),
+    "rd_timer_read": (c_i, [c_vp, c_i, c_dp, ctypes.POINTER(c_i), c_dp, c_dp]),
+    "rd_rccl_unique_id": (c_i, [c_vp]),
+    "rd_rccl_init": (c_i, [c_vp, c_i, c_i, c_vp]),
+    "rd_rccl_bcast_model": (c_i, [c_vp, c_i]),
+    "rd_rccl_allreduce_max": (c_i, [c_vp, c_vp, c_i]),
+    "rd_rccl_barrier": (c_i, [c_vp]),
+    "rd_rccl_finalize": (c_i, [c_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and bind every declared symbol.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m radian_amd.build` (hipcc --offload-arch=gfx950). "
+            "radian_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

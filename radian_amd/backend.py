@@ -1,0 +1,221 @@
+"""Python face of the C ABI: one Backend == one rd_ctx == one GPU rank."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .weights import pack_blob, DEFAULT_DILATIONS
+
+RD_TIMER_CONV, RD_TIMER_DECODE, RD_TIMER_HEAD, RD_TIMER_IN = 0, 1, 2, 3
+
+
+class RadianHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _lib.LIB_PATH
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Backend:
+    """Owns an rd_ctx.  All compute goes to the HIP library; nothing here falls back to the CPU."""
+
+    def __init__(self, device_id=0):
+        self._L = _lib.load()
+        h = ctypes.c_void_p()
+        self._h = None
+        self._check(self._L.rd_create(int(device_id), ctypes.byref(h)))
+        self._h = h
+        self.device_id = device_id
+        self.lm_k = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise RadianHipError(f"[rd error {rc}] " + self._L.rd_last_error().decode("utf-8", "replace"))
+
+    def close(self):
+        if self._h is not None:
+            self._L.rd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sync(self):
+        self._check(self._L.rd_sync(self._h))
+
+    @property
+    def max_beam_width(self):
+        return self._L.rd_decode_max_width()
+
+    # ------------------------------------------------------------------ artefacts
+    def load_weights(self, flat, dilations=DEFAULT_DILATIONS):
+        """model.load_weights (radian/model.py:44): flat float32 parameters in Keras order."""
+        blob = pack_blob(flat, dilations)
+        self.load_weights_blob(blob)
+
+    def load_weights_blob(self, blob):
+        buf = ctypes.create_string_buffer(blob, len(blob))
+        self._check(self._L.rd_load_weights(self._h, ctypes.cast(buf, ctypes.c_void_p), len(blob)))
+
+    def load_lm(self, table, k):
+        """Dense LM table [4^k,4] float64 (radian/basecall.py:48-57); None unloads."""
+        if table is None:
+            self._check(self._L.rd_load_lm(self._h, None, 0))
+            self.lm_k = None
+            return
+        table = np.ascontiguousarray(table, dtype=np.float64)
+        if table.shape != (4 ** k, 4):
+            raise ValueError(f"LM table must be [4^{k},4], got {table.shape}")
+        self._check(self._L.rd_load_lm(self._h, _p(table), int(k)))
+        self.lm_k = k
+
+    # ------------------------------------------------------------------ seams (host arrays)
+    def forward(self, windows):
+        """sig_model.predict (radian/basecall.py:91,93): [n,T] -> [n,T,5] float32."""
+        windows = np.ascontiguousarray(windows, dtype=np.float32)
+        if windows.ndim != 2:
+            raise ValueError("windows must be [n_windows, chunk_len]")
+        n, T = windows.shape
+        probs = np.empty((n, T, 5), dtype=np.float32)
+        self._check(self._L.rd_forward(self._h, _p(windows), n, T, _p(probs)))
+        return probs
+
+    def assemble(self, probs, pad, step):
+        """assemble_matrices after the pad trim (radian/basecall.py:96,100).  probs [nW,T,5] of one read."""
+        probs = np.ascontiguousarray(probs, dtype=np.float32)
+        nW, T, _ = probs.shape
+        cap = (nW - 1) * step + T
+        out = np.empty((max(cap, 1), 5), dtype=np.float64)
+        n_rows = ctypes.c_int64(0)
+        is64 = ctypes.c_int(0)
+        self._check(self._L.rd_assemble(self._h, _p(probs), nW, T, int(pad), int(step), _p(out), out.shape[0],
+                                        ctypes.byref(n_rows), ctypes.byref(is64)))
+        out = out[: n_rows.value]
+        return out if is64.value else out.astype(np.float32)
+
+    def decode_batch(self, mats, seq_off, seq_len, beam_width, use_lm=False, s_threshold=0.0, r_threshold=0.0,
+                     with_scores=False):
+        """beam_search over a batch of sequences given as concatenated rows (radian/decode.py:100-212).
+        Returns a list of uint8 label arrays (and the winners' log pr_total when with_scores)."""
+        mats = np.ascontiguousarray(mats)
+        if mats.dtype not in (np.float32, np.float64):
+            raise TypeError("probabilities must be float32 or float64")
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+        seq_len = np.ascontiguousarray(seq_len, dtype=np.int32)
+        n = int(seq_len.shape[0])
+        label_off = np.zeros(n, dtype=np.int64)
+        if n:
+            label_off[1:] = np.cumsum(seq_len[:-1].astype(np.int64))
+        labels = np.zeros(int(seq_len.astype(np.int64).sum()) + 1, dtype=np.uint8)
+        lens = np.zeros(n, dtype=np.int32)
+        scores = np.zeros(n, dtype=np.float64) if with_scores else None
+        self._check(self._L.rd_decode_batch(self._h, _p(mats), 1 if mats.dtype == np.float64 else 0, _p(seq_off), _p(seq_len), n,
+                                            int(beam_width), 1 if use_lm else 0, float(s_threshold), float(r_threshold),
+                                            _p(labels), _p(label_off), _p(lens), _p(scores)))
+        out = [labels[label_off[i]: label_off[i] + lens[i]].copy() for i in range(n)]
+        return (out, scores) if with_scores else out
+
+    def decode(self, mat, beam_width, use_lm=False, s_threshold=0.0, r_threshold=0.0):
+        mat = np.ascontiguousarray(mat)
+        return self.decode_batch(mat.reshape(-1, 5), [0], [mat.shape[0]], beam_width, use_lm, s_threshold, r_threshold)[0]
+
+    # ------------------------------------------------------------------ fused paths
+    def basecall_chunk(self, windows, valid_len, beam_width):
+        """forward + LM-free per-window beam search (radian/basecall.py:86-96,110-121)."""
+        windows = np.ascontiguousarray(windows, dtype=np.float32)
+        n, T = windows.shape
+        valid_len = np.ascontiguousarray(valid_len, dtype=np.int32)
+        labels = np.zeros((n, T), dtype=np.uint8)
+        lens = np.zeros(n, dtype=np.int32)
+        self._check(self._L.rd_basecall_chunk(self._h, _p(windows), n, T, _p(valid_len), int(beam_width), _p(labels), _p(lens)))
+        return [labels[i, : lens[i]].copy() for i in range(n)]
+
+    def basecall_global(self, windows, read_win_off, pads, step, beam_width, use_lm, s_threshold=0.0, r_threshold=0.0):
+        """forward + per-read assembly + one beam search per read (radian/basecall.py:86-109)."""
+        windows = np.ascontiguousarray(windows, dtype=np.float32)
+        nW, T = windows.shape
+        read_win_off = np.ascontiguousarray(read_win_off, dtype=np.int32)
+        pads = np.ascontiguousarray(pads, dtype=np.int32)
+        n_reads = pads.shape[0]
+        caps = np.array([(read_win_off[r + 1] - read_win_off[r] - 1) * step + T - pads[r] for r in range(n_reads)], dtype=np.int64)
+        caps = np.maximum(caps, 0)
+        label_off = np.zeros(n_reads, dtype=np.int64)
+        label_off[1:] = np.cumsum(caps[:-1])
+        labels = np.zeros(int(caps.sum()) + 1, dtype=np.uint8)
+        lens = np.zeros(n_reads, dtype=np.int32)
+        self._check(self._L.rd_basecall_global(self._h, _p(windows), T, int(step), _p(read_win_off), _p(pads), n_reads,
+                                               int(beam_width), 1 if use_lm else 0, float(s_threshold), float(r_threshold),
+                                               _p(labels), _p(label_off), _p(lens)))
+        return [labels[label_off[r]: label_off[r] + lens[r]].copy() for r in range(n_reads)]
+
+    # ------------------------------------------------------------------ device-resident (bench)
+    def dev_alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        self._check(self._L.rd_dev_alloc(self._h, int(nbytes), ctypes.byref(p)))
+        return p
+
+    def dev_free(self, p):
+        self._check(self._L.rd_dev_free(self._h, p))
+
+    def h2d(self, d_ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._check(self._L.rd_memcpy_h2d(self._h, d_ptr, _p(arr), arr.nbytes))
+
+    def d2h(self, arr, d_ptr):
+        self._check(self._L.rd_memcpy_d2h(self._h, _p(arr), d_ptr, arr.nbytes))
+
+    def forward_resident(self, d_windows, n, T, d_probs=None):
+        self._check(self._L.rd_forward_resident(self._h, d_windows, n, T, d_probs))
+
+    def basecall_chunk_resident(self, d_windows, n, T, valid_len, beam_width, labels, lens):
+        self._check(self._L.rd_basecall_chunk_resident(self._h, d_windows, n, T, _p(valid_len), int(beam_width), _p(labels), _p(lens)))
+
+    def decode_resident(self, d_probs, n, T, valid_len, beam_width, labels, lens):
+        self._check(self._L.rd_decode_resident(self._h, d_probs, n, T, _p(valid_len), int(beam_width), _p(labels), _p(lens)))
+
+    def timer_enable(self, which, max_launches):
+        self._check(self._L.rd_timer_enable(self._h, which, max_launches))
+
+    def timer_read(self, which):
+        ms = ctypes.c_double()
+        n = ctypes.c_int()
+        fl = ctypes.c_double()
+        by = ctypes.c_double()
+        self._check(self._L.rd_timer_read(self._h, which, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by)))
+        return {"total_ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+
+    # ------------------------------------------------------------------ multi-GPU start-up
+    def rccl_unique_id(self):
+        buf = (ctypes.c_uint8 * 128)()
+        self._check(self._L.rd_rccl_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+        return bytes(buf)
+
+    def rccl_init(self, rank, nranks, uid):
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(uid)
+        self._check(self._L.rd_rccl_init(self._h, rank, nranks, ctypes.cast(buf, ctypes.c_void_p)))
+
+    def rccl_bcast_model(self, root=0):
+        self._check(self._L.rd_rccl_bcast_model(self._h, root))
+
+    def rccl_allreduce_max(self, values):
+        a = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._check(self._L.rd_rccl_allreduce_max(self._h, _p(a), a.size))
+        return a
+
+    def rccl_barrier(self):
+        self._check(self._L.rd_rccl_barrier(self._h))

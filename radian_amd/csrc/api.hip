@@ -1,0 +1,881 @@
+// api.hip -- the C ABI of libradian_hip.so (declared in include/radian_hip.h).
+// Context, artefact loading/repacking, host-pointer wrappers around the device paths, fused paths,
+// kernel timers and the RCCL start-up broadcast.
+#include "common.h"
+#include "../../include/radian_hip.h"
+
+#include <dlfcn.h>
+#include <math.h>
+#include <rccl/rccl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+// --------------------------------------------------------------------------------------------- errors
+static thread_local char g_err[1024] = "";
+
+void rd_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* rd_last_error(void) { return g_err; }
+extern "C" int rd_version(void) { return 1; }
+
+int DevBuf::reserve(size_t bytes)
+{
+    if (bytes <= cap) return 0;
+    size_t want = align_up(bytes + bytes / 8, 1 << 20);
+    void* np = nullptr;
+    if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    hipError_t e = hipMalloc(&np, want);
+    if (e != hipSuccess) {
+        rd_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        return -1;
+    }
+    p = np;
+    cap = want;
+    return 0;
+}
+
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+extern "C" int rd_device_count(int* n)
+{
+    RD_REQUIRE(n != nullptr, "rd_device_count: null argument");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        rd_set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return RD_ERR_HIP;
+    }
+    *n = c;
+    return RD_OK;
+}
+
+
+// --------------------------------------------------------------------------------------------- context
+extern "C" int rd_create(int device_id, rd_ctx** out)
+{
+    RD_REQUIRE(out != nullptr, "rd_create: null out pointer");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        rd_set_error("rd_create: no HIP device available (%s); this backend has no CPU fallback",
+                     e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return RD_ERR_HIP;
+    }
+    RD_REQUIRE(device_id >= 0 && device_id < n, "rd_create: device_id %d out of range [0,%d)", device_id, n);
+    RD_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    RD_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        rd_set_error("rd_create: device %d is %s; libradian_hip is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+        return RD_ERR_HIP;
+    }
+    rd_ctx* ctx = new rd_ctx();
+    ctx->device = device_id;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        rd_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return RD_ERR_HIP;
+    }
+    *out = ctx;
+    return RD_OK;
+}
+
+static void timer_free(KernelTimer& t)
+{
+    for (auto ev : t.starts) (void)hipEventDestroy(ev);
+    for (auto ev : t.stops) (void)hipEventDestroy(ev);
+    t.starts.clear();
+    t.stops.clear();
+    t.used = 0;
+    t.enabled = false;
+}
+
+extern "C" int rd_rccl_finalize(rd_ctx* ctx);
+
+extern "C" int rd_destroy(rd_ctx* ctx)
+{
+    if (!ctx) return RD_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    rd_rccl_finalize(ctx);
+    timer_free(ctx->timer_conv);
+    timer_free(ctx->timer_decode);
+    timer_free(ctx->timer_head);
+    timer_free(ctx->timer_in);
+    DevBuf* bufs[] = {&ctx->ws_in, &ctx->ws_act0, &ctx->ws_act1, &ctx->ws_probs, &ctx->ws_mat, &ctx->ws_seq,
+                      &ctx->ws_nodes_child, &ctx->ws_nodes_back, &ctx->ws_labels, &ctx->ws_misc, &ctx->model.storage,
+                      &ctx->lm.storage, &ctx->lm.gate_storage};
+    for (DevBuf* b : bufs) b->release();
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RD_OK;
+}
+
+extern "C" int rd_sync(rd_ctx* ctx)
+{
+    RD_REQUIRE(ctx, "rd_sync: null context");
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    return RD_OK;
+}
+
+// --------------------------------------------------------------------------------------------- weights
+namespace {
+
+constexpr size_t CONV_PK = (size_t)RD_K * RD_C * RD_C;  // 196608 floats
+constexpr size_t D1_PK = (size_t)RD_C * RD_H;
+
+struct ModelLayout {
+    size_t w_in, b_in, w_match, b_match, w_conv[2 * RD_MAX_BLOCKS], b_conv[2 * RD_MAX_BLOCKS], w_d1, b_d1, w_d2, b_d2, total;
+};
+
+ModelLayout model_layout(int nblocks)
+{
+    ModelLayout L = {};
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        size_t o = off;
+        off += align_up(n, 64);
+        return o;
+    };
+    L.w_in = take(RD_K * RD_C);
+    L.b_in = take(RD_C);
+    L.w_match = take(RD_C);
+    L.b_match = take(RD_C);
+    for (int b = 0; b < nblocks; b++)
+        for (int w = 0; w < 2; w++) {
+            if (b == 0 && w == 0) continue;
+            L.w_conv[2 * b + w] = take(CONV_PK);
+            L.b_conv[2 * b + w] = take(RD_C);
+        }
+    L.w_d1 = take(D1_PK);
+    L.b_d1 = take(RD_H);
+    L.w_d2 = take(RD_H * RD_NCLS);
+    L.b_d2 = take(RD_NCLS);
+    L.total = off;
+    return L;
+}
+
+void model_bind(Model& m, const ModelLayout& L)
+{
+    float* base = m.storage.as<float>();
+    m.w_in = base + L.w_in;
+    m.b_in = base + L.b_in;
+    m.w_match = base + L.w_match;
+    m.b_match = base + L.b_match;
+    for (int b = 0; b < m.nblocks; b++)
+        for (int w = 0; w < 2; w++) {
+            if (b == 0 && w == 0) continue;
+            m.w_conv[2 * b + w] = base + L.w_conv[2 * b + w];
+            m.b_conv[2 * b + w] = base + L.b_conv[2 * b + w];
+        }
+    m.w_d1 = base + L.w_d1;
+    m.b_d1 = base + L.b_d1;
+    m.w_d2 = base + L.w_d2;
+    m.b_d2 = base + L.b_d2;
+}
+
+// Keras conv kernel [j][ci][co] -> [chunk = j*8 + ci/32][co][ci%32]
+void pack_conv(const float* k, float* dst)
+{
+    for (int j = 0; j < RD_K; j++)
+        for (int ci = 0; ci < RD_C; ci++) {
+            const float* src = k + ((size_t)j * RD_C + ci) * RD_C;
+            const int chunk = j * (RD_C / 32) + ci / 32;
+            float* d = dst + (size_t)chunk * RD_C * 32 + (ci % 32);
+            for (int co = 0; co < RD_C; co++) d[(size_t)co * 32] = src[co];
+        }
+}
+
+// Keras dense kernel [ci][h] -> [chunk = ci/32][h][ci%32]
+void pack_dense(const float* k, float* dst)
+{
+    for (int ci = 0; ci < RD_C; ci++) {
+        const float* src = k + (size_t)ci * RD_H;
+        float* d = dst + (size_t)(ci / 32) * RD_H * 32 + (ci % 32);
+        for (int h = 0; h < RD_H; h++) d[(size_t)h * 32] = src[h];
+    }
+}
+
+}  // namespace
+
+extern "C" int rd_load_weights(rd_ctx* ctx, const void* blob, size_t nbytes)
+{
+    RD_REQUIRE(ctx && blob, "rd_load_weights: null argument");
+    RD_REQUIRE(nbytes >= sizeof(rd_weights_header), "rd_load_weights: blob too small (%zu bytes)", nbytes);
+    rd_weights_header h;
+    memcpy(&h, blob, sizeof(h));
+    RD_REQUIRE(h.magic == 0x574e4452u, "rd_load_weights: bad magic 0x%08x", h.magic);
+    RD_REQUIRE(h.version == 1, "rd_load_weights: unsupported version %u", h.version);
+    RD_REQUIRE(h.nb_filters == RD_C && h.kernel_size == RD_K && h.relu_units == RD_H && h.n_classes == RD_NCLS,
+               "rd_load_weights: geometry (%u filters, k=%u, %u relu units, %u classes) is not sig2seq.yaml's (256,3,128,5)",
+               h.nb_filters, h.kernel_size, h.relu_units, h.n_classes);
+    RD_REQUIRE(h.n_blocks >= 1 && h.n_blocks <= RD_MAX_BLOCKS, "rd_load_weights: n_blocks %u out of range", h.n_blocks);
+    const int nb = (int)h.n_blocks;
+    size_t expect = (size_t)RD_K * RD_C + RD_C + CONV_PK + RD_C + RD_C + RD_C;
+    expect += (size_t)(nb - 1) * 2 * (CONV_PK + RD_C);
+    expect += D1_PK + RD_H + (size_t)RD_H * RD_NCLS + RD_NCLS;
+    RD_REQUIRE(h.n_floats == expect, "rd_load_weights: header says %u floats, geometry needs %zu", h.n_floats, expect);
+    RD_REQUIRE(nbytes == sizeof(h) + expect * sizeof(float), "rd_load_weights: blob is %zu bytes, expected %zu", nbytes,
+               sizeof(h) + expect * sizeof(float));
+    for (int b = 0; b < nb; b++) RD_REQUIRE(h.dilations[b] >= 1 && h.dilations[b] <= 4096, "rd_load_weights: bad dilation");
+    const float* w = (const float*)((const char*)blob + sizeof(h));
+
+    RD_HIP(hipSetDevice(ctx->device));
+    Model& m = ctx->model;
+    m.loaded = false;
+    m.nblocks = nb;
+    for (int b = 0; b < nb; b++) m.dil[b] = (int)h.dilations[b];
+    ModelLayout L = model_layout(nb);
+    std::vector<float> host(L.total, 0.f);
+    size_t off = 0;
+    for (int b = 0; b < nb; b++) {
+        if (b == 0) {
+            memcpy(&host[L.w_in], w + off, sizeof(float) * RD_K * RD_C);
+            off += RD_K * RD_C;
+            memcpy(&host[L.b_in], w + off, sizeof(float) * RD_C);
+            off += RD_C;
+        } else {
+            pack_conv(w + off, &host[L.w_conv[2 * b]]);
+            off += CONV_PK;
+            memcpy(&host[L.b_conv[2 * b]], w + off, sizeof(float) * RD_C);
+            off += RD_C;
+        }
+        pack_conv(w + off, &host[L.w_conv[2 * b + 1]]);
+        off += CONV_PK;
+        memcpy(&host[L.b_conv[2 * b + 1]], w + off, sizeof(float) * RD_C);
+        off += RD_C;
+        if (b == 0) {
+            memcpy(&host[L.w_match], w + off, sizeof(float) * RD_C);
+            off += RD_C;
+            memcpy(&host[L.b_match], w + off, sizeof(float) * RD_C);
+            off += RD_C;
+        }
+    }
+    pack_dense(w + off, &host[L.w_d1]);
+    off += D1_PK;
+    memcpy(&host[L.b_d1], w + off, sizeof(float) * RD_H);
+    off += RD_H;
+    memcpy(&host[L.w_d2], w + off, sizeof(float) * RD_H * RD_NCLS);
+    off += RD_H * RD_NCLS;
+    memcpy(&host[L.b_d2], w + off, sizeof(float) * RD_NCLS);
+    off += RD_NCLS;
+    if (off != expect) {
+        rd_set_error("rd_load_weights: internal size mismatch");
+        return RD_ERR_ARG;
+    }
+    if (m.storage.reserve(L.total * sizeof(float))) return RD_ERR_NOMEM;
+    RD_HIP(hipMemcpy(m.storage.p, host.data(), L.total * sizeof(float), hipMemcpyHostToDevice));
+    model_bind(m, L);
+    m.loaded = true;
+    return RD_OK;
+}
+
+// --------------------------------------------------------------------------------------------- LM
+static void lm_bind(LM& lm)
+{
+    const size_t n = (size_t)1 << (2 * lm.k);
+    lm.table = lm.storage.as<double>();
+    lm.d_entropy = lm.table + n * 4;
+}
+
+extern "C" int rd_load_lm(rd_ctx* ctx, const double* table, int k)
+{
+    RD_REQUIRE(ctx, "rd_load_lm: null context");
+    LM& lm = ctx->lm;
+    lm.loaded = false;
+    lm.gate_valid = false;
+    if (!table) return RD_OK;
+    RD_REQUIRE(k >= 1 && k <= 13, "rd_load_lm: context length %d out of range [1,13]", k);
+    RD_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << (2 * k);
+    // per-context entropy, decode.py:73-76,85-90 (math.log == glibc log; python sum is left-assoc)
+    std::vector<double> ent(n);
+    for (size_t c = 0; c < n; c++) {
+        const double* d = table + c * 4;
+        double s = 0.0;
+        bool any = false;
+        for (int i = 0; i < 4; i++)
+            if (d[i] > 0) {
+                double v = d[i] * log(d[i]);
+                s = any ? s + v : v;
+                any = true;
+            }
+        ent[c] = any ? -s : 0.0;
+    }
+    lm.k = k;
+    if (lm.storage.reserve(n * 5 * sizeof(double))) return RD_ERR_NOMEM;
+    lm_bind(lm);
+    RD_HIP(hipMemcpy(lm.table, table, n * 4 * sizeof(double), hipMemcpyHostToDevice));
+    RD_HIP(hipMemcpy(lm.d_entropy, ent.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    lm.loaded = true;
+    return RD_OK;
+}
+
+// --------------------------------------------------------------------------------------------- helpers
+namespace {
+
+struct SeqMeta {
+    // device pointers inside ctx->ws_seq
+    int64_t *d_seq_off, *d_node_off, *d_label_off;
+    int32_t *d_seq_len, *d_label_len;
+    double* d_score;
+    int64_t total_nodes, total_labels;
+};
+
+// uploads per-sequence metadata; label_off_host may be null (then packed prefix sums are used)
+int prepare_seq_meta(rd_ctx* ctx, const int64_t* seq_off, const int32_t* seq_len, int n_seq, int W, const int64_t* label_off_host,
+                     int64_t label_total_host, SeqMeta& sm, std::vector<int64_t>& label_off_used)
+{
+    std::vector<int64_t> node_off(n_seq), lab_off(n_seq);
+    int64_t nodes = 0, labs = 0;
+    for (int i = 0; i < n_seq; i++) {
+        RD_REQUIRE(seq_len[i] >= 0, "decode: negative sequence length at %d", i);
+        node_off[i] = nodes;
+        nodes += 1 + (int64_t)W * seq_len[i];
+        lab_off[i] = labs;
+        labs += seq_len[i];
+    }
+    (void)label_off_host;
+    (void)label_total_host;
+    label_off_used = lab_off;
+    const size_t n = (size_t)n_seq;
+    size_t bytes = align_up(n * 8, 256) * 3 + align_up(n * 4, 256) * 2 + align_up(n * 8, 256);
+    if (ctx->ws_seq.reserve(bytes)) return RD_ERR_NOMEM;
+    char* p = (char*)ctx->ws_seq.p;
+    sm.d_seq_off = (int64_t*)p; p += align_up(n * 8, 256);
+    sm.d_node_off = (int64_t*)p; p += align_up(n * 8, 256);
+    sm.d_label_off = (int64_t*)p; p += align_up(n * 8, 256);
+    sm.d_seq_len = (int32_t*)p; p += align_up(n * 4, 256);
+    sm.d_label_len = (int32_t*)p; p += align_up(n * 4, 256);
+    sm.d_score = (double*)p;
+    sm.total_nodes = nodes;
+    sm.total_labels = labs;
+    RD_HIP(hipMemcpyAsync(sm.d_seq_off, seq_off, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    RD_HIP(hipMemcpyAsync(sm.d_seq_len, seq_len, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    RD_HIP(hipMemcpyAsync(sm.d_node_off, node_off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+    RD_HIP(hipMemcpyAsync(sm.d_label_off, lab_off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+    // the host vectors must outlive the async copies
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    return RD_OK;
+}
+
+// decode sequences over device rows and deliver labels to host buffers
+int decode_and_fetch(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* seq_off, const int32_t* seq_len, int n_seq,
+                     int W, int use_lm, double s_thr, double r_thr, uint8_t* labels_out, const int64_t* label_off,
+                     int32_t* label_len, double* best_score)
+{
+    if (n_seq == 0) return RD_OK;
+    SeqMeta sm;
+    std::vector<int64_t> lab_off;
+    int rc = prepare_seq_meta(ctx, seq_off, seq_len, n_seq, W, nullptr, 0, sm, lab_off);
+    if (rc) return rc;
+    if (ctx->ws_labels.reserve((size_t)sm.total_labels + 16)) return RD_ERR_NOMEM;
+    uint8_t* d_labels = ctx->ws_labels.as<uint8_t>();
+    rc = rd_decode_dev(ctx, d_probs, is_f64, sm.d_seq_off, sm.d_seq_len, sm.d_node_off, sm.d_label_off, n_seq, sm.total_nodes, W,
+                       use_lm, s_thr, r_thr, d_labels, sm.d_label_len, best_score ? sm.d_score : nullptr);
+    if (rc) return rc;
+    std::vector<uint8_t> hl((size_t)sm.total_labels + 16);
+    RD_HIP(hipMemcpyAsync(hl.data(), d_labels, (size_t)sm.total_labels, hipMemcpyDeviceToHost, ctx->stream));
+    RD_HIP(hipMemcpyAsync(label_len, sm.d_label_len, (size_t)n_seq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (best_score) RD_HIP(hipMemcpyAsync(best_score, sm.d_score, (size_t)n_seq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n_seq; i++) {
+        if (label_len[i] < 0 || label_len[i] > seq_len[i]) {
+            rd_set_error("decode: sequence %d produced an impossible label length %d (rows %d)", i, label_len[i], seq_len[i]);
+            return RD_ERR_STATE;
+        }
+        if (label_len[i]) memcpy(labels_out + label_off[i], hl.data() + lab_off[i], (size_t)label_len[i]);
+    }
+    return RD_OK;
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------------- seams
+extern "C" int rd_forward(rd_ctx* ctx, const float* windows, int n_windows, int chunk_len, float* probs)
+{
+    RD_REQUIRE(ctx && (n_windows == 0 || (windows && probs)), "rd_forward: null argument");
+    RD_REQUIRE(n_windows >= 0 && chunk_len >= 1, "rd_forward: bad shape n_windows=%d chunk_len=%d", n_windows, chunk_len);
+    if (n_windows == 0) return RD_OK;
+    RD_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)n_windows * chunk_len;
+    if (ctx->ws_in.reserve(n * 4) || ctx->ws_probs.reserve(n * 20)) return RD_ERR_NOMEM;
+    RD_HIP(hipMemcpyAsync(ctx->ws_in.p, windows, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = rd_forward_dev(ctx, ctx->ws_in.as<float>(), n_windows, chunk_len, ctx->ws_probs.as<float>());
+    if (rc) return rc;
+    RD_HIP(hipMemcpyAsync(probs, ctx->ws_probs.p, n * 20, hipMemcpyDeviceToHost, ctx->stream));
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    return RD_OK;
+}
+
+static int64_t assembled_rows(int nW, int T, int pad, int step)
+{
+    int64_t N = 0;
+    for (int i = 0; i < nW; i++) {
+        int rows = (i == nW - 1) ? T - pad : T;
+        int64_t end = (int64_t)i * step + rows;
+        if (rows > 0 && end > N) N = end;
+    }
+    return N;
+}
+
+static int assembled_is_f64(int nW, int T, int pad, int step)
+{
+    // some time step is covered twice <=> a window i >= 1 with rows starts inside window i-1
+    if (step >= T) return 0;
+    if (nW >= 3) return 1;
+    if (nW == 2 && T - pad > 0) return 1;
+    return 0;
+}
+
+extern "C" int rd_assemble(rd_ctx* ctx, const float* probs, int n_windows, int chunk_len, int pad, int step, double* out,
+                           int64_t out_cap, int64_t* n_rows, int* is_f64)
+{
+    RD_REQUIRE(ctx && probs && out && n_rows, "rd_assemble: null argument");
+    RD_REQUIRE(n_windows >= 1 && chunk_len >= 1, "rd_assemble: bad shape");
+    RD_REQUIRE(step >= 1 && step <= chunk_len, "rd_assemble: step %d must be in [1, chunk_len]", step);
+    RD_REQUIRE(pad >= 0 && pad <= chunk_len, "rd_assemble: pad %d out of range", pad);
+    RD_HIP(hipSetDevice(ctx->device));
+    const int64_t N = assembled_rows(n_windows, chunk_len, pad, step);
+    RD_REQUIRE(N <= out_cap, "rd_assemble: output needs %lld rows, capacity %lld", (long long)N, (long long)out_cap);
+    const size_t nin = (size_t)n_windows * chunk_len * 5;
+    if (ctx->ws_probs.reserve(nin * 4) || ctx->ws_mat.reserve((size_t)(N + 1) * 40)) return RD_ERR_NOMEM;
+    RD_HIP(hipMemcpyAsync(ctx->ws_probs.p, probs, nin * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = rd_assemble_dev(ctx, ctx->ws_probs.as<float>(), n_windows, chunk_len, pad, step, ctx->ws_mat.as<double>(), N);
+    if (rc) return rc;
+    if (N) RD_HIP(hipMemcpyAsync(out, ctx->ws_mat.p, (size_t)N * 40, hipMemcpyDeviceToHost, ctx->stream));
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    *n_rows = N;
+    if (is_f64) *is_f64 = assembled_is_f64(n_windows, chunk_len, pad, step);
+    return RD_OK;
+}
+
+extern "C" int rd_decode_batch(rd_ctx* ctx, const void* probs, int prob_is_f64, const int64_t* seq_off, const int32_t* seq_len,
+                               int n_seq, int beam_width, int use_lm, double s_thr, double r_thr, uint8_t* labels_out,
+                               const int64_t* label_off, int32_t* label_len, double* best_score)
+{
+    RD_REQUIRE(ctx, "rd_decode_batch: null context");
+    RD_REQUIRE(n_seq >= 0, "rd_decode_batch: negative n_seq");
+    if (n_seq == 0) return RD_OK;
+    RD_REQUIRE(seq_off && seq_len && labels_out && label_off && label_len, "rd_decode_batch: null argument");
+    RD_REQUIRE(beam_width >= 1 && beam_width <= rd_decode_max_width(), "rd_decode_batch: beam_width %d out of range [1,%d]",
+               beam_width, rd_decode_max_width());
+    RD_HIP(hipSetDevice(ctx->device));
+    int64_t rows = 0;
+    for (int i = 0; i < n_seq; i++) {
+        RD_REQUIRE(seq_len[i] >= 0 && seq_off[i] >= 0, "rd_decode_batch: bad sequence %d", i);
+        if (seq_off[i] + seq_len[i] > rows) rows = seq_off[i] + seq_len[i];
+    }
+    RD_REQUIRE(rows == 0 || probs, "rd_decode_batch: null probs");
+    const size_t rb = prob_is_f64 ? 40 : 20;
+    if (ctx->ws_mat.reserve((size_t)(rows + 1) * rb)) return RD_ERR_NOMEM;
+    if (rows) RD_HIP(hipMemcpyAsync(ctx->ws_mat.p, probs, (size_t)rows * rb, hipMemcpyHostToDevice, ctx->stream));
+    return decode_and_fetch(ctx, ctx->ws_mat.p, prob_is_f64, seq_off, seq_len, n_seq, beam_width, use_lm, s_thr, r_thr, labels_out,
+                            label_off, label_len, best_score);
+}
+
+// --------------------------------------------------------------------------------------------- fused
+static int chunk_decode_from_probs(rd_ctx* ctx, const float* d_probs, int n_windows, int chunk_len, const int32_t* valid_len,
+                                   int beam_width, uint8_t* labels_out, int32_t* label_len)
+{
+    std::vector<int64_t> seq_off(n_windows), lab_off(n_windows);
+    for (int i = 0; i < n_windows; i++) {
+        RD_REQUIRE(valid_len[i] >= 0 && valid_len[i] <= chunk_len, "valid_len[%d]=%d out of range [0,%d]", i, valid_len[i], chunk_len);
+        seq_off[i] = (int64_t)i * chunk_len;
+        lab_off[i] = (int64_t)i * chunk_len;
+    }
+    return decode_and_fetch(ctx, d_probs, 0, seq_off.data(), valid_len, n_windows, beam_width, 0, 0.0, 0.0, labels_out, lab_off.data(),
+                            label_len, nullptr);
+}
+
+extern "C" int rd_basecall_chunk_resident(rd_ctx* ctx, const float* d_windows, int n_windows, int chunk_len,
+                                          const int32_t* valid_len, int beam_width, uint8_t* labels_out, int32_t* label_len)
+{
+    RD_REQUIRE(ctx && d_windows && valid_len && labels_out && label_len, "rd_basecall_chunk_resident: null argument");
+    RD_REQUIRE(n_windows >= 1 && chunk_len >= 1, "rd_basecall_chunk_resident: bad shape");
+    RD_REQUIRE(beam_width >= 1 && beam_width <= rd_decode_max_width(), "beam_width %d out of range", beam_width);
+    RD_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)n_windows * chunk_len;
+    if (ctx->ws_probs.reserve(n * 20)) return RD_ERR_NOMEM;
+    int rc = rd_forward_dev(ctx, d_windows, n_windows, chunk_len, ctx->ws_probs.as<float>());
+    if (rc) return rc;
+    return chunk_decode_from_probs(ctx, ctx->ws_probs.as<float>(), n_windows, chunk_len, valid_len, beam_width, labels_out, label_len);
+}
+
+extern "C" int rd_basecall_chunk(rd_ctx* ctx, const float* windows, int n_windows, int chunk_len, const int32_t* valid_len,
+                                 int beam_width, uint8_t* labels_out, int32_t* label_len)
+{
+    RD_REQUIRE(ctx && windows, "rd_basecall_chunk: null argument");
+    RD_REQUIRE(n_windows >= 1 && chunk_len >= 1, "rd_basecall_chunk: bad shape");
+    RD_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)n_windows * chunk_len;
+    if (ctx->ws_in.reserve(n * 4)) return RD_ERR_NOMEM;
+    RD_HIP(hipMemcpyAsync(ctx->ws_in.p, windows, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    return rd_basecall_chunk_resident(ctx, ctx->ws_in.as<float>(), n_windows, chunk_len, valid_len, beam_width, labels_out, label_len);
+}
+
+extern "C" int rd_decode_resident(rd_ctx* ctx, const float* d_probs, int n_windows, int chunk_len, const int32_t* valid_len,
+                                  int beam_width, uint8_t* labels_out, int32_t* label_len)
+{
+    RD_REQUIRE(ctx && d_probs && valid_len && labels_out && label_len, "rd_decode_resident: null argument");
+    RD_REQUIRE(beam_width >= 1 && beam_width <= rd_decode_max_width(), "beam_width %d out of range", beam_width);
+    RD_HIP(hipSetDevice(ctx->device));
+    return chunk_decode_from_probs(ctx, d_probs, n_windows, chunk_len, valid_len, beam_width, labels_out, label_len);
+}
+
+extern "C" int rd_forward_resident(rd_ctx* ctx, const float* d_windows, int n_windows, int chunk_len, float* d_probs)
+{
+    RD_REQUIRE(ctx && d_windows, "rd_forward_resident: null argument");
+    RD_HIP(hipSetDevice(ctx->device));
+    if (!d_probs) {
+        if (ctx->ws_probs.reserve((size_t)n_windows * chunk_len * 20)) return RD_ERR_NOMEM;
+        d_probs = ctx->ws_probs.as<float>();
+    }
+    return rd_forward_dev(ctx, d_windows, n_windows, chunk_len, d_probs);
+}
+
+extern "C" int rd_basecall_global(rd_ctx* ctx, const float* windows, int chunk_len, int step, const int32_t* read_win_off,
+                                  const int32_t* pad, int n_reads, int beam_width, int use_lm, double s_thr, double r_thr,
+                                  uint8_t* labels_out, const int64_t* label_off, int32_t* label_len)
+{
+    RD_REQUIRE(ctx && windows && read_win_off && pad && labels_out && label_off && label_len, "rd_basecall_global: null argument");
+    RD_REQUIRE(n_reads >= 1 && chunk_len >= 1, "rd_basecall_global: bad shape");
+    RD_REQUIRE(step >= 1 && step <= chunk_len, "rd_basecall_global: step %d must be in [1, chunk_len]", step);
+    RD_REQUIRE(beam_width >= 1 && beam_width <= rd_decode_max_width(), "beam_width %d out of range", beam_width);
+    RD_HIP(hipSetDevice(ctx->device));
+    const int nW = read_win_off[n_reads];
+    RD_REQUIRE(nW >= n_reads, "rd_basecall_global: every read needs at least one window");
+    const size_t n = (size_t)nW * chunk_len;
+    if (ctx->ws_in.reserve(n * 4) || ctx->ws_probs.reserve(n * 20)) return RD_ERR_NOMEM;
+    RD_HIP(hipMemcpyAsync(ctx->ws_in.p, windows, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = rd_forward_dev(ctx, ctx->ws_in.as<float>(), nW, chunk_len, ctx->ws_probs.as<float>());
+    if (rc) return rc;
+    // per-read assembly into one concatenated float64 matrix; reads whose reference dtype is float32
+    // (no time step covered twice) are decoded straight from the float32 window rows.
+    std::vector<int64_t> seq_off64(n_reads), seq_off32(n_reads);
+    std::vector<int32_t> seq_len(n_reads);
+    std::vector<int> is64(n_reads);
+    int64_t rows64 = 0;
+    for (int r = 0; r < n_reads; r++) {
+        const int w0 = read_win_off[r], w1 = read_win_off[r + 1];
+        RD_REQUIRE(w1 > w0, "rd_basecall_global: read %d has no windows", r);
+        RD_REQUIRE(pad[r] >= 0 && pad[r] <= chunk_len, "rd_basecall_global: pad[%d] out of range", r);
+        const int64_t N = assembled_rows(w1 - w0, chunk_len, pad[r], step);
+        seq_len[r] = (int32_t)N;
+        is64[r] = assembled_is_f64(w1 - w0, chunk_len, pad[r], step);
+        seq_off64[r] = rows64;
+        seq_off32[r] = (int64_t)w0 * chunk_len;
+        if (is64[r]) rows64 += N;
+    }
+    if (ctx->ws_mat.reserve((size_t)(rows64 + 1) * 40)) return RD_ERR_NOMEM;
+    for (int r = 0; r < n_reads; r++) {
+        if (!is64[r]) continue;
+        const int w0 = read_win_off[r], w1 = read_win_off[r + 1];
+        rc = rd_assemble_dev(ctx, ctx->ws_probs.as<float>() + (size_t)w0 * chunk_len * 5, w1 - w0, chunk_len, pad[r], step,
+                             ctx->ws_mat.as<double>() + seq_off64[r] * 5, seq_len[r]);
+        if (rc) return rc;
+    }
+    // two decode launches: float64 (assembled) reads and float32 (single-coverage) reads
+    for (int pass = 0; pass < 2; pass++) {
+        std::vector<int64_t> so, lo;
+        std::vector<int32_t> sl;
+        std::vector<int> idx;
+        for (int r = 0; r < n_reads; r++)
+            if (is64[r] == (pass == 0)) {
+                so.push_back(pass == 0 ? seq_off64[r] : seq_off32[r]);
+                sl.push_back(seq_len[r]);
+                lo.push_back(label_off[r]);
+                idx.push_back(r);
+            }
+        if (idx.empty()) continue;
+        std::vector<int32_t> ll(idx.size());
+        rc = decode_and_fetch(ctx, pass == 0 ? (const void*)ctx->ws_mat.p : (const void*)ctx->ws_probs.p, pass == 0 ? 1 : 0, so.data(),
+                              sl.data(), (int)idx.size(), beam_width, use_lm, s_thr, r_thr, labels_out, lo.data(), ll.data(), nullptr);
+        if (rc) return rc;
+        for (size_t i = 0; i < idx.size(); i++) label_len[idx[i]] = ll[i];
+    }
+    return RD_OK;
+}
+
+// --------------------------------------------------------------------------------------------- device memory
+extern "C" int rd_dev_alloc(rd_ctx* ctx, size_t bytes, void** d_ptr)
+{
+    RD_REQUIRE(ctx && d_ptr, "rd_dev_alloc: null argument");
+    RD_HIP(hipSetDevice(ctx->device));
+    RD_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return RD_OK;
+}
+extern "C" int rd_dev_free(rd_ctx* ctx, void* d_ptr)
+{
+    RD_REQUIRE(ctx, "rd_dev_free: null context");
+    if (d_ptr) RD_HIP(hipFree(d_ptr));
+    return RD_OK;
+}
+extern "C" int rd_memcpy_h2d(rd_ctx* ctx, void* d_dst, const void* src, size_t bytes)
+{
+    RD_REQUIRE(ctx && d_dst && src, "rd_memcpy_h2d: null argument");
+    RD_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    return RD_OK;
+}
+extern "C" int rd_memcpy_d2h(rd_ctx* ctx, void* dst, const void* d_src, size_t bytes)
+{
+    RD_REQUIRE(ctx && dst && d_src, "rd_memcpy_d2h: null argument");
+    RD_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    return RD_OK;
+}
+
+// --------------------------------------------------------------------------------------------- timers
+static KernelTimer* timer_of(rd_ctx* ctx, int which)
+{
+    switch (which) {
+        case RD_TIMER_CONV: return &ctx->timer_conv;
+        case RD_TIMER_DECODE: return &ctx->timer_decode;
+        case RD_TIMER_HEAD: return &ctx->timer_head;
+        case RD_TIMER_IN: return &ctx->timer_in;
+    }
+    return nullptr;
+}
+
+extern "C" int rd_timer_enable(rd_ctx* ctx, int which, int max_launches)
+{
+    RD_REQUIRE(ctx, "rd_timer_enable: null context");
+    KernelTimer* t = timer_of(ctx, which);
+    RD_REQUIRE(t, "rd_timer_enable: unknown timer %d", which);
+    RD_HIP(hipSetDevice(ctx->device));
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    timer_free(*t);
+    t->flops = t->bytes = 0.0;
+    if (max_launches <= 0) return RD_OK;
+    t->starts.resize(max_launches);
+    t->stops.resize(max_launches);
+    for (int i = 0; i < max_launches; i++) {
+        RD_HIP(hipEventCreate(&t->starts[i]));
+        RD_HIP(hipEventCreate(&t->stops[i]));
+    }
+    t->enabled = true;
+    return RD_OK;
+}
+
+extern "C" int rd_timer_read(rd_ctx* ctx, int which, double* total_ms, int* launches, double* flops, double* bytes)
+{
+    RD_REQUIRE(ctx, "rd_timer_read: null context");
+    KernelTimer* t = timer_of(ctx, which);
+    RD_REQUIRE(t, "rd_timer_read: unknown timer %d", which);
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    double ms = 0.0;
+    for (size_t i = 0; i < t->used; i++) {
+        float f = 0.f;
+        RD_HIP(hipEventElapsedTime(&f, t->starts[i], t->stops[i]));
+        ms += f;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = (int)t->used;
+    if (flops) *flops = t->flops;
+    if (bytes) *bytes = t->bytes;
+    return RD_OK;
+}
+
+// --------------------------------------------------------------------------------------------- RCCL
+namespace {
+
+struct RcclApi {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.h) return RD_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) {
+        rd_set_error("cannot dlopen librccl: %s", dlerror());
+        return RD_ERR_RCCL;
+    }
+    g_rccl.h = h;
+#define RD_SYM(field, name)                                                        \
+    *(void**)(&g_rccl.field) = dlsym(h, name);                                     \
+    if (!g_rccl.field) {                                                           \
+        rd_set_error("librccl lacks symbol %s", name);                             \
+        g_rccl.h = nullptr;                                                        \
+        return RD_ERR_RCCL;                                                        \
+    }
+    RD_SYM(GetUniqueId, "ncclGetUniqueId");
+    RD_SYM(CommInitRank, "ncclCommInitRank");
+    RD_SYM(CommDestroy, "ncclCommDestroy");
+    RD_SYM(Broadcast, "ncclBroadcast");
+    RD_SYM(AllReduce, "ncclAllReduce");
+    RD_SYM(GetErrorString, "ncclGetErrorString");
+#undef RD_SYM
+    return RD_OK;
+}
+
+struct RcclState {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    DevBuf scratch;
+};
+
+#define RD_NCCL(expr)                                                                              \
+    do {                                                                                           \
+        ncclResult_t _r = (expr);                                                                  \
+        if (_r != ncclSuccess) {                                                                   \
+            rd_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, g_rccl.GetErrorString(_r)); \
+            return RD_ERR_RCCL;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+struct BcastHeader {
+    int32_t model_loaded, nblocks, dil[RD_MAX_BLOCKS];
+    int32_t lm_loaded, lm_k;
+    int64_t model_floats, lm_doubles;
+};
+
+}  // namespace
+
+extern "C" int rd_rccl_unique_id(uint8_t id_out[128])
+{
+    RD_REQUIRE(id_out, "rd_rccl_unique_id: null argument");
+    int rc = rccl_load();
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    RD_NCCL(g_rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, 128);
+    return RD_OK;
+}
+
+extern "C" int rd_rccl_init(rd_ctx* ctx, int rank, int nranks, const uint8_t id[128])
+{
+    RD_REQUIRE(ctx && id, "rd_rccl_init: null argument");
+    RD_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "rd_rccl_init: bad rank %d of %d", rank, nranks);
+    int rc = rccl_load();
+    if (rc) return rc;
+    RD_HIP(hipSetDevice(ctx->device));
+    if (ctx->rccl) rd_rccl_finalize(ctx);
+    RcclState* st = new RcclState();
+    st->rank = rank;
+    st->nranks = nranks;
+    ncclUniqueId uid;
+    memcpy(&uid, id, 128);
+    ncclResult_t r = g_rccl.CommInitRank(&st->comm, nranks, uid, rank);
+    if (r != ncclSuccess) {
+        rd_set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, g_rccl.GetErrorString(r));
+        delete st;
+        return RD_ERR_RCCL;
+    }
+    ctx->rccl = st;
+    return RD_OK;
+}
+
+extern "C" int rd_rccl_finalize(rd_ctx* ctx)
+{
+    if (!ctx || !ctx->rccl) return RD_OK;
+    RcclState* st = (RcclState*)ctx->rccl;
+    if (st->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(st->comm);
+    st->scratch.release();
+    delete st;
+    ctx->rccl = nullptr;
+    return RD_OK;
+}
+
+extern "C" int rd_rccl_bcast_model(rd_ctx* ctx, int root)
+{
+    RD_REQUIRE(ctx && ctx->rccl, "rd_rccl_bcast_model: rd_rccl_init not called");
+    RcclState* st = (RcclState*)ctx->rccl;
+    RD_REQUIRE(root >= 0 && root < st->nranks, "rd_rccl_bcast_model: bad root");
+    RD_HIP(hipSetDevice(ctx->device));
+    BcastHeader hd = {};
+    if (st->rank == root) {
+        RD_REQUIRE(ctx->model.loaded, "rd_rccl_bcast_model: root has no weights loaded");
+        hd.model_loaded = 1;
+        hd.nblocks = ctx->model.nblocks;
+        for (int i = 0; i < RD_MAX_BLOCKS; i++) hd.dil[i] = ctx->model.dil[i];
+        hd.model_floats = (int64_t)model_layout(ctx->model.nblocks).total;
+        hd.lm_loaded = ctx->lm.loaded ? 1 : 0;
+        hd.lm_k = ctx->lm.k;
+        hd.lm_doubles = ctx->lm.loaded ? (int64_t)5 << (2 * ctx->lm.k) : 0;
+    }
+    if (st->scratch.reserve(sizeof(BcastHeader))) return RD_ERR_NOMEM;
+    RD_HIP(hipMemcpyAsync(st->scratch.p, &hd, sizeof(hd), hipMemcpyHostToDevice, ctx->stream));
+    RD_NCCL(g_rccl.Broadcast(st->scratch.p, st->scratch.p, sizeof(hd), ncclUint8, root, st->comm, ctx->stream));
+    RD_HIP(hipMemcpyAsync(&hd, st->scratch.p, sizeof(hd), hipMemcpyDeviceToHost, ctx->stream));
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    if (st->rank != root) {
+        Model& m = ctx->model;
+        m.loaded = false;
+        m.nblocks = hd.nblocks;
+        for (int i = 0; i < RD_MAX_BLOCKS; i++) m.dil[i] = hd.dil[i];
+        if (m.storage.reserve((size_t)hd.model_floats * 4)) return RD_ERR_NOMEM;
+        model_bind(m, model_layout(m.nblocks));
+        ctx->lm.loaded = false;
+        ctx->lm.gate_valid = false;
+        if (hd.lm_loaded) {
+            ctx->lm.k = hd.lm_k;
+            if (ctx->lm.storage.reserve((size_t)hd.lm_doubles * 8)) return RD_ERR_NOMEM;
+            lm_bind(ctx->lm);
+        }
+    }
+    // one broadcast of the packed weights (8.8 MB) and, when present, one of the LM table + entropies
+    RD_NCCL(g_rccl.Broadcast(ctx->model.storage.p, ctx->model.storage.p, (size_t)hd.model_floats, ncclFloat32, root, st->comm,
+                             ctx->stream));
+    if (hd.lm_loaded)
+        RD_NCCL(g_rccl.Broadcast(ctx->lm.storage.p, ctx->lm.storage.p, (size_t)hd.lm_doubles, ncclFloat64, root, st->comm,
+                                 ctx->stream));
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->model.loaded = true;
+    if (hd.lm_loaded) ctx->lm.loaded = true;
+    return RD_OK;
+}
+
+extern "C" int rd_rccl_allreduce_max(rd_ctx* ctx, double* inout, int n)
+{
+    RD_REQUIRE(ctx && ctx->rccl && inout && n >= 1, "rd_rccl_allreduce_max: bad argument / rd_rccl_init not called");
+    RcclState* st = (RcclState*)ctx->rccl;
+    RD_HIP(hipSetDevice(ctx->device));
+    if (st->scratch.reserve((size_t)n * 8 + 256)) return RD_ERR_NOMEM;
+    RD_HIP(hipMemcpyAsync(st->scratch.p, inout, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    RD_NCCL(g_rccl.AllReduce(st->scratch.p, st->scratch.p, (size_t)n, ncclFloat64, ncclMax, st->comm, ctx->stream));
+    RD_HIP(hipMemcpyAsync(inout, st->scratch.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    return RD_OK;
+}
+
+extern "C" int rd_rccl_barrier(rd_ctx* ctx)
+{
+    double v = 0.0;
+    return rd_rccl_allreduce_max(ctx, &v, 1);
+}

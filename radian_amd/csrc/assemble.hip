@@ -1,0 +1,50 @@
+// assemble.hip -- global-mode stitch of overlapping window outputs into one [N,5] matrix.
+//
+// Replaces radian/matrix_assembly.py:6-53 (assemble_matrices) after the pad trim of
+// radian/basecall.py:96.  For absolute time step t the reference stacks the rows of every window
+// covering t (window i starts at i*step) and "averages" them -- but np.add's result is discarded
+// (matrix_assembly.py:52), so the assembled row is the EARLIEST covering window's row,
+// L1-normalised in float64 by sklearn.normalize when more than one window covers t, and the
+// untouched float32 row otherwise.  This is a pure gather: 20 B read + 40 B written per row, one
+// thread per row, fully coalesced on the write side.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__ probs, int nW, int T, int pad, int step,
+                                                        double* __restrict__ out, int64_t N)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    // windows i with i*step <= t < i*step + rows_i ; rows_i = T except the last (T - pad)
+    int64_t lo = t - T + 1;
+    int i_min = lo <= 0 ? 0 : (int)((lo + step - 1) / step);
+    int i_max = (int)(t / step);
+    if (i_max > nW - 1) i_max = nW - 1;
+    if (i_max == nW - 1 && t >= (int64_t)(nW - 1) * step + (T - pad)) i_max--;  // trimmed rows of the last window
+    if (i_min > i_max) i_min = i_max;  // cannot happen for t < N
+    const float* r = probs + ((size_t)i_min * T + (size_t)(t - (int64_t)i_min * step)) * 5;
+    double x[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) x[c] = (double)r[c];
+    if (i_max > i_min) {
+        double norm = (((fabs(x[0]) + fabs(x[1])) + fabs(x[2])) + fabs(x[3])) + fabs(x[4]);
+        if (norm == 0.0) norm = 1.0;
+#pragma unroll
+        for (int c = 0; c < 5; c++) x[c] = x[c] / norm;
+    }
+#pragma unroll
+    for (int c = 0; c < 5; c++) out[t * 5 + c] = x[c];
+}
+
+}  // namespace
+
+int rd_assemble_dev(rd_ctx* ctx, const float* d_probs, int nW, int T, int pad, int step, double* d_out, int64_t N)
+{
+    if (N <= 0) return RD_OK;
+    const int threads = 256;
+    const int64_t blocks = (N + threads - 1) / threads;
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)blocks), dim3(threads), 0, ctx->stream, d_probs, nW, T, pad, step, d_out, N);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}

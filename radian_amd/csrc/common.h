@@ -1,0 +1,114 @@
+// common.h -- shared declarations for the radian_hip library (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+
+#define RD_OK 0
+#define RD_ERR_ARG (-1)
+#define RD_ERR_HIP (-2)
+#define RD_ERR_STATE (-3)
+#define RD_ERR_NOMEM (-4)
+#define RD_ERR_RCCL (-5)
+
+void rd_set_error(const char* fmt, ...);
+
+#define RD_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            rd_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));   \
+            return RD_ERR_HIP;                                                                         \
+        }                                                                                              \
+    } while (0)
+
+#define RD_REQUIRE(cond, ...)                                                                          \
+    do {                                                                                               \
+        if (!(cond)) {                                                                                 \
+            rd_set_error(__VA_ARGS__);                                                                 \
+            return RD_ERR_ARG;                                                                         \
+        }                                                                                              \
+    } while (0)
+
+// A grow-only device buffer (workspace); never shrinks, freed with the context.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+// Model geometry: radian/models/sig2seq.yaml:34-49
+constexpr int RD_C = 256;      // tcn.nb_filters
+constexpr int RD_K = 3;        // tcn.kernel_size
+constexpr int RD_H = 128;      // relu_units
+constexpr int RD_NCLS = 5;     // softmax_units (A,C,G,T,blank)
+constexpr int RD_MAX_BLOCKS = 16;
+
+struct Model {
+    bool loaded = false;
+    int nblocks = 0;
+    int dil[RD_MAX_BLOCKS] = {0};
+    // device tensors (packed layouts, see forward.hip)
+    float* w_in = nullptr;      // block0.conv0 kernel [3][256]
+    float* b_in = nullptr;      // [256]
+    float* w_match = nullptr;   // [256]
+    float* b_match = nullptr;   // [256]
+    float* w_conv[2 * RD_MAX_BLOCKS] = {nullptr};  // packed [24 chunks][256 co][32 k]; index 2*blk+which (blk0.conv0 unused)
+    float* b_conv[2 * RD_MAX_BLOCKS] = {nullptr};  // [256]
+    float* w_d1 = nullptr;      // packed like conv, K=256: [8 chunks][128 co][32 k]
+    float* b_d1 = nullptr;      // [128]
+    float* w_d2 = nullptr;      // [128][5] (Keras layout)
+    float* b_d2 = nullptr;      // [5]
+    DevBuf storage;
+};
+
+struct LM {
+    bool loaded = false;
+    int k = 0;
+    double* table = nullptr;        // [4^k][4] device
+    double* d_entropy = nullptr;    // [4^k] device: entropy of each context's distribution (glibc log, computed at load)
+    uint32_t* gate_bits = nullptr;  // bit ctx: d_entropy[ctx] < gate_r_thr
+    double gate_r_thr = 0.0;
+    bool gate_valid = false;
+    DevBuf storage, gate_storage;   // storage = table followed by d_entropy (one RCCL broadcast)
+};
+
+struct KernelTimer {
+    // HIP-event timing of one kernel family on the launch stream (bench.py roofline leg)
+    bool enabled = false;
+    std::vector<hipEvent_t> starts, stops;
+    size_t used = 0;
+    double flops = 0.0;  // algorithmic flops accumulated over recorded launches
+    double bytes = 0.0;
+};
+
+struct rd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Model model;
+    LM lm;
+    // workspaces
+    DevBuf ws_in, ws_act0, ws_act1, ws_probs, ws_mat, ws_seq, ws_nodes_child, ws_nodes_back, ws_labels, ws_misc;
+    // pinned host staging
+    void* h_stage = nullptr;
+    size_t h_stage_cap = 0;
+    KernelTimer timer_conv, timer_decode, timer_head, timer_in;
+    void* rccl = nullptr;  // RcclState*
+};
+
+// forward.hip
+int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_probs);
+// decode.hip
+int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* d_seq_off, const int32_t* d_seq_len,
+                  const int64_t* d_node_off, const int64_t* d_label_off, int n_seq, int64_t total_nodes, int W, int use_lm,
+                  double s_thr, double r_thr, uint8_t* d_labels, int32_t* d_label_len, double* d_best_score);
+// assemble.hip
+int rd_assemble_dev(rd_ctx* ctx, const float* d_probs, int nW, int T, int pad, int step, double* d_out, int64_t N);
+
+extern "C" int rd_decode_max_width(void);
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -1,0 +1,369 @@
+// forward.hip -- Sig2Seq signal model forward: TCN (6 dilated causal residual blocks, 256 filters, k=3)
+// -> Dense(128) -> ReLU -> Dense(5) -> softmax.
+//
+// Replaces `sig_model.predict(batch)` (radian/basecall.py:88-93) for the graph built by
+// radian/model.py:52-89 with radian/models/sig2seq.yaml:34-49; the residual block is keras-tcn 3.5's:
+//   x1 = relu(conv_d(x)); x1 = relu(conv_d(x1)); out = relu(match(x) + x1)
+// with match = 1x1 conv in block 0 (C_in 1 -> 256) and identity elsewhere; causal padding means
+//   out[t] = b + sum_j W[j] . x[t - (K-1-j) d]   with x[<0] = 0 inside each window.
+//
+// Layout in HBM: activations [window][t][256] fp32 (1 KiB per time step, channel-contiguous), two
+// ping-pong tensors (block input/output and the mid activation; the residual add is in place).
+// Weights are repacked once at load into the exact LDS image of each K-chunk:
+//   conv  [chunk = tap*8 + ci/32][co 0..255][ci%32]     (32 KiB per chunk, 24 chunks per conv)
+//   dense [chunk = ci/32]        [h  0..127][ci%32]
+//
+// The dilated conv is an implicit GEMM  M = windows*T (time), N = 256 (co), K = 768 (tap, ci)  on the
+// exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32 (gfx950 has no TF32; fp32 MFMA = 157 TFLOP/s
+// peak).  One 256-thread workgroup (4 waves, 2x2) owns a 128(t) x 256(co) output tile: all output
+// channels of a time tile, so each activation row is read once per tap.  Per K-chunk (one tap, 32
+// input channels) the A tile (128 shifted rows x 32) and the B tile (256 co x 32) are staged
+// global -> registers -> LDS (rows padded to 36 floats: conflict-free ds_read_b128), double
+// buffered with one barrier per chunk; each wave holds a 64 x 128 accumulator (8 MFMA tiles =
+// 128 VGPRs).  One ds_read_b128 feeds four MFMAs: lane (r, h) reads k = 8g+4h .. 8g+4h+3 of its
+// row, and MFMA number kr of the group consumes element kr of both operands, i.e. k-pair
+// (8g+kr, 8g+4+kr).  Bias, ReLU, the residual add (identity or block-0 1x1 match) and the second
+// ReLU are fused into the epilogue.  The head reuses the same core with N = 128, then reduces
+// 128 -> 5 and applies softmax from LDS.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;       // time steps per workgroup tile
+constexpr int BK = 32;        // K-chunk depth
+constexpr int LDA = BK + 4;   // padded LDS row (floats): 144 B, keeps 16-B alignment, conflict-free b128 reads
+
+enum { EPI_RELU = 0, EPI_RES_IDENT = 1, EPI_RES_MATCH = 2, EPI_HEAD = 3 };
+
+struct ConvArgs {
+    const float* in;      // [nW][T][256]
+    float* out;           // [nW][T][256]     (EPI_HEAD: unused)
+    const float* wpk;     // packed weights
+    const float* bias;    // [BN]
+    const float* resid;   // EPI_RES_IDENT: [nW][T][256] (may alias out)
+    const float* x;       // EPI_RES_MATCH: raw windows [nW][T]
+    const float* wmatch;  // [256]
+    const float* bmatch;  // [256]
+    const float* w2;      // EPI_HEAD: [128][5]
+    const float* b2;      // EPI_HEAD: [5]
+    float* probs;         // EPI_HEAD: [nW][T][5]
+    int T;
+    int dil;
+    int tiles_per_win;
+};
+
+template <int NT, int TAPS, int EPI>
+__global__ __launch_bounds__(256) void tcn_gemm_kernel(ConvArgs a)
+{
+    constexpr int BN = 2 * NT * 32;       // output channels per workgroup (2 waves along N)
+    constexpr int NCHUNK = TAPS * (RD_C / BK);
+    constexpr int A_F4 = BM * BK / 4 / 256;   // float4 per thread for the A tile (4)
+    constexpr int B_F4 = BN * BK / 4 / 256;   // float4 per thread for the B tile (8 or 4)
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDA];   // 108 KiB (conv) / 72 KiB (head), static
+    float* As = smem;                       // [2][BM][LDA]
+    float* Bs = smem + 2 * BM * LDA;        // [2][BN][LDA]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1;   // wave row (64 time steps)
+    const int wn = wave & 1;    // wave col (NT*32 channels)
+    const int win = blockIdx.x / a.tiles_per_win;
+    const int t0 = (blockIdx.x - win * a.tiles_per_win) * BM;
+    const int T = a.T;
+    const float* __restrict__ inw = a.in + (size_t)win * T * RD_C;
+
+    const int ld_row = tid >> 3;          // 0..31
+    const int ld_col = (tid & 7) * 4;     // 0..28
+
+    float4 ra[A_F4], rb[B_F4];
+
+    auto load_chunk = [&](int chunk) {
+        const int tap = chunk / (RD_C / BK);
+        const int ci0 = (chunk - tap * (RD_C / BK)) * BK;
+        const int shift = (TAPS - 1 - tap) * a.dil;
+#pragma unroll
+        for (int r = 0; r < A_F4; r++) {
+            const int row = ld_row + 32 * r;
+            const int t = t0 + row - shift;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0 && t < T) v = *(const float4*)(inw + (size_t)t * RD_C + ci0 + ld_col);
+            ra[r] = v;
+        }
+        const float4* wsrc = (const float4*)(a.wpk + (size_t)chunk * BN * BK);
+#pragma unroll
+        for (int r = 0; r < B_F4; r++) rb[r] = wsrc[tid + 256 * r];
+    };
+    auto store_chunk = [&](int buf) {
+        float* Ab = As + buf * BM * LDA;
+        float* Bb = Bs + buf * BN * LDA;
+#pragma unroll
+        for (int r = 0; r < A_F4; r++) *(float4*)(Ab + (ld_row + 32 * r) * LDA + ld_col) = ra[r];
+#pragma unroll
+        for (int r = 0; r < B_F4; r++) {
+            const int idx = tid + 256 * r;
+            *(float4*)(Bb + (idx >> 3) * LDA + (idx & 7) * 4) = rb[r];
+        }
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[m][n][e] = 0.f;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+
+    const int fr = lane & 31;
+    const int fh = lane >> 5;
+    for (int chunk = 0; chunk < NCHUNK; chunk++) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < NCHUNK) load_chunk(chunk + 1);
+        const float* Ab = As + buf * BM * LDA + (wm * 64 + fr) * LDA + 4 * fh;
+        const float* Bb = Bs + buf * BN * LDA + (wn * NT * 32 + fr) * LDA + 4 * fh;
+#pragma unroll
+        for (int g = 0; g < BK / 8; g++) {
+            float4 af[2], bf[NT];
+#pragma unroll
+            for (int m = 0; m < 2; m++) af[m] = *(const float4*)(Ab + m * 32 * LDA + 8 * g);
+#pragma unroll
+            for (int n = 0; n < NT; n++) bf[n] = *(const float4*)(Bb + n * 32 * LDA + 8 * g);
+#pragma unroll
+            for (int kr = 0; kr < 4; kr++) {
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    const float av = kr == 0 ? af[m].x : kr == 1 ? af[m].y : kr == 2 ? af[m].z : af[m].w;
+#pragma unroll
+                    for (int n = 0; n < NT; n++) {
+                        const float bv = kr == 0 ? bf[n].x : kr == 1 ? bf[n].y : kr == 2 ? bf[n].z : bf[n].w;
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (chunk + 1 < NCHUNK) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    // C/D layout of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    if constexpr (EPI != EPI_HEAD) {
+        float* outw = a.out + (size_t)win * T * RD_C;  // may alias a.resid (in-place residual)
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            const int co = wn * NT * 32 + n * 32 + fr;
+            const float bias = a.bias[co];
+            float wmt = 0.f, bmt = 0.f;
+            if constexpr (EPI == EPI_RES_MATCH) {
+                wmt = a.wmatch[co];
+                bmt = a.bmatch[co];
+            }
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int row = wm * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    const int t = t0 + row;
+                    if (t < T) {
+                        float v = acc[m][n][e] + bias;
+                        v = v > 0.f ? v : 0.f;
+                        if constexpr (EPI == EPI_RES_IDENT) {
+                            v += a.resid[((size_t)win * T + t) * RD_C + co];
+                            v = v > 0.f ? v : 0.f;
+                        } else if constexpr (EPI == EPI_RES_MATCH) {
+                            const float r = bmt + a.x[(size_t)win * T + t] * wmt;
+                            v = r + v;
+                            v = v > 0.f ? v : 0.f;
+                        }
+                        outw[(size_t)t * RD_C + co] = v;
+                    }
+                }
+            }
+        }
+    } else {
+        // Dense(128) bias + ReLU into LDS, then Dense(5) + softmax   (model.py:72-75)
+        constexpr int LDH = RD_H + 1;
+        float* hs = smem;  // [BM][LDH]  (staging buffers are dead after the last barrier)
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            const int hcol = wn * NT * 32 + n * 32 + fr;
+            const float bias = a.bias[hcol];
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int row = wm * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    float v = acc[m][n][e] + bias;
+                    hs[row * LDH + hcol] = v > 0.f ? v : 0.f;
+                }
+        }
+        float* w2s = smem + BM * LDH;  // [128*5 + 5]
+        for (int i = tid; i < RD_H * 5; i += 256) w2s[i] = a.w2[i];
+        if (tid < 5) w2s[RD_H * 5 + tid] = a.b2[tid];
+        __syncthreads();
+        if (tid < BM) {
+            const int t = t0 + tid;
+            if (t < T) {
+                float lg[5];
+#pragma unroll
+                for (int o = 0; o < 5; o++) lg[o] = w2s[RD_H * 5 + o];
+                for (int j = 0; j < RD_H; j++) {
+                    const float h = hs[tid * LDH + j];
+#pragma unroll
+                    for (int o = 0; o < 5; o++) lg[o] += h * w2s[j * 5 + o];
+                }
+                float mx = lg[0];
+#pragma unroll
+                for (int o = 1; o < 5; o++) mx = lg[o] > mx ? lg[o] : mx;
+                float e[5], s = 0.f;
+#pragma unroll
+                for (int o = 0; o < 5; o++) {
+                    e[o] = expf(lg[o] - mx);
+                    s += e[o];
+                }
+                float* pr = a.probs + ((size_t)win * T + t) * 5;
+#pragma unroll
+                for (int o = 0; o < 5; o++) pr[o] = e[o] / s;
+            }
+        }
+    }
+}
+
+// Block 0, first conv: C_in = 1 (VALU; memory-bound 1 KiB write per time step), fused bias + ReLU.
+__global__ __launch_bounds__(256) void tcn_in_kernel(const float* __restrict__ x, const float* __restrict__ w /*[3][256]*/,
+                                                      const float* __restrict__ b, float* __restrict__ out, int T, int dil,
+                                                      size_t total_rows)
+{
+    const int c4 = (threadIdx.x & 63) * 4;
+    const float4 w0 = *(const float4*)(w + c4), w1 = *(const float4*)(w + 256 + c4), w2 = *(const float4*)(w + 512 + c4);
+    const float4 bb = *(const float4*)(b + c4);
+    for (size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < total_rows; row += (size_t)gridDim.x * 4) {
+        const int t = (int)(row % (size_t)T);
+        const float* xw = x + (row - t);
+        const float x2 = xw[t];
+        const float x1 = t - dil >= 0 ? xw[t - dil] : 0.f;
+        const float x0 = t - 2 * dil >= 0 ? xw[t - 2 * dil] : 0.f;
+        float4 v;
+        v.x = bb.x + x0 * w0.x + x1 * w1.x + x2 * w2.x;
+        v.y = bb.y + x0 * w0.y + x1 * w1.y + x2 * w2.y;
+        v.z = bb.z + x0 * w0.z + x1 * w1.z + x2 * w2.z;
+        v.w = bb.w + x0 * w0.w + x1 * w1.w + x2 * w2.w;
+        v.x = v.x > 0.f ? v.x : 0.f;
+        v.y = v.y > 0.f ? v.y : 0.f;
+        v.z = v.z > 0.f ? v.z : 0.f;
+        v.w = v.w > 0.f ? v.w : 0.f;
+        *(float4*)(out + row * RD_C + c4) = v;
+    }
+}
+
+
+int timer_begin(rd_ctx* ctx, KernelTimer& tm)
+{
+    if (tm.enabled && tm.used < tm.starts.size()) RD_HIP(hipEventRecord(tm.starts[tm.used], ctx->stream));
+    return RD_OK;
+}
+int timer_end(rd_ctx* ctx, KernelTimer& tm, double flops, double bytes)
+{
+    if (tm.enabled && tm.used < tm.starts.size()) {
+        RD_HIP(hipEventRecord(tm.stops[tm.used], ctx->stream));
+        tm.used++;
+        tm.flops += flops;
+        tm.bytes += bytes;
+    }
+    return RD_OK;
+}
+
+}  // namespace
+
+// d_windows [nW][T] fp32 (already MAD-normalised) -> d_probs [nW][T][5] fp32; all on ctx->stream.
+int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_probs)
+{
+    Model& m = ctx->model;
+    if (!m.loaded) {
+        rd_set_error("rd_forward: no weights loaded (rd_load_weights)");
+        return RD_ERR_STATE;
+    }
+    RD_REQUIRE(nW >= 0 && T >= 1, "rd_forward: bad shape nW=%d T=%d", nW, T);
+    if (nW == 0) return RD_OK;
+    int rc = RD_OK;
+    const size_t act_bytes = (size_t)nW * T * RD_C * sizeof(float);
+    if (ctx->ws_act0.reserve(act_bytes) || ctx->ws_act1.reserve(act_bytes)) return RD_ERR_NOMEM;
+    float* X = ctx->ws_act0.as<float>();    // block input / output (residual added in place)
+    float* MID = ctx->ws_act1.as<float>();  // activation between the two convs of a block
+    const size_t rows = (size_t)nW * T;
+    const int tiles = (T + BM - 1) / BM;
+    const int grid = nW * tiles;
+    const double conv_flops = 2.0 * (double)rows * RD_C * RD_C * RD_K;
+    const double conv_bytes = 2.0 * (double)rows * RD_C * 4.0;
+
+    for (int b = 0; b < m.nblocks; b++) {
+        const int d = m.dil[b];
+        ConvArgs a = {};
+        a.T = T;
+        a.dil = d;
+        a.tiles_per_win = tiles;
+        if (b == 0) {
+            // conv0: 1 -> 256 on the VALU
+            size_t g = (rows + 3) / 4;
+            if (g > 256 * 64) g = 256 * 64;
+            if ((rc = timer_begin(ctx, ctx->timer_in))) return rc;
+            hipLaunchKernelGGL(tcn_in_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, d_windows, m.w_in, m.b_in, MID, T, d,
+                               rows);
+            RD_HIP(hipGetLastError());
+            if ((rc = timer_end(ctx, ctx->timer_in, 2.0 * rows * RD_C * RD_K, (double)rows * (RD_C * 4.0 + 4.0)))) return rc;
+            // conv1 + relu, + 1x1 match residual + relu
+            a.in = MID;
+            a.out = X;
+            a.wpk = m.w_conv[1];
+            a.bias = m.b_conv[1];
+            a.x = d_windows;
+            a.wmatch = m.w_match;
+            a.bmatch = m.b_match;
+            if ((rc = timer_begin(ctx, ctx->timer_conv))) return rc;
+            hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_MATCH>), dim3(grid), dim3(256), 0, ctx->stream, a);
+            RD_HIP(hipGetLastError());
+            if ((rc = timer_end(ctx, ctx->timer_conv, conv_flops, conv_bytes))) return rc;
+        } else {
+            a.in = X;
+            a.out = MID;
+            a.wpk = m.w_conv[2 * b];
+            a.bias = m.b_conv[2 * b];
+            if ((rc = timer_begin(ctx, ctx->timer_conv))) return rc;
+            hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RELU>), dim3(grid), dim3(256), 0, ctx->stream, a);
+            RD_HIP(hipGetLastError());
+            if ((rc = timer_end(ctx, ctx->timer_conv, conv_flops, conv_bytes))) return rc;
+            a.in = MID;
+            a.out = X;
+            a.resid = X;
+            a.wpk = m.w_conv[2 * b + 1];
+            a.bias = m.b_conv[2 * b + 1];
+            if ((rc = timer_begin(ctx, ctx->timer_conv))) return rc;
+            hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_IDENT>), dim3(grid), dim3(256), 0, ctx->stream, a);
+            RD_HIP(hipGetLastError());
+            if ((rc = timer_end(ctx, ctx->timer_conv, conv_flops, conv_bytes + (double)rows * RD_C * 4.0))) return rc;
+        }
+    }
+    ConvArgs h = {};
+    h.T = T;
+    h.dil = 0;
+    h.tiles_per_win = tiles;
+    h.in = X;
+    h.wpk = m.w_d1;
+    h.bias = m.b_d1;
+    h.w2 = m.w_d2;
+    h.b2 = m.b_d2;
+    h.probs = d_probs;
+    if ((rc = timer_begin(ctx, ctx->timer_head))) return rc;
+    hipLaunchKernelGGL((tcn_gemm_kernel<2, 1, EPI_HEAD>), dim3(grid), dim3(256), 0, ctx->stream, h);
+    RD_HIP(hipGetLastError());
+    if ((rc = timer_end(ctx, ctx->timer_head, 2.0 * rows * (RD_C * RD_H + RD_H * 5), (double)rows * (RD_C * 4.0 + 20.0))))
+        return rc;
+    return RD_OK;
+}

@@ -1,0 +1,179 @@
+"""HIP beam search (through the C ABI) against the golden vectors of the reference and against the CPU oracle.
+
+Bar: emitted labelings bit-exact; winner scores within a few ulp (ROCm's log/log1p/exp vs glibc)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+BASES = "ACGT"
+
+
+def fdec(h):
+    return float.fromhex(h)
+
+
+@pytest.fixture(scope="module")
+def be():
+    from radian_amd import Backend
+    b = Backend(0)
+    yield b
+    b.close()
+
+
+def s_of(labels):
+    return "".join(BASES[c] for c in labels)
+
+
+def softmax_rows(z):
+    z = z - z.max(axis=1, keepdims=True)
+    e = np.exp(z)
+    return e / e.sum(axis=1, keepdims=True)
+
+
+def test_golden_nolm(be, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "beam_nolm_cases.json")))
+    mats = np.load(os.path.join(golden_dir, "beam_nolm_mats.npz"))
+    bad = []
+    for c in g["cases"]:
+        mat = mats[c["mat"]]
+        (lab,), sc = be.decode_batch(mat.reshape(-1, 5), [0], [mat.shape[0]], c["W"], with_scores=True)
+        if s_of(lab) != c["seq"]:
+            bad.append((c["mat"], c["T"], c["kind"], c["W"]))
+        elif "final" in c:
+            exp = fdec(c["final"][0]["pr_total"])
+            if np.isfinite(exp):
+                assert abs(sc[0] - exp) <= 1e-12 * max(1.0, abs(exp)), (c["mat"], c["W"], sc[0], exp)
+            else:
+                assert sc[0] == exp
+    assert not bad, bad
+
+
+def test_golden_lm(be, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "beam_lm_cases.json")))
+    mats = np.load(os.path.join(golden_dir, "beam_lm_mats.npz"))
+    bad = []
+    cur = None
+    for c in g["cases"]:
+        if cur != c["lm"]:
+            be.load_lm(mats[c["lm"]], c["k"])
+            cur = c["lm"]
+        mat = mats[c["mat"]]
+        lab = be.decode(mat, c["W"], use_lm=True, s_threshold=fdec(c["s_thr"]), r_threshold=fdec(c["r_thr"]))
+        if s_of(lab) != c["seq"]:
+            bad.append((c["mat"], c["k"], c["W"], c["s_thr"], c["r_thr"]))
+    be.load_lm(None, 0)
+    assert not bad, bad
+
+
+def test_batch_vs_oracle_chunk_shapes(be, oracle):
+    """A batch like BASELINE config 3: many 1024-row windows + 512-row tails, float32, W in {1,10,25}."""
+    rng = np.random.default_rng(11)
+    lens = [1024, 1024, 512, 1024, 700, 1, 0, 1024, 333, 64, 65, 63]
+    rows = []
+    for i, n in enumerate(lens):
+        z = rng.normal(size=(n, 5)) * (1.0 if i % 2 == 0 else 3.0)
+        if i % 3 == 0:
+            z[:, 4] += 1.5
+        rows.append(softmax_rows(z).astype(np.float32))
+    mats = np.concatenate(rows, axis=0)
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    for W in (1, 2, 6, 10, 12, 13, 25, 30):
+        got = be.decode_batch(mats, off, lens, W)
+        exp = oracle.beam_search_batch(mats, off, lens, W)
+        for i in range(len(lens)):
+            assert np.array_equal(got[i], exp[i]), (W, i, lens[i])
+
+
+def test_global_shape_f64_with_lm_vs_oracle(be, oracle):
+    """BASELINE config 4 shape: [4096,5] float64 assembled matrices, W=10, k-mer LM, thresholds 0.5/0.5."""
+    rng = np.random.default_rng(12)
+    k = 5
+    table = rng.dirichlet([0.3] * 4, size=4 ** k)
+    be.load_lm(table, k)
+    lens = [4096, 2000, 4096]
+    rows = []
+    for i, n in enumerate(lens):
+        z = rng.normal(size=(n, 5)) * 2.5
+        z[:, 4] += 1.0
+        rows.append(softmax_rows(z))
+    mats = np.concatenate(rows, axis=0)
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    for W in (6, 10):
+        got = be.decode_batch(mats, off, lens, W, use_lm=True, s_threshold=0.5, r_threshold=0.5)
+        exp = oracle.beam_search_batch(mats, off, lens, W, table, 0.5, 0.5, k)
+        for i in range(len(lens)):
+            assert np.array_equal(got[i], exp[i]), (W, i)
+    be.load_lm(None, 0)
+
+
+def test_lm_k11_table(be, oracle):
+    """The 12-mer LM geometry of the reference (context 11 -> 4^11 x 4 table, 128 MiB)."""
+    rng = np.random.default_rng(13)
+    k = 11
+    table = rng.dirichlet([0.3] * 4, size=4 ** k)
+    be.load_lm(table, k)
+    z = rng.normal(size=(1500, 5)) * 2.5
+    z[:, 4] += 1.0
+    mat = softmax_rows(z)
+    got = be.decode(mat, 10, use_lm=True, s_threshold=0.5, r_threshold=0.5)
+    exp, _ = oracle.beam_search_labels(mat, 10, table, 0.5, 0.5, k)
+    assert np.array_equal(got, exp)
+    be.load_lm(None, 0)
+
+
+def test_float32_with_lm_vs_oracle(be, oracle):
+    """single-window read in global mode: the matrix stays float32 (numpy-1.19 semantics in the oracle)."""
+    rng = np.random.default_rng(14)
+    k = 3
+    table = rng.dirichlet([0.3] * 4, size=4 ** k)
+    be.load_lm(table, k)
+    for kind in (1.0, 3.0):
+        mat = softmax_rows(rng.normal(size=(600, 5)) * kind).astype(np.float32)
+        for W in (6, 10):
+            got = be.decode(mat, W, use_lm=True, s_threshold=0.5, r_threshold=0.9)
+            exp, _ = oracle.beam_search_labels(mat, W, table, 0.5, 0.9, k)
+            assert np.array_equal(got, exp)
+    be.load_lm(None, 0)
+
+
+def test_properties_at_full_size(be):
+    """Size-independent properties at BASELINE batch size: 512 windows x 1024 rows, W=10.
+    (a) permutation invariance of the batch, (b) a sequence decodes the same alone and in the batch,
+    (c) one-hot rows decode to the CTC collapse of the argmax path."""
+    rng = np.random.default_rng(15)
+    n, T = 512, 1024
+    z = rng.normal(size=(n * T, 5)).astype(np.float32) * 2.0
+    mats = softmax_rows(z).astype(np.float32)
+    off = np.arange(n, dtype=np.int64) * T
+    lens = np.full(n, T, dtype=np.int32)
+    a = be.decode_batch(mats, off, lens, 10)
+    perm = rng.permutation(n)
+    b = be.decode_batch(mats, off[perm], lens[perm], 10)
+    for i in range(n):
+        assert np.array_equal(a[perm[i]], b[i])
+    for i in (0, 17, 511):
+        alone = be.decode(mats[i * T:(i + 1) * T], 10)
+        assert np.array_equal(alone, a[i])
+    # one-hot: beam search == greedy collapse
+    path = rng.integers(0, 5, size=2000)
+    hot = np.zeros((2000, 5), dtype=np.float32)
+    hot[np.arange(2000), path] = 1.0
+    exp = [int(c) for i, c in enumerate(path) if c != 4 and (i == 0 or path[i - 1] != c)]
+    for W in (1, 10, 25):
+        got = be.decode(hot, W)
+        assert got.tolist() == exp
+
+
+def test_errors(be):
+    from radian_amd import RadianHipError
+    m = np.full((4, 5), 0.2, dtype=np.float32)
+    with pytest.raises(RadianHipError):
+        be.decode(m, 0)
+    with pytest.raises(RadianHipError):
+        be.decode(m, be.max_beam_width + 1)
+    with pytest.raises(RadianHipError):
+        be.decode(m, 6, use_lm=True)  # no LM loaded
+    assert be.decode(np.zeros((0, 5), dtype=np.float32), 6).tolist() == []
