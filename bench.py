@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: input signal samples/s basecalled (chunk=1024, beam=10).
+
+Workload (BASELINE.json configs[2], SURVEY.md section 8d cfg 3): synthetic Gaussian int16 reads of 4096
+samples, MAD-normalised, chunk 1024 / step 512 -> 8 windows per read; one STEP = one batch of 512 windows
+(64 reads, the north_star batch) through the whole hot path: TCN forward (fp32 MFMA) -> per-window CTC
+prefix beam search W=10 (chunk mode: LM unused, reference basecall.py:110-121) -> labels back on the host.
+Inputs are resident in HBM when the timed region starts.  One process per GPU; ranks shard reads with no
+data-path collective (weak scaling); the only RCCL traffic is the start-up broadcast of the weights.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+No PyTorch in the measured process: rendezvous for the RCCL unique id goes through a file keyed by
+MASTER_PORT, barrier and max-over-ranks through RCCL (rd_rccl_*).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CHUNK, STEP, READ_LEN, BATCH_WINDOWS, BEAM = 1024, 512, 4096, 512, 10
+FLOP_PER_CONV_ROW = 2 * 256 * 256 * 3  # one dilated conv, per window time step
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+
+
+def rendezvous_uid(be, rank, world):
+    """rank 0 creates the 128-byte RCCL id and publishes it in a file; the others poll for it."""
+    port = os.environ.get("MASTER_PORT", "29500")
+    run = os.environ.get("TORCHELASTIC_RUN_ID", "none")
+    path = f"/tmp/radian_rccl_uid_{port}_{run}_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}"
+    if rank == 0:
+        uid = be.rccl_unique_id()
+        tmp = path + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid, path
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > 120:
+            raise RuntimeError("timed out waiting for the RCCL unique id from rank 0")
+        time.sleep(0.01)
+    with open(path, "rb") as f:
+        return f.read(), path
+
+
+def cpu_baseline(windows, valid, n_reads):
+    """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload, all host cores."""
+    from oracle import oracle as orc
+    from radian_amd import weights
+    orc.build()
+    w = weights.synthetic_weights(seed=1234)
+    cores = orc.num_threads()
+    t0 = time.perf_counter()
+    probs = orc.tcn_forward(w, windows, nthreads=cores)
+    t1 = time.perf_counter()
+    n, T = windows.shape
+    off = np.arange(n, dtype=np.int64) * T
+    orc.beam_search_batch(probs.reshape(-1, 5), off, valid, BEAM, nthreads=cores)
+    t2 = time.perf_counter()
+    samples = n_reads * READ_LEN
+    return {
+        "value": samples / (t2 - t0), "unit": "samples/s", "cores": int(cores), "kind": "port",
+        "sample": f"{n_reads} reads x {READ_LEN} samples ({n} windows) of the same workload; oracle forward "
+                  f"{t1 - t0:.2f}s + beam search {t2 - t1:.2f}s, OpenMP over {cores} threads",
+        "forward_s": t1 - t0, "decode_s": t2 - t1,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reads", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+
+    from radian_amd import Backend, weights, synthetic
+    from radian_amd.backend import RD_TIMER_CONV, RD_TIMER_DECODE, RD_TIMER_HEAD
+
+    be = Backend(local_rank)
+    uid_path = None
+    if world > 1:
+        uid, uid_path = rendezvous_uid(be, rank, world)
+        be.rccl_init(rank, world, uid)
+        if rank == 0:
+            be.load_weights(weights.synthetic_weights(seed=1234))
+        be.rccl_bcast_model(0)  # the one collective of the job: 8.8 MB of packed weights over xGMI
+    else:
+        be.load_weights(weights.synthetic_weights(seed=1234))
+
+    # ---- synthetic input, resident in HBM: 4 distinct batches of 64 reads per rank, cycled
+    reads_per_batch = BATCH_WINDOWS // 8
+    n_batches = 4
+    batches = []
+    for b in range(n_batches):
+        reads = synthetic.synthetic_reads(reads_per_batch, READ_LEN, seed=1000 * rank + b)
+        win, valid, _, _ = synthetic.reads_to_windows(reads, CHUNK, STEP)
+        assert win.shape == (BATCH_WINDOWS, CHUNK)
+        d = be.dev_alloc(win.nbytes)
+        be.h2d(d, win)
+        batches.append((d, valid, win))
+    labels = np.zeros((BATCH_WINDOWS, CHUNK), dtype=np.uint8)
+    lens = np.zeros(BATCH_WINDOWS, dtype=np.int32)
+
+    def step(i):
+        d, valid, _ = batches[i % n_batches]
+        be.basecall_chunk_resident(d, BATCH_WINDOWS, CHUNK, valid, BEAM, labels, lens)
+
+    for i in range(args.warmup):
+        step(i)
+    be.sync()
+    if world > 1:
+        be.rccl_barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    be.sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        be.rccl_barrier()
+        elapsed = float(be.rccl_allreduce_max([elapsed])[0])
+    assert lens.min() >= 0 and lens.max() <= CHUNK and lens.sum() > 0
+
+    samples_per_step = reads_per_batch * READ_LEN  # input samples basecalled per step per GPU
+    value = world * args.steps * samples_per_step / elapsed
+
+    # ---- roofline of the dominant kernel (dilated conv on fp32 MFMA), HIP events on the launch stream
+    roof = None
+    cpu = None
+    if rank == 0:
+        n_prof = 2
+        be.timer_enable(RD_TIMER_CONV, 11 * n_prof)
+        be.timer_enable(RD_TIMER_DECODE, n_prof)
+        be.timer_enable(RD_TIMER_HEAD, n_prof)
+        for i in range(n_prof):
+            step(i)
+        be.sync()
+        tc = be.timer_read(RD_TIMER_CONV)
+        td = be.timer_read(RD_TIMER_DECODE)
+        th = be.timer_read(RD_TIMER_HEAD)
+        be.timer_enable(RD_TIMER_CONV, 0)
+        be.timer_enable(RD_TIMER_DECODE, 0)
+        be.timer_enable(RD_TIMER_HEAD, 0)
+        rows = BATCH_WINDOWS * CHUNK
+        flop_per_launch = rows * FLOP_PER_CONV_ROW
+        avg_s = tc["total_ms"] / max(1, tc["launches"]) * 1e-3
+        achieved = flop_per_launch / avg_s / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("conv_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {
+            "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "kernel": "tcn_gemm_kernel<4,3,*> (dilated causal conv 256->256, k=3, v_mfma_f32_32x32x2_f32)",
+            "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_s * 1e3, "launches_timed": tc["launches"],
+            "conv_ms_per_step": tc["total_ms"] / n_prof, "decode_ms_per_step": td["total_ms"] / n_prof,
+            "head_ms_per_step": th["total_ms"] / n_prof,
+            "decode_timesteps_per_s": float(sum(b[1].sum() for b in batches[:n_prof])) / max(1e-9, td["total_ms"] * 1e-3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            nr = args.cpu_reads
+            cpu = cpu_baseline(batches[0][2][: nr * 8], batches[0][1][: nr * 8], nr)
+
+    if rank == 0:
+        out = {
+            "metric": "signal samples/s basecalled (chunk=1024, beam=10)",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: synthetic Gaussian int16 reads x 4096 samples (round(N(500,80))), "
+                            "MAD-normalised, chunk=1024 step=512 -> 8 windows/read; step = 512 windows (64 reads): "
+                            "TCN forward fp32 + chunk-mode CTC beam search W=10 (LM unused in chunk mode, "
+                            "reference basecall.py:110-121) + labels to host; random He-normal weights seed 1234",
+                "chunk_len": CHUNK, "step_size": STEP, "batch_windows": BATCH_WINDOWS, "beam_width": BEAM,
+                "decode_type": "chunk", "samples_per_step_per_gpu": samples_per_step, "sharding": "reads per rank, no data-path collective",
+            },
+            "roofline": roof,
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["gpu_over_cpu"] = value / cpu["value"]
+        print(json.dumps(out))
+        if uid_path and os.path.exists(uid_path):
+            os.remove(uid_path)
+    for d, _, _ in batches:
+        be.dev_free(d)
+    be.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,7 +145,7 @@ constexpr size_t CONV_PK = (size_t)RD_K * RD_C * RD_C;  // 196608 floats
 constexpr size_t D1_PK = (size_t)RD_C * RD_H;
 
 struct ModelLayout {
-    size_t w_in, b_in, w_match, b_match, w_conv[2 * RD_MAX_BLOCKS], b_conv[2 * RD_MAX_BLOCKS], w_d1, b_d1, w_d2, b_d2, total;
+    size_t zeros, w_in, b_in, w_match, b_match, w_conv[2 * RD_MAX_BLOCKS], b_conv[2 * RD_MAX_BLOCKS], w_d1, b_d1, w_d2, b_d2, total;
 };
 
 ModelLayout model_layout(int nblocks)
@@ -157,6 +157,7 @@ ModelLayout model_layout(int nblocks)
         off += align_up(n, 64);
         return o;
     };
+    L.zeros = take(64);
     L.w_in = take(RD_K * RD_C);
     L.b_in = take(RD_C);
     L.w_match = take(RD_C);
@@ -178,6 +179,7 @@ ModelLayout model_layout(int nblocks)
 void model_bind(Model& m, const ModelLayout& L)
 {
     float* base = m.storage.as<float>();
+    m.zeros = base + L.zeros;
     m.w_in = base + L.w_in;
     m.b_in = base + L.b_in;
     m.w_match = base + L.w_match;
@@ -194,25 +196,28 @@ void model_bind(Model& m, const ModelLayout& L)
     m.b_d2 = base + L.b_d2;
 }
 
-// Keras conv kernel [j][ci][co] -> [chunk = j*8 + ci/32][co][ci%32]
+// LDS image order (forward.hip): rows of 32 floats whose 16-B slots are XOR-swizzled by (row >> 1) & 7.
+static inline int swz_k(int row, int k) { return ((((k >> 2) ^ ((row >> 1) & 7)) << 2) | (k & 3)); }
+
+// Keras conv kernel [j][ci][co] -> [chunk = j*8 + ci/32][co][swizzled ci%32]
 void pack_conv(const float* k, float* dst)
 {
     for (int j = 0; j < RD_K; j++)
         for (int ci = 0; ci < RD_C; ci++) {
             const float* src = k + ((size_t)j * RD_C + ci) * RD_C;
             const int chunk = j * (RD_C / 32) + ci / 32;
-            float* d = dst + (size_t)chunk * RD_C * 32 + (ci % 32);
-            for (int co = 0; co < RD_C; co++) d[(size_t)co * 32] = src[co];
+            float* d = dst + (size_t)chunk * RD_C * 32;
+            for (int co = 0; co < RD_C; co++) d[(size_t)co * 32 + swz_k(co, ci % 32)] = src[co];
         }
 }
 
-// Keras dense kernel [ci][h] -> [chunk = ci/32][h][ci%32]
+// Keras dense kernel [ci][h] -> [chunk = ci/32][h][swizzled ci%32]
 void pack_dense(const float* k, float* dst)
 {
     for (int ci = 0; ci < RD_C; ci++) {
         const float* src = k + (size_t)ci * RD_H;
-        float* d = dst + (size_t)(ci / 32) * RD_H * 32 + (ci % 32);
-        for (int h = 0; h < RD_H; h++) d[(size_t)h * 32] = src[h];
+        float* d = dst + (size_t)(ci / 32) * RD_H * 32;
+        for (int h = 0; h < RD_H; h++) d[(size_t)h * 32 + swz_k(h, ci % 32)] = src[h];
     }
 }
 

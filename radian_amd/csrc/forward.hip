@@ -17,10 +17,10 @@
 // exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32 (gfx950 has no TF32; fp32 MFMA = 157 TFLOP/s
 // peak).  One 256-thread workgroup (4 waves, 2x2) owns a 128(t) x 256(co) output tile: all output
 // channels of a time tile, so each activation row is read once per tap.  Per K-chunk (one tap, 32
-// input channels) the A tile (128 shifted rows x 32) and the B tile (256 co x 32) are staged
-// global -> registers -> LDS (rows padded to 36 floats: conflict-free ds_read_b128), double
-// buffered with one barrier per chunk; each wave holds a 64 x 128 accumulator (8 MFMA tiles =
-// 128 VGPRs).  One ds_read_b128 feeds four MFMAs: lane (r, h) reads k = 8g+4h .. 8g+4h+3 of its
+// input channels) the A tile (128 shifted rows x 32) and the B tile (256 co x 32) go HBM/L2 -> LDS by
+// LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), 128-B rows with XOR-swizzled
+// 16-B slots (conflict-free ds_read_b128), double buffered with one barrier per chunk; each wave holds
+// a 64 x 128 accumulator (8 MFMA tiles = 128 VGPRs).  One ds_read_b128 feeds four MFMAs: lane (r, h) reads k = 8g+4h .. 8g+4h+3 of its
 // row, and MFMA number kr of the group consumes element kr of both operands, i.e. k-pair
 // (8g+kr, 8g+4+kr).  Bias, ReLU, the residual add (identity or block-0 1x1 match) and the second
 // ReLU are fused into the epilogue.  The head reuses the same core with N = 128, then reduces
@@ -33,7 +33,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;       // time steps per workgroup tile
 constexpr int BK = 32;        // K-chunk depth
-constexpr int LDA = BK + 4;   // padded LDS row (floats): 144 B, keeps 16-B alignment, conflict-free b128 reads
 
 enum { EPI_RELU = 0, EPI_RES_IDENT = 1, EPI_RES_MATCH = 2, EPI_HEAD = 3 };
 
@@ -49,26 +48,38 @@ struct ConvArgs {
     const float* w2;      // EPI_HEAD: [128][5]
     const float* b2;      // EPI_HEAD: [5]
     float* probs;         // EPI_HEAD: [nW][T][5]
+    const float* zeros;   // >= 32 zero floats (source of the causal left padding for the LDS-DMA)
     int T;
     int dil;
     int tiles_per_win;
 };
+
+// LDS image of a K-chunk tile: [row][32 floats] (128-B rows, no padding -- LDS-DMA writes 1 KiB per
+// wave-instruction contiguously), with the 16-B slots of each row XOR-swizzled by (row >> 1) & 7 so that the
+// 16 lanes of a ds_read_b128 group (16 distinct rows, same logical slot) hit 16 different 16-B bank slots of
+// the 256-B bank row.  The swizzle is applied on the global SOURCE address of the DMA and again on the read.
+__device__ __forceinline__ void glds16(const float* src, float* lds_dst)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
 
 template <int NT, int TAPS, int EPI>
 __global__ __launch_bounds__(256) void tcn_gemm_kernel(ConvArgs a)
 {
     constexpr int BN = 2 * NT * 32;       // output channels per workgroup (2 waves along N)
     constexpr int NCHUNK = TAPS * (RD_C / BK);
-    constexpr int A_F4 = BM * BK / 4 / 256;   // float4 per thread for the A tile (4)
-    constexpr int B_F4 = BN * BK / 4 / 256;   // float4 per thread for the B tile (8 or 4)
+    constexpr int STAGE_FLOATS = 2 * (BM + BN) * BK;
+    constexpr int HEAD_FLOATS = BM * (RD_H + 1) + RD_H * 5 + 8;
+    constexpr int SMEM_FLOATS = (EPI == EPI_HEAD && HEAD_FLOATS > STAGE_FLOATS) ? HEAD_FLOATS : STAGE_FLOATS;
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDA];   // 108 KiB (conv) / 72 KiB (head), static
-    float* As = smem;                       // [2][BM][LDA]
-    float* Bs = smem + 2 * BM * LDA;        // [2][BN][LDA]
+    __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];  // 96 KiB (conv) / 67 KiB (head)
+    float* As = smem;                      // [2][BM][BK]
+    float* Bs = smem + 2 * BM * BK;        // [2][BN][BK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1;   // wave row (64 time steps)
     const int wn = wave & 1;    // wave col (NT*32 channels)
     const int win = blockIdx.x / a.tiles_per_win;
@@ -76,36 +87,30 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(ConvArgs a)
     const int T = a.T;
     const float* __restrict__ inw = a.in + (size_t)win * T * RD_C;
 
-    const int ld_row = tid >> 3;          // 0..31
-    const int ld_col = (tid & 7) * 4;     // 0..28
+    // DMA roles: a wave-instruction moves 8 rows x 128 B; lane -> (row-in-piece, physical 16-B slot)
+    const int dma_r = lane >> 3;
+    const int dma_ps = lane & 7;
 
-    float4 ra[A_F4], rb[B_F4];
-
-    auto load_chunk = [&](int chunk) {
+    auto stage = [&](int chunk, int buf) {
         const int tap = chunk / (RD_C / BK);
         const int ci0 = (chunk - tap * (RD_C / BK)) * BK;
         const int shift = (TAPS - 1 - tap) * a.dil;
+        float* Ab = As + buf * BM * BK;
+        float* Bb = Bs + buf * BN * BK;
 #pragma unroll
-        for (int r = 0; r < A_F4; r++) {
-            const int row = ld_row + 32 * r;
+        for (int r = 0; r < BM / 32; r++) {
+            const int piece = r * 4 + wave;            // 1 KiB piece = rows 8*piece .. 8*piece+7
+            const int row = piece * 8 + dma_r;
+            const int slot = dma_ps ^ ((row >> 1) & 7);
             const int t = t0 + row - shift;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < T) v = *(const float4*)(inw + (size_t)t * RD_C + ci0 + ld_col);
-            ra[r] = v;
+            const float* src = (t >= 0 && t < T) ? inw + (size_t)t * RD_C + ci0 + slot * 4 : a.zeros + dma_ps * 4;
+            glds16(src, Ab + piece * 256);
         }
-        const float4* wsrc = (const float4*)(a.wpk + (size_t)chunk * BN * BK);
+        const float* wsrc = a.wpk + (size_t)chunk * BN * BK + lane * 4;   // pre-swizzled on the host: linear copy
 #pragma unroll
-        for (int r = 0; r < B_F4; r++) rb[r] = wsrc[tid + 256 * r];
-    };
-    auto store_chunk = [&](int buf) {
-        float* Ab = As + buf * BM * LDA;
-        float* Bb = Bs + buf * BN * LDA;
-#pragma unroll
-        for (int r = 0; r < A_F4; r++) *(float4*)(Ab + (ld_row + 32 * r) * LDA + ld_col) = ra[r];
-#pragma unroll
-        for (int r = 0; r < B_F4; r++) {
-            const int idx = tid + 256 * r;
-            *(float4*)(Bb + (idx >> 3) * LDA + (idx & 7) * 4) = rb[r];
+        for (int r = 0; r < BN / 32; r++) {
+            const int piece = r * 4 + wave;
+            glds16(wsrc + piece * 256, Bb + piece * 256);
         }
     };
 
@@ -117,24 +122,47 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(ConvArgs a)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[m][n][e] = 0.f;
 
-    load_chunk(0);
-    store_chunk(0);
+    stage(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
     __syncthreads();
 
     const int fr = lane & 31;
     const int fh = lane >> 5;
+    const int swz = (fr >> 1) & 7;
+    int koff[BK / 8];
+#pragma unroll
+    for (int g = 0; g < BK / 8; g++) koff[g] = ((2 * g + fh) ^ swz) * 4;
+
+    // residual prefetch registers (EPI_RES_IDENT): same (m, n, e) indexing as acc
+    f32x16 res[2][NT];
+
     for (int chunk = 0; chunk < NCHUNK; chunk++) {
         const int buf = chunk & 1;
-        if (chunk + 1 < NCHUNK) load_chunk(chunk + 1);
-        const float* Ab = As + buf * BM * LDA + (wm * 64 + fr) * LDA + 4 * fh;
-        const float* Bb = Bs + buf * BN * LDA + (wn * NT * 32 + fr) * LDA + 4 * fh;
+        if (chunk + 1 < NCHUNK) stage(chunk + 1, buf ^ 1);
+        if constexpr (EPI == EPI_RES_IDENT) {
+            if (chunk == NCHUNK - 1) {
+                // fetch the residual tile under the last chunk's MFMAs (reads precede every store of this thread)
+#pragma unroll
+                for (int n = 0; n < NT; n++)
+#pragma unroll
+                    for (int m = 0; m < 2; m++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++) {
+                            const int t = t0 + wm * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                            const int co = wn * NT * 32 + n * 32 + fr;
+                            res[m][n][e] = (t < T) ? a.resid[((size_t)win * T + t) * RD_C + co] : 0.f;
+                        }
+            }
+        }
+        const float* Ab = As + buf * BM * BK + (wm * 64 + fr) * BK;
+        const float* Bb = Bs + buf * BN * BK + (wn * NT * 32 + fr) * BK;
 #pragma unroll
         for (int g = 0; g < BK / 8; g++) {
             float4 af[2], bf[NT];
 #pragma unroll
-            for (int m = 0; m < 2; m++) af[m] = *(const float4*)(Ab + m * 32 * LDA + 8 * g);
+            for (int m = 0; m < 2; m++) af[m] = *(const float4*)(Ab + m * 32 * BK + koff[g]);
 #pragma unroll
-            for (int n = 0; n < NT; n++) bf[n] = *(const float4*)(Bb + n * 32 * LDA + 8 * g);
+            for (int n = 0; n < NT; n++) bf[n] = *(const float4*)(Bb + n * 32 * BK + koff[g]);
 #pragma unroll
             for (int kr = 0; kr < 4; kr++) {
 #pragma unroll
@@ -148,8 +176,7 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(ConvArgs a)
                 }
             }
         }
-        if (chunk + 1 < NCHUNK) store_chunk(buf ^ 1);
-        __syncthreads();
+        __syncthreads();   // drains the DMA of chunk+1 (vmcnt(0)) and fences the buffer swap
     }
 
     // ---------------- epilogue ----------------
@@ -175,7 +202,7 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(ConvArgs a)
                         float v = acc[m][n][e] + bias;
                         v = v > 0.f ? v : 0.f;
                         if constexpr (EPI == EPI_RES_IDENT) {
-                            v += a.resid[((size_t)win * T + t) * RD_C + co];
+                            v += res[m][n][e];
                             v = v > 0.f ? v : 0.f;
                         } else if constexpr (EPI == EPI_RES_MATCH) {
                             const float r = bmt + a.x[(size_t)win * T + t] * wmt;
@@ -306,6 +333,7 @@ int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_
     for (int b = 0; b < m.nblocks; b++) {
         const int d = m.dil[b];
         ConvArgs a = {};
+        a.zeros = m.zeros;
         a.T = T;
         a.dil = d;
         a.tiles_per_win = tiles;
@@ -351,6 +379,7 @@ int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_
         }
     }
     ConvArgs h = {};
+    h.zeros = m.zeros;
     h.T = T;
     h.dil = 0;
     h.tiles_per_win = tiles;
