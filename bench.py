@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-reads", type=int, default=2)
+    ap.add_argument("--cpu-reads", type=int, default=0, help="reads in the CPU-baseline sample (0: sized to the host core count)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,25 +118,37 @@ def main():
         batches.append((d, valid, win))
     labels = np.zeros((BATCH_WINDOWS, CHUNK), dtype=np.uint8)
     lens = np.zeros(BATCH_WINDOWS, dtype=np.int32)
+    # output buffers of the two-stream pipeline (a batch's labels land two submits later / at flush)
+    out = [(np.zeros((BATCH_WINDOWS, CHUNK), dtype=np.uint8), np.full(BATCH_WINDOWS, -1, dtype=np.int32)) for _ in range(2)]
 
     def step(i):
+        """unpipelined: forward -> decode -> labels on the host, one stream (used for the per-kernel timing pass)"""
         d, valid, _ = batches[i % n_batches]
         be.basecall_chunk_resident(d, BATCH_WINDOWS, CHUNK, valid, BEAM, labels, lens)
 
+    def submit(i):
+        """pipelined: forward(i) on the compute stream overlaps beam search + copy-out of batch i-1"""
+        d, valid, _ = batches[i % n_batches]
+        lab, ln = out[i % 2]
+        be.pipe_submit(d, BATCH_WINDOWS, CHUNK, valid, BEAM, lab, ln)
+
     for i in range(args.warmup):
-        step(i)
+        submit(i)
+    be.pipe_flush()
     be.sync()
     if world > 1:
         be.rccl_barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        submit(i)
+    be.pipe_flush()   # every batch's labels are on the host when the clock stops
     be.sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         be.rccl_barrier()
         elapsed = float(be.rccl_allreduce_max([elapsed])[0])
-    assert lens.min() >= 0 and lens.max() <= CHUNK and lens.sum() > 0
+    for lab, ln in out[: max(1, min(2, args.steps))]:
+        assert ln.min() >= 0 and ln.max() <= CHUNK and ln.sum() > 0
 
     samples_per_step = reads_per_batch * READ_LEN  # input samples basecalled per step per GPU
     value = world * args.steps * samples_per_step / elapsed
@@ -179,7 +191,8 @@ def main():
             "decode_timesteps_per_s": float(sum(b[1].sum() for b in batches[:n_prof])) / max(1e-9, td["total_ms"] * 1e-3),
         }
         if world == 1 and not args.no_cpu_baseline:
-            nr = args.cpu_reads
+            ncores = os.cpu_count() or 1
+            nr = args.cpu_reads or max(2, min(reads_per_batch, ncores // 4))   # ~10-30 s of CPU work, all cores busy
             cpu = cpu_baseline(batches[0][2][: nr * 8], batches[0][1][: nr * 8], nr)
 
     if rank == 0:
@@ -195,6 +208,7 @@ def main():
                             "reference basecall.py:110-121) + labels to host; random He-normal weights seed 1234",
                 "chunk_len": CHUNK, "step_size": STEP, "batch_windows": BATCH_WINDOWS, "beam_width": BEAM,
                 "decode_type": "chunk", "samples_per_step_per_gpu": samples_per_step, "sharding": "reads per rank, no data-path collective",
+                "pipelining": "2 HIP streams: forward(i) overlaps beam search + label copy-out of batch i-1; all labels on host at stop",
             },
             "roofline": roof,
         }

@@ -188,6 +188,13 @@ class Backend:
     def decode_resident(self, d_probs, n, T, valid_len, beam_width, labels, lens):
         self._check(self._L.rd_decode_resident(self._h, d_probs, n, T, _p(valid_len), int(beam_width), _p(labels), _p(lens)))
 
+    def pipe_submit(self, d_windows, n, T, valid_len, beam_width, labels, lens):
+        """Two-stream pipeline (rd_pipe_submit): labels/lens are filled two submits later or at pipe_flush()."""
+        self._check(self._L.rd_pipe_submit(self._h, d_windows, n, T, _p(valid_len), int(beam_width), _p(labels), _p(lens)))
+
+    def pipe_flush(self):
+        self._check(self._L.rd_pipe_flush(self._h))
+
     def timer_enable(self, which, max_launches):
         self._check(self._L.rd_timer_enable(self._h, which, max_launches))
 

@@ -110,6 +110,7 @@ static void timer_free(KernelTimer& t)
 }
 
 extern "C" int rd_rccl_finalize(rd_ctx* ctx);
+void rd_pipe_destroy_internal(rd_ctx* ctx);
 
 extern "C" int rd_destroy(rd_ctx* ctx)
 {
@@ -117,6 +118,7 @@ extern "C" int rd_destroy(rd_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     rd_rccl_finalize(ctx);
+    rd_pipe_destroy_internal(ctx);
     timer_free(ctx->timer_conv);
     timer_free(ctx->timer_decode);
     timer_free(ctx->timer_head);
@@ -199,13 +201,13 @@ void model_bind(Model& m, const ModelLayout& L)
 // LDS image order (forward.hip): rows of 32 floats whose 16-B slots are XOR-swizzled by (row >> 1) & 7.
 static inline int swz_k(int row, int k) { return ((((k >> 2) ^ ((row >> 1) & 7)) << 2) | (k & 3)); }
 
-// Keras conv kernel [j][ci][co] -> [chunk = j*8 + ci/32][co][swizzled ci%32]
+// Keras conv kernel [j][ci][co] -> [chunk = (ci/32)*3 + j][co][swizzled ci%32]
 void pack_conv(const float* k, float* dst)
 {
     for (int j = 0; j < RD_K; j++)
         for (int ci = 0; ci < RD_C; ci++) {
             const float* src = k + ((size_t)j * RD_C + ci) * RD_C;
-            const int chunk = j * (RD_C / 32) + ci / 32;
+            const int chunk = (ci / 32) * RD_K + j;
             float* d = dst + (size_t)chunk * RD_C * 32;
             for (int co = 0; co < RD_C; co++) d[(size_t)co * 32 + swz_k(co, ci % 32)] = src[co];
         }
@@ -620,6 +622,173 @@ extern "C" int rd_basecall_global(rd_ctx* ctx, const float* windows, int chunk_l
         for (size_t i = 0; i < idx.size(); i++) label_len[idx[i]] = ll[i];
     }
     return RD_OK;
+}
+
+
+// --------------------------------------------------------------------------------------------- two-stream pipeline
+// Chunk-mode batches flow through two HIP streams: the forward of batch i+1 (MFMA-bound, ctx->stream) overlaps the
+// beam search of batch i (VALU/latency-bound, a second high-priority stream) and its label copy-out.  Two slots of
+// probability / metadata / pinned output buffers; a slot is recycled only after its labels were handed to the caller.
+namespace {
+
+struct PipeSlot {
+    DevBuf probs, meta, labels;
+    void* h_meta = nullptr;
+    size_t h_meta_cap = 0;
+    void* h_out = nullptr;
+    size_t h_out_cap = 0;
+    hipEvent_t fwd_done = nullptr, dec_done = nullptr;
+    bool busy = false;
+    int n = 0, T = 0;
+    uint8_t* user_labels = nullptr;
+    int32_t* user_lens = nullptr;
+};
+
+struct Pipe {
+    hipStream_t s_dec = nullptr;
+    PipeSlot slot[2];
+    int next = 0;
+};
+
+int pinned_reserve(void** p, size_t* cap, size_t bytes)
+{
+    if (bytes <= *cap) return RD_OK;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    size_t want = align_up(bytes + bytes / 8, 1 << 16);
+    RD_HIP(hipHostMalloc(p, want, hipHostMallocDefault));
+    *cap = want;
+    return RD_OK;
+}
+
+int pipe_get(rd_ctx* ctx, Pipe** out)
+{
+    if (!ctx->pipe) {
+        Pipe* p = new Pipe();
+        int lo = 0, hi = 0;
+        RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        RD_HIP(hipStreamCreateWithPriority(&p->s_dec, hipStreamNonBlocking, hi));
+        for (int i = 0; i < 2; i++) {
+            RD_HIP(hipEventCreateWithFlags(&p->slot[i].fwd_done, hipEventDisableTiming));
+            RD_HIP(hipEventCreateWithFlags(&p->slot[i].dec_done, hipEventDisableTiming));
+        }
+        ctx->pipe = p;
+    }
+    *out = (Pipe*)ctx->pipe;
+    return RD_OK;
+}
+
+int pipe_collect(PipeSlot& s)
+{
+    if (!s.busy) return RD_OK;
+    RD_HIP(hipEventSynchronize(s.dec_done));
+    const size_t nT = (size_t)s.n * s.T;
+    const uint8_t* hl = (const uint8_t*)s.h_out;
+    const int32_t* hlen = (const int32_t*)((const char*)s.h_out + align_up(nT, 256));
+    s.busy = false;
+    for (int i = 0; i < s.n; i++) {
+        if (hlen[i] < 0 || hlen[i] > s.T) {
+            rd_set_error("pipeline: window %d produced an impossible label length %d", i, hlen[i]);
+            return RD_ERR_STATE;
+        }
+        s.user_lens[i] = hlen[i];
+        if (hlen[i]) memcpy(s.user_labels + (size_t)i * s.T, hl + (size_t)i * s.T, (size_t)hlen[i]);
+    }
+    return RD_OK;
+}
+
+void pipe_destroy(rd_ctx* ctx)
+{
+    Pipe* p = (Pipe*)ctx->pipe;
+    if (!p) return;
+    if (p->s_dec) (void)hipStreamSynchronize(p->s_dec);
+    for (int i = 0; i < 2; i++) {
+        PipeSlot& s = p->slot[i];
+        s.probs.release();
+        s.meta.release();
+        s.labels.release();
+        if (s.h_meta) (void)hipHostFree(s.h_meta);
+        if (s.h_out) (void)hipHostFree(s.h_out);
+        if (s.fwd_done) (void)hipEventDestroy(s.fwd_done);
+        if (s.dec_done) (void)hipEventDestroy(s.dec_done);
+    }
+    if (p->s_dec) (void)hipStreamDestroy(p->s_dec);
+    delete p;
+    ctx->pipe = nullptr;
+}
+
+}  // namespace
+
+void rd_pipe_destroy_internal(rd_ctx* ctx) { pipe_destroy(ctx); }
+
+extern "C" int rd_pipe_submit(rd_ctx* ctx, const float* d_windows, int n_windows, int chunk_len, const int32_t* valid_len,
+                              int beam_width, uint8_t* labels_out, int32_t* label_len)
+{
+    RD_REQUIRE(ctx && d_windows && valid_len && labels_out && label_len, "rd_pipe_submit: null argument");
+    RD_REQUIRE(n_windows >= 1 && chunk_len >= 1, "rd_pipe_submit: bad shape");
+    RD_REQUIRE(beam_width >= 1 && beam_width <= rd_decode_max_width(), "beam_width %d out of range", beam_width);
+    RD_HIP(hipSetDevice(ctx->device));
+    Pipe* p = nullptr;
+    int rc = pipe_get(ctx, &p);
+    if (rc) return rc;
+    PipeSlot& s = p->slot[p->next];
+    if ((rc = pipe_collect(s))) return rc;  // the slot's previous batch (two submits ago) goes to its caller first
+    const size_t n = (size_t)n_windows, nT = n * chunk_len;
+    if (s.probs.reserve(nT * 20)) return RD_ERR_NOMEM;
+    // forward on the compute stream
+    rc = rd_forward_dev(ctx, d_windows, n_windows, chunk_len, s.probs.as<float>());
+    if (rc) return rc;
+    RD_HIP(hipEventRecord(s.fwd_done, ctx->stream));
+    // metadata: [seq_off | node_off | label_off] int64, then seq_len int32, then label_len int32 (device only)
+    const size_t o_node = align_up(n * 8, 256), o_lab = 2 * o_node, o_len = 3 * o_node, o_llen = o_len + align_up(n * 4, 256);
+    const size_t meta_bytes = o_llen + align_up(n * 4, 256);
+    if ((rc = pinned_reserve(&s.h_meta, &s.h_meta_cap, meta_bytes))) return rc;
+    if (s.meta.reserve(meta_bytes)) return RD_ERR_NOMEM;
+    int64_t* h_seq = (int64_t*)s.h_meta;
+    int64_t* h_node = (int64_t*)((char*)s.h_meta + o_node);
+    int64_t* h_lab = (int64_t*)((char*)s.h_meta + o_lab);
+    int32_t* h_len = (int32_t*)((char*)s.h_meta + o_len);
+    int64_t nodes = 0;
+    for (int i = 0; i < n_windows; i++) {
+        RD_REQUIRE(valid_len[i] >= 0 && valid_len[i] <= chunk_len, "valid_len[%d]=%d out of range", i, valid_len[i]);
+        h_seq[i] = (int64_t)i * chunk_len;
+        h_lab[i] = (int64_t)i * chunk_len;
+        h_node[i] = nodes;
+        nodes += 1 + (int64_t)beam_width * valid_len[i];
+        h_len[i] = valid_len[i];
+    }
+    if (s.labels.reserve(nT + 16)) return RD_ERR_NOMEM;
+    if ((rc = pinned_reserve(&s.h_out, &s.h_out_cap, align_up(nT, 256) + n * 4))) return rc;
+    // decode stream: wait for the probabilities, upload metadata, search, copy labels out
+    RD_HIP(hipStreamWaitEvent(p->s_dec, s.fwd_done, 0));
+    RD_HIP(hipMemcpyAsync(s.meta.p, s.h_meta, o_llen, hipMemcpyHostToDevice, p->s_dec));
+    char* dm = (char*)s.meta.p;
+    rc = rd_decode_dev(ctx, s.probs.p, 0, (const int64_t*)dm, (const int32_t*)(dm + o_len), (const int64_t*)(dm + o_node),
+                       (const int64_t*)(dm + o_lab), n_windows, nodes, beam_width, 0, 0.0, 0.0, s.labels.as<uint8_t>(),
+                       (int32_t*)(dm + o_llen), nullptr, p->s_dec);
+    if (rc) return rc;
+    RD_HIP(hipMemcpyAsync(s.h_out, s.labels.p, nT, hipMemcpyDeviceToHost, p->s_dec));
+    RD_HIP(hipMemcpyAsync((char*)s.h_out + align_up(nT, 256), dm + o_llen, n * 4, hipMemcpyDeviceToHost, p->s_dec));
+    RD_HIP(hipEventRecord(s.dec_done, p->s_dec));
+    s.busy = true;
+    s.n = n_windows;
+    s.T = chunk_len;
+    s.user_labels = labels_out;
+    s.user_lens = label_len;
+    p->next ^= 1;
+    return RD_OK;
+}
+
+extern "C" int rd_pipe_flush(rd_ctx* ctx)
+{
+    RD_REQUIRE(ctx, "rd_pipe_flush: null context");
+    Pipe* p = (Pipe*)ctx->pipe;
+    if (!p) return RD_OK;
+    RD_HIP(hipSetDevice(ctx->device));
+    int rc = pipe_collect(p->slot[p->next]);  // older batch first
+    if (rc) return rc;
+    return pipe_collect(p->slot[p->next ^ 1]);
 }
 
 // --------------------------------------------------------------------------------------------- device memory

@@ -99,6 +99,7 @@ struct rd_ctx {
     size_t h_stage_cap = 0;
     KernelTimer timer_conv, timer_decode, timer_head, timer_in;
     void* rccl = nullptr;  // RcclState*
+    void* pipe = nullptr;  // Pipe* (two-stream forward/decode software pipeline)
 };
 
 // forward.hip
@@ -106,7 +107,8 @@ int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_
 // decode.hip
 int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* d_seq_off, const int32_t* d_seq_len,
                   const int64_t* d_node_off, const int64_t* d_label_off, int n_seq, int64_t total_nodes, int W, int use_lm,
-                  double s_thr, double r_thr, uint8_t* d_labels, int32_t* d_label_len, double* d_best_score);
+                  double s_thr, double r_thr, uint8_t* d_labels, int32_t* d_label_len, double* d_best_score,
+                  hipStream_t stream = nullptr /* default: ctx->stream */);
 // assemble.hip
 int rd_assemble_dev(rd_ctx* ctx, const float* d_probs, int nW, int T, int pad, int step, double* d_out, int64_t N);
 

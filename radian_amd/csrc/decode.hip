@@ -417,22 +417,22 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
 }
 
 template <typename PT, int R>
-int launch_r(rd_ctx* ctx, const DecodeArgs& a, int n_seq, bool lm)
+int launch_r(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
 {
     if (lm)
-        hipLaunchKernelGGL((beam_search_kernel<PT, R, true>), dim3(n_seq), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL((beam_search_kernel<PT, R, true>), dim3(n_seq), dim3(64), 0, st, a);
     else
-        hipLaunchKernelGGL((beam_search_kernel<PT, R, false>), dim3(n_seq), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL((beam_search_kernel<PT, R, false>), dim3(n_seq), dim3(64), 0, st, a);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }
 
 template <typename PT>
-int launch_pt(rd_ctx* ctx, const DecodeArgs& a, int n_seq, bool lm)
+int launch_pt(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
 {
-    if (a.W <= Cfg<1>::WM) return launch_r<PT, 1>(ctx, a, n_seq, lm);
-    if (a.W <= Cfg<2>::WM) return launch_r<PT, 2>(ctx, a, n_seq, lm);
-    return launch_r<PT, 4>(ctx, a, n_seq, lm);
+    if (a.W <= Cfg<1>::WM) return launch_r<PT, 1>(st, a, n_seq, lm);
+    if (a.W <= Cfg<2>::WM) return launch_r<PT, 2>(st, a, n_seq, lm);
+    return launch_r<PT, 4>(st, a, n_seq, lm);
 }
 
 __global__ void lm_gate_kernel(const double* __restrict__ entropy, size_t n, double r_thr, uint32_t* __restrict__ bits)
@@ -472,8 +472,9 @@ static int ensure_lm_gate(rd_ctx* ctx, double r_thr)
 
 int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* d_seq_off, const int32_t* d_seq_len,
                   const int64_t* d_node_off, const int64_t* d_label_off, int n_seq, int64_t total_nodes, int W, int use_lm,
-                  double s_thr, double r_thr, uint8_t* d_labels, int32_t* d_label_len, double* d_best_score)
+                  double s_thr, double r_thr, uint8_t* d_labels, int32_t* d_label_len, double* d_best_score, hipStream_t stream)
 {
+    hipStream_t st = stream ? stream : ctx->stream;
     RD_REQUIRE(W >= 1 && W <= Cfg<4>::WM, "beam_width %d out of range [1,%d]", W, Cfg<4>::WM);
     if (n_seq == 0) return RD_OK;
     if (use_lm) {
@@ -503,11 +504,11 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* d
     a.label_len = d_label_len;
     a.best_score = d_best_score;
     KernelTimer& tm = ctx->timer_decode;
-    if (tm.enabled && tm.used < tm.starts.size()) RD_HIP(hipEventRecord(tm.starts[tm.used], ctx->stream));
-    int rc = is_f64 ? launch_pt<double>(ctx, a, n_seq, use_lm != 0) : launch_pt<float>(ctx, a, n_seq, use_lm != 0);
+    if (tm.enabled && tm.used < tm.starts.size()) RD_HIP(hipEventRecord(tm.starts[tm.used], st));
+    int rc = is_f64 ? launch_pt<double>(st, a, n_seq, use_lm != 0) : launch_pt<float>(st, a, n_seq, use_lm != 0);
     if (rc) return rc;
     if (tm.enabled && tm.used < tm.starts.size()) {
-        RD_HIP(hipEventRecord(tm.stops[tm.used], ctx->stream));
+        RD_HIP(hipEventRecord(tm.stops[tm.used], st));
         tm.used++;
     }
     return RD_OK;

@@ -27,6 +27,8 @@
 // 128 -> 5 and applies softmax from LDS.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -65,17 +67,17 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_dst)
 }
 
 template <int NT, int TAPS, int EPI>
-__global__ __launch_bounds__(256) void tcn_gemm_kernel(ConvArgs a)
+__global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
 {
     constexpr int BN = 2 * NT * 32;       // output channels per workgroup (2 waves along N)
     constexpr int NCHUNK = TAPS * (RD_C / BK);
-    constexpr int STAGE_FLOATS = 2 * (BM + BN) * BK;
+    constexpr int STAGE_FLOATS = (BM + BN) * BK;   // ONE stage: two workgroups per CU cover each other's DMA latency
     constexpr int HEAD_FLOATS = BM * (RD_H + 1) + RD_H * 5 + 8;
     constexpr int SMEM_FLOATS = (EPI == EPI_HEAD && HEAD_FLOATS > STAGE_FLOATS) ? HEAD_FLOATS : STAGE_FLOATS;
 
-    __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];  // 96 KiB (conv) / 67 KiB (head)
-    float* As = smem;                      // [2][BM][BK]
-    float* Bs = smem + 2 * BM * BK;        // [2][BN][BK]
+    __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];  // 48 KiB (conv) / 67 KiB (head)
+    float* As = smem;                  // [BM][BK]
+    float* Bs = smem + BM * BK;        // [BN][BK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -91,12 +93,12 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(ConvArgs a)
     const int dma_r = lane >> 3;
     const int dma_ps = lane & 7;
 
-    auto stage = [&](int chunk, int buf) {
-        const int tap = chunk / (RD_C / BK);
-        const int ci0 = (chunk - tap * (RD_C / BK)) * BK;
+    auto stage = [&](int chunk) {
+        // chunk order: input-channel chunk outer, tap inner -> the three shifted reads of the same rows are adjacent in time
+        const int cc = chunk / TAPS;
+        const int tap = chunk - cc * TAPS;
+        const int ci0 = cc * BK;
         const int shift = (TAPS - 1 - tap) * a.dil;
-        float* Ab = As + buf * BM * BK;
-        float* Bb = Bs + buf * BN * BK;
 #pragma unroll
         for (int r = 0; r < BM / 32; r++) {
             const int piece = r * 4 + wave;            // 1 KiB piece = rows 8*piece .. 8*piece+7
@@ -104,13 +106,13 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(ConvArgs a)
             const int slot = dma_ps ^ ((row >> 1) & 7);
             const int t = t0 + row - shift;
             const float* src = (t >= 0 && t < T) ? inw + (size_t)t * RD_C + ci0 + slot * 4 : a.zeros + dma_ps * 4;
-            glds16(src, Ab + piece * 256);
+            glds16(src, As + piece * 256);
         }
         const float* wsrc = a.wpk + (size_t)chunk * BN * BK + lane * 4;   // pre-swizzled on the host: linear copy
 #pragma unroll
         for (int r = 0; r < BN / 32; r++) {
             const int piece = r * 4 + wave;
-            glds16(wsrc + piece * 256, Bb + piece * 256);
+            glds16(wsrc + piece * 256, Bs + piece * 256);
         }
     };
 
@@ -122,40 +124,20 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(ConvArgs a)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[m][n][e] = 0.f;
 
-    stage(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-    __syncthreads();
-
     const int fr = lane & 31;
     const int fh = lane >> 5;
     const int swz = (fr >> 1) & 7;
     int koff[BK / 8];
 #pragma unroll
     for (int g = 0; g < BK / 8; g++) koff[g] = ((2 * g + fh) ^ swz) * 4;
-
-    // residual prefetch registers (EPI_RES_IDENT): same (m, n, e) indexing as acc
-    f32x16 res[2][NT];
+    const float* Ab = As + (wm * 64 + fr) * BK;
+    const float* Bb = Bs + (wn * NT * 32 + fr) * BK;
 
     for (int chunk = 0; chunk < NCHUNK; chunk++) {
-        const int buf = chunk & 1;
-        if (chunk + 1 < NCHUNK) stage(chunk + 1, buf ^ 1);
-        if constexpr (EPI == EPI_RES_IDENT) {
-            if (chunk == NCHUNK - 1) {
-                // fetch the residual tile under the last chunk's MFMAs (reads precede every store of this thread)
-#pragma unroll
-                for (int n = 0; n < NT; n++)
-#pragma unroll
-                    for (int m = 0; m < 2; m++)
-#pragma unroll
-                        for (int e = 0; e < 16; e++) {
-                            const int t = t0 + wm * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                            const int co = wn * NT * 32 + n * 32 + fr;
-                            res[m][n][e] = (t < T) ? a.resid[((size_t)win * T + t) * RD_C + co] : 0.f;
-                        }
-            }
-        }
-        const float* Ab = As + buf * BM * BK + (wm * 64 + fr) * BK;
-        const float* Bb = Bs + buf * BN * BK + (wn * NT * 32 + fr) * BK;
+        if (chunk) __syncthreads();          // every wave has read the previous chunk out of LDS
+        stage(chunk);
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's DMA pieces have landed
+        __syncthreads();                     // ... and everyone else's
 #pragma unroll
         for (int g = 0; g < BK / 8; g++) {
             float4 af[2], bf[NT];
@@ -176,44 +158,64 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(ConvArgs a)
                 }
             }
         }
-        __syncthreads();   // drains the DMA of chunk+1 (vmcnt(0)) and fences the buffer swap
     }
+    if constexpr (EPI == EPI_HEAD) __syncthreads();   // staging LDS is reused by the head epilogue
 
     // ---------------- epilogue ----------------
     // C/D layout of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     if constexpr (EPI != EPI_HEAD) {
-        float* outw = a.out + (size_t)win * T * RD_C;  // may alias a.resid (in-place residual)
+        // out may alias resid (in-place residual): each element is read, then written, by the same thread only, so the
+        // restrict-qualified views just let the compiler batch a row's loads ahead of the previous row's stores.
+        float* __restrict__ outw = a.out + (size_t)win * T * RD_C;
+        const float* __restrict__ resw = (EPI == EPI_RES_IDENT) ? a.resid + (size_t)win * T * RD_C : nullptr;
+        float bias[NT], wmt[NT], bmt[NT];
 #pragma unroll
         for (int n = 0; n < NT; n++) {
             const int co = wn * NT * 32 + n * 32 + fr;
-            const float bias = a.bias[co];
-            float wmt = 0.f, bmt = 0.f;
+            bias[n] = a.bias[co];
+            wmt[n] = bmt[n] = 0.f;
             if constexpr (EPI == EPI_RES_MATCH) {
-                wmt = a.wmatch[co];
-                bmt = a.bmatch[co];
+                wmt[n] = a.wmatch[co];
+                bmt[n] = a.bmatch[co];
             }
+        }
+        // one code path without per-element bounds checks for interior tiles (no branch / wait per store)
+        auto emit = [&](auto guard_tag) {
+            constexpr bool GUARD = decltype(guard_tag)::value;
 #pragma unroll
             for (int m = 0; m < 2; m++) {
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const int row = wm * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
                     const int t = t0 + row;
-                    if (t < T) {
-                        float v = acc[m][n][e] + bias;
+                    if (GUARD && t >= T) continue;
+                    float xv = 0.f;
+                    if constexpr (EPI == EPI_RES_MATCH) xv = a.x[(size_t)win * T + t];
+                    float* orow = outw + (size_t)t * RD_C + wn * NT * 32 + fr;
+                    float rv[NT];
+                    if constexpr (EPI == EPI_RES_IDENT) {
+                        const float* rrow = resw + (size_t)t * RD_C + wn * NT * 32 + fr;
+#pragma unroll
+                        for (int n = 0; n < NT; n++) rv[n] = rrow[n * 32];
+                    }
+#pragma unroll
+                    for (int n = 0; n < NT; n++) {
+                        float v = acc[m][n][e] + bias[n];
                         v = v > 0.f ? v : 0.f;
                         if constexpr (EPI == EPI_RES_IDENT) {
-                            v += res[m][n][e];
+                            v += rv[n];
                             v = v > 0.f ? v : 0.f;
                         } else if constexpr (EPI == EPI_RES_MATCH) {
-                            const float r = bmt + a.x[(size_t)win * T + t] * wmt;
-                            v = r + v;
+                            v = (bmt[n] + xv * wmt[n]) + v;
                             v = v > 0.f ? v : 0.f;
                         }
-                        outw[(size_t)t * RD_C + co] = v;
+                        orow[n * 32] = v;
                     }
                 }
             }
-        }
+        };
+        if (t0 + BM <= T) emit(std::false_type{});
+        else emit(std::true_type{});
     } else {
         // Dense(128) bias + ReLU into LDS, then Dense(5) + softmax   (model.py:72-75)
         constexpr int LDH = RD_H + 1;

@@ -131,6 +131,36 @@ def test_fused_global_equals_separate(be, oracle):
     be.load_lm(None, 0)
 
 
+def test_pipeline_equals_unpipelined(be):
+    """rd_pipe_submit/flush (two streams, batch i+1 forward overlapping batch i decode) == rd_basecall_chunk."""
+    rng = np.random.default_rng(8)
+    n, T = 24, 1024
+    batches = []
+    for b in range(5):
+        x = rng.normal(size=(n, T)).astype(np.float32)
+        valid = np.full(n, T, dtype=np.int32)
+        valid[7::8] = 512
+        valid[3] = 0
+        batches.append((x, valid))
+    ref = [be.basecall_chunk(x, v, 10) for x, v in batches]
+    dptr = []
+    for x, _ in batches:
+        d = be.dev_alloc(x.nbytes)
+        be.h2d(d, x)
+        dptr.append(d)
+    outs = [(np.zeros((n, T), dtype=np.uint8), np.full(n, -1, dtype=np.int32)) for _ in batches]
+    for b, (x, v) in enumerate(batches):
+        be.pipe_submit(dptr[b], n, T, v, 10, outs[b][0], outs[b][1])
+    be.pipe_flush()
+    for b in range(len(batches)):
+        lab, ln = outs[b]
+        for i in range(n):
+            assert ln[i] == len(ref[b][i]), (b, i)
+            assert np.array_equal(lab[i, : ln[i]], ref[b][i]), (b, i)
+    for d in dptr:
+        be.dev_free(d)
+
+
 def test_forward_requires_weights():
     from radian_amd import Backend, RadianHipError
     b = Backend(0)
