@@ -30,27 +30,6 @@ FLOP_PER_CONV_ROW = 2 * 256 * 256 * 3  # one dilated conv, per window time step
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 
 
-def rendezvous_uid(be, rank, world):
-    """rank 0 creates the 128-byte RCCL id and publishes it in a file; the others poll for it."""
-    port = os.environ.get("MASTER_PORT", "29500")
-    run = os.environ.get("TORCHELASTIC_RUN_ID", "none")
-    path = f"/tmp/radian_rccl_uid_{port}_{run}_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}"
-    if rank == 0:
-        uid = be.rccl_unique_id()
-        tmp = path + ".tmp"
-        with open(tmp, "wb") as f:
-            f.write(uid)
-        os.replace(tmp, path)
-        return uid, path
-    t0 = time.time()
-    while not os.path.exists(path):
-        if time.time() - t0 > 120:
-            raise RuntimeError("timed out waiting for the RCCL unique id from rank 0")
-        time.sleep(0.01)
-    with open(path, "rb") as f:
-        return f.read(), path
-
-
 def cpu_baseline(windows, valid, n_reads):
     """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload, all host cores."""
     from oracle import oracle as orc
@@ -97,7 +76,9 @@ def main():
     be = Backend(local_rank)
     uid_path = None
     if world > 1:
-        uid, uid_path = rendezvous_uid(be, rank, world)
+        from radian_amd import dist
+        uid_path = dist.uid_path()
+        uid = dist.exchange_uid(be.rccl_unique_id, rank, uid_path)   # 128-byte id through a file; no PyTorch here
         be.rccl_init(rank, world, uid)
         if rank == 0:
             be.load_weights(weights.synthetic_weights(seed=1234))

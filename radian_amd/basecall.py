@@ -1,0 +1,215 @@
+"""Drop-in for radian/basecall.py: same command line, fast5 in, FASTA out -- the loop body runs on the MI355X.
+
+    python -m radian_amd.basecall fast5_dir fasta_dir [--chunk-len 1024] [--step-size 128] [--batch-size 32]
+           [--outlier-clip 4] [--rna-model models/rnamodel_12mer_pc.json | None] [--sig-model models/sig2seq.h5]
+           [--sig-config models/sig2seq.yaml] [--beam-width 6] [--decode-type {global,chunk}] [--sig-threshold 0.5]
+           [--rna-threshold 0.5] [--context-len 11] [--local]
+
+Flags, defaults, read order, FASTA naming/rotation and the stdout lines follow radian/basecall.py:19-141.
+What differs (results do not): reads are batched ACROSS reads for the GPU (the forward is batch independent,
+SURVEY F10), so `--batch-size` only bounds nothing any more (`--gpu-batch-windows` sizes device batches);
+`--rna-model None` disables the LM in global mode instead of crashing at decode.py:83; `--sig-model` also
+accepts `synthetic[:seed]` (seeded He-normal weights: the reference's sig2seq.h5 is not distributed with
+the source tree) and packed `.rdnw` blobs; extra flags `--device`, `--gpus`.
+"""
+import argparse
+import os
+import sys
+from time import time
+
+import numpy as np
+
+from . import fast5, lm as lm_mod, weights as weights_mod
+from .preprocess import mad_normalise, get_windows
+from .sequence_assembly import consensus_sequence, labels_to_str
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description="Basecall a nanopore dRNA sequencing run.")
+    parser.add_argument("fast5_dir", help="Directory of single/multi fast5 files.")
+    parser.add_argument("fasta_dir", help="Directory to output fasta files.")
+    parser.add_argument("--local", action="store_true")
+    parser.add_argument("--chunk-len", default=1024, type=int)
+    parser.add_argument("--step-size", default=128, type=int)
+    parser.add_argument("--batch-size", default=32, type=int)
+    parser.add_argument("--outlier-clip", default=4, type=int)
+    parser.add_argument("--rna-model", default="models/rnamodel_12mer_pc.json")
+    parser.add_argument("--sig-model", default="models/sig2seq.h5")
+    parser.add_argument("--sig-config", default="models/sig2seq.yaml")
+    parser.add_argument("--beam-width", default=6, type=int)
+    parser.add_argument("--decode-type", choices=["global", "chunk"], default="global")
+    parser.add_argument("--sig-threshold", default=0.5, type=float)
+    parser.add_argument("--rna-threshold", default=0.5, type=float)
+    parser.add_argument("--context-len", default=11, type=int)
+    # extensions
+    parser.add_argument("--device", default=0, type=int, help="GPU index (single-process run)")
+    parser.add_argument("--gpus", default=1, type=int, help="shard reads over this many GPUs (one process each)")
+    parser.add_argument("--gpu-batch-windows", default=512, type=int, help="windows per device batch (across reads)")
+    return parser
+
+
+def load_dilations(sig_config):
+    """models/sig2seq.yaml `model.tcn` -> per-block dilations; checks the fixed geometry (sig2seq.yaml:34-49)."""
+    if not sig_config or not os.path.exists(sig_config):
+        return weights_mod.DEFAULT_DILATIONS
+    import yaml
+    with open(sig_config) as f:
+        cfg = yaml.safe_load(f)
+    m = cfg["model"]
+    t = m["tcn"]
+    if (t["nb_filters"], t["kernel_size"], m["relu_units"], m["softmax_units"]) != (256, 3, 128, 5):
+        raise ValueError("sig-config geometry differs from sig2seq.yaml's (256 filters, k=3, 128 relu units, 5 classes)")
+    if t.get("use_skip_connections") or t.get("use_batch_norm") or t.get("dropout_rate", 0.0) not in (0, 0.0) \
+            or t.get("padding") != "causal" or t.get("activation") != "relu":
+        raise ValueError("sig-config uses TCN options this backend does not implement (skip connections / batch norm / dropout / non-causal)")
+    return tuple(int(d) for d in t["dilations"]) * int(t.get("nb_stacks", 1))
+
+
+def load_sig_model(spec, dilations):
+    """Flat float32 parameters in load_weights order (radian/model.py:42-45)."""
+    if spec.startswith("synthetic"):
+        seed = int(spec.split(":", 1)[1]) if ":" in spec else 1234
+        return weights_mod.synthetic_weights(seed=seed, dilations=dilations)
+    if spec.endswith(".rdnw"):
+        with open(spec, "rb") as f:
+            flat, dil = weights_mod.unpack_blob(f.read())
+        if tuple(dil) != tuple(dilations):
+            raise ValueError(f"{spec}: dilations {dil} differ from the config's {dilations}")
+        return flat
+    from .h5weights import read_keras_weights
+    return read_keras_weights(spec, dilations)
+
+
+class FastaWriter:
+    """reads-{n}.fasta with a new file after every 1000 reads (basecall.py:65-67,129-141)."""
+
+    def __init__(self, fasta_dir):
+        self.dir = fasta_dir
+        self.n = 0
+        self.i = 0
+        self.f = open(f"{fasta_dir}/reads-{self.n}.fasta", "w")
+
+    def write(self, read_id, sequence):
+        self.f.write(f">{read_id}\n{sequence[::-1]}\n")  # reversed to be 5' to 3' (basecall.py:129)
+        self.i += 1
+        if self.i == 1000:
+            self.f.close()
+            self.n += 1
+            self.f = open(f"{self.dir}/reads-{self.n}.fasta", "w")
+            self.i = 0
+
+    def close(self):
+        self.f.close()
+
+
+def preprocess_read(read, args):
+    """basecall.py:76-83.  Returns (windows float32 [nW, chunk], pad) or None when the read is skipped."""
+    raw_signal = read.get_raw_data()
+    try:
+        norm_signal = mad_normalise(raw_signal, args.outlier_clip)
+    except ValueError as e:
+        print(e.args)
+        print(f"{read.read_id} signal issue, skipping this read.")
+        return None
+    windows, pad = get_windows(norm_signal, args.chunk_len, args.step_size)
+    return windows.astype(np.float32), pad
+
+
+def basecall_batch(be, batch, args, use_lm):
+    """batch: list of (read_id, windows, pad).  Returns the sequences (un-reversed) in batch order."""
+    windows = np.concatenate([w for _, w, _ in batch], axis=0)
+    if args.decode_type == "global":
+        off = np.zeros(len(batch) + 1, dtype=np.int32)
+        off[1:] = np.cumsum([w.shape[0] for _, w, _ in batch])
+        pads = np.array([p for _, _, p in batch], dtype=np.int32)
+        labels = be.basecall_global(windows, off, pads, args.step_size, args.beam_width, use_lm,
+                                    args.sig_threshold, args.rna_threshold)
+        return [labels_to_str(l) for l in labels]
+    valid = np.concatenate([np.r_[np.full(w.shape[0] - 1, args.chunk_len, dtype=np.int32), np.int32(args.chunk_len - p)]
+                            for _, w, p in batch]).astype(np.int32)
+    frags = be.basecall_chunk(windows, valid, args.beam_width)
+    out, i = [], 0
+    for _, w, _ in batch:
+        read_fragments = [labels_to_str(f) for f in frags[i:i + w.shape[0]]]
+        i += w.shape[0]
+        out.append(consensus_sequence(read_fragments))  # basecall.py:122-123
+    return out
+
+
+def run(args, be, reads=None, writer=None, shard=(0, 1)):
+    """The driver loop (basecall.py:69-141) over `reads` (default: every read under args.fast5_dir).
+    shard=(rank, world): this process handles reads whose index % world == rank and returns
+    [(read_index, read_id, sequence)] instead of writing when writer is None."""
+    if reads is None:
+        reads = fast5.iter_directory(args.fast5_dir)
+    use_lm = getattr(args, "_lm_loaded", False) and args.decode_type == "global"
+    rank, world = shard
+    results = []
+    batch, batch_idx, n_win = [], [], 0
+
+    def flush():
+        nonlocal batch, batch_idx, n_win
+        if not batch:
+            return
+        t0 = time()
+        seqs = basecall_batch(be, batch, args, use_lm)
+        dur = (time() - t0) / len(batch)
+        for (rid, _, _), idx, seq in zip(batch, batch_idx, seqs):
+            if writer is not None:
+                writer.write(rid, seq)
+            results.append((idx, rid, seq))
+            print(f"Basecalled read {rid} in {dur:.2f} sec.")
+        batch, batch_idx, n_win = [], [], 0
+
+    for idx, read in enumerate(reads):
+        if idx % world != rank:
+            continue
+        pre = preprocess_read(read, args)
+        if pre is None:
+            continue
+        w, pad = pre
+        if batch and n_win + w.shape[0] > args.gpu_batch_windows:
+            flush()
+        batch.append((read.read_id, w, pad))
+        batch_idx.append(idx)
+        n_win += w.shape[0]
+    flush()
+    return results
+
+
+def setup_backend(args, be):
+    """Load weights and (when given) the RNA model into a Backend; mirrors basecall.py:47-62."""
+    dil = load_dilations(args.sig_config)
+    be.load_weights(load_sig_model(args.sig_model, dil), dil)
+    args._lm_loaded = False
+    if args.rna_model != "None":
+        if os.path.exists(args.rna_model):
+            table, k = lm_mod.load_json(args.rna_model)
+            if args.decode_type == "global":
+                if k != args.context_len:
+                    raise KeyError(f"--context-len {args.context_len} does not match the RNA model's context length {k} "
+                                   "(the reference fails with KeyError at decode.py:83)")
+                be.load_lm(table, k)
+                args._lm_loaded = True
+        elif args.decode_type == "global":
+            raise FileNotFoundError(args.rna_model)
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.gpus > 1:
+        from .launch import run_multi_gpu
+        return run_multi_gpu(args, argv if argv is not None else sys.argv[1:])
+    from .backend import Backend
+    be = Backend(args.device)
+    setup_backend(args, be)
+    writer = FastaWriter(args.fasta_dir)
+    try:
+        run(args, be, writer=writer)
+    finally:
+        writer.close()  # basecall.py:141
+        be.close()
+
+
+if __name__ == "__main__":
+    main()

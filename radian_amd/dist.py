@@ -1,0 +1,151 @@
+"""Process-group plumbing for the multi-GPU path: one process per GPU, reads sharded by index, ONE start-up
+broadcast of the artefacts, no data-path collective.
+
+Two interchangeable transports behind the same four calls (barrier, allreduce_max, bcast_artifacts, close):
+  * RcclComm  -- RCCL over xGMI through libradian_hip.so's rd_rccl_* (the GPU path; no PyTorch in the process);
+  * GlooComm  -- torch.distributed `gloo` on CPU tensors (used by the CPU tests to exercise the same
+                 sharding / merge logic with world_size 2, and usable on hosts without RCCL).
+"""
+import os
+import time
+
+import numpy as np
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def _proc_start_time(pid):
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            return f.read().rsplit(")", 1)[1].split()[19]  # field 22: start time in clock ticks since boot
+    except Exception:
+        return "0"
+
+
+def uid_path(tag=None):
+    """Rendezvous file for the RCCL unique id.  All ranks of one launch are children of the same launcher process
+    (torch.distributed.run's agent, or radian_amd.launch), so its pid + start time names the launch uniquely and a
+    file left behind by an earlier, crashed launch can never be picked up."""
+    if tag is None:
+        ppid = os.getppid()
+        tag = f"{os.environ.get('MASTER_PORT', '29500')}_{ppid}_{_proc_start_time(ppid)}"
+    return f"/tmp/radian_rccl_uid_{tag}"
+
+
+def exchange_uid(make_uid, rank, path, timeout=120.0):
+    """rank 0 publishes the 128-byte RCCL unique id through a file (atomic rename); the others poll for it."""
+    if rank == 0:
+        uid = make_uid()
+        tmp = path + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > timeout:
+            raise RuntimeError("timed out waiting for the RCCL unique id from rank 0")
+        time.sleep(0.01)
+    with open(path, "rb") as f:
+        return f.read()
+
+
+class SingleComm:
+    rank, world = 0, 1
+
+    def barrier(self):
+        pass
+
+    def allreduce_max(self, values):
+        return np.asarray(values, dtype=np.float64)
+
+    def bcast_artifacts(self, be, load_fn):
+        load_fn(be)
+
+    def close(self):
+        pass
+
+
+class RcclComm:
+    """RCCL communicator owned by the Backend's rd_ctx."""
+
+    def __init__(self, be, rank, world, uid_file):
+        self.be, self.rank, self.world, self._uid_file = be, rank, world, uid_file
+        uid = exchange_uid(be.rccl_unique_id, rank, uid_file)
+        be.rccl_init(rank, world, uid)
+
+    def barrier(self):
+        self.be.rccl_barrier()
+
+    def allreduce_max(self, values):
+        return self.be.rccl_allreduce_max(values)
+
+    def bcast_artifacts(self, be, load_fn):
+        """rank 0 loads + repacks weights / LM, then one broadcast puts the device images on every rank."""
+        if self.rank == 0:
+            load_fn(be)
+        be.rccl_bcast_model(0)
+
+    def close(self):
+        if self.rank == 0 and os.path.exists(self._uid_file):
+            os.remove(self._uid_file)
+
+
+class GlooComm:
+    """torch.distributed gloo; artefacts travel as host bytes and every rank loads them itself."""
+
+    def __init__(self, rank, world, init_method=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.rank, self.world = rank, world
+        if not dist.is_initialized():
+            dist.init_process_group("gloo", rank=rank, world_size=world, init_method=init_method)
+
+    def barrier(self):
+        self._dist.barrier()
+
+    def allreduce_max(self, values):
+        import torch
+        t = torch.tensor(np.asarray(values, dtype=np.float64))
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return t.numpy()
+
+    def bcast_artifacts(self, be, load_fn):
+        """load_fn(be) must call be.load_weights(flat, dilations) / be.load_lm(table, k); rank 0 runs it against a
+        recorder, the recorded host arrays are broadcast, every rank replays them into its own backend."""
+        rec = _Recorder()
+        if self.rank == 0:
+            load_fn(rec)
+        box = [rec.calls if self.rank == 0 else None]
+        self._dist.broadcast_object_list(box, src=0)
+        for name, a, kw in box[0]:
+            getattr(be, name)(*a, **kw)
+
+    def close(self):
+        if self._dist.is_initialized():
+            self._dist.destroy_process_group()
+
+
+class _Recorder:
+    def __init__(self):
+        self.calls = []
+
+    def load_weights(self, *a, **kw):
+        self.calls.append(("load_weights", a, kw))
+
+    def load_lm(self, *a, **kw):
+        self.calls.append(("load_lm", a, kw))
+
+
+def shard_indices(n, rank, world):
+    """Round-robin shard of read indices (what basecall.run uses: index % world == rank)."""
+    return list(range(rank, n, world))
+
+
+def merge_results(per_rank_results):
+    """[(read_index, read_id, sequence)] lists from every rank -> one list in input order."""
+    merged = [r for rr in per_rank_results for r in rr]
+    merged.sort(key=lambda r: r[0])
+    return merged

@@ -1,0 +1,40 @@
+"""Test double with the Backend interface, computed by the CPU oracle.  TESTS ONLY: lets the host-side driver,
+sharding and merge logic run without a GPU (the product itself has no CPU path)."""
+import numpy as np
+
+from oracle import oracle as orc
+
+
+class OracleBackend:
+    def __init__(self, device_id=0):
+        self.w = None
+        self.dil = None
+        self.lm = None
+        self.k = 0
+
+    def load_weights(self, flat, dilations=(1, 2, 4, 8, 16, 32)):
+        self.w = np.asarray(flat, dtype=np.float32)
+        self.dil = tuple(dilations)
+
+    def load_lm(self, table, k):
+        self.lm, self.k = (None, 0) if table is None else (np.asarray(table, dtype=np.float64), k)
+
+    def forward(self, windows):
+        return orc.tcn_forward(self.w, np.asarray(windows, dtype=np.float32), dilations=self.dil)
+
+    def basecall_chunk(self, windows, valid_len, beam_width):
+        probs = self.forward(windows)
+        return [orc.beam_search_labels(probs[i, : valid_len[i]], beam_width)[0] for i in range(probs.shape[0])]
+
+    def basecall_global(self, windows, read_win_off, pads, step, beam_width, use_lm, s_threshold=0.0, r_threshold=0.0):
+        probs = self.forward(windows)
+        out = []
+        for r in range(len(pads)):
+            m = orc.assemble_matrices(probs[read_win_off[r]:read_win_off[r + 1]], int(pads[r]), step)
+            lab, _ = orc.beam_search_labels(m, beam_width, self.lm if use_lm else None, s_threshold, r_threshold,
+                                            self.k if use_lm else 0)
+            out.append(lab)
+        return out
+
+    def close(self):
+        pass

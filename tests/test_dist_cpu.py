@@ -1,0 +1,58 @@
+"""N>1 path on CPU: world_size-2 gloo job running the product's sharded driver; merged output must equal the
+single-process run, in input order."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("mode", ["chunk", "global"])
+def test_two_rank_gloo_equals_single(tmp_path, mode, oracle):
+    world = 2
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="3")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(tmp_path), mode], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    from radian_amd import basecall, dist, weights
+    from _oracle_backend import OracleBackend
+    from _reads import golden_reads
+    import numpy as np
+    per_rank = []
+    for rank in range(world):
+        with open(tmp_path / f"rank{rank}.jsonl") as f:
+            per_rank.append([tuple(json.loads(l)) for l in f])
+    assert sorted(i for i, _, _ in per_rank[0]) == dist.shard_indices(5, 0, 2)
+    assert sorted(i for i, _, _ in per_rank[1]) == dist.shard_indices(5, 1, 2)
+    merged = dist.merge_results(per_rank)
+    # single process reference run of the same driver
+    args = basecall.build_parser().parse_args(
+        ["a", "b", "--chunk-len", "256", "--step-size", "128", "--beam-width", "4", "--decode-type", mode,
+         "--gpu-batch-windows", "24", "--context-len", "3"])
+    be = OracleBackend()
+    be.load_weights(weights.synthetic_weights(seed=5, dilations=(1, 2, 4)), (1, 2, 4))
+    if mode == "global":
+        be.load_lm(np.random.default_rng(9).dirichlet([0.3] * 4, size=64), 3)
+    args._lm_loaded = mode == "global"
+    single = basecall.run(args, be, reads=golden_reads(1500), writer=None)
+    assert [tuple(x) for x in merged] == [tuple(x) for x in single]
+    assert [i for i, _, _ in merged] == [0, 1, 2, 3, 4]
+    assert all(len(s) > 0 for _, _, s in merged)

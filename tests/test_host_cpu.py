@@ -1,0 +1,153 @@
+"""Host-side product logic without a GPU: preprocess / stitch / LM loader against the golden vectors, fast5 and
+Keras-h5 readers, the CLI contract and the driver loop (with the oracle-backed test double)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def test_product_preprocess_matches_golden(golden_dir):
+    from radian_amd import preprocess as P
+    g = json.load(open(os.path.join(golden_dir, "preprocess_cases.json")))
+    arr = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    for c in g["cases"]:
+        sig = arr["sig_" + c["name"]]
+        if "error" in c:
+            with pytest.raises(ValueError) as ei:
+                P.mad_normalise(sig, c["clip"])
+            assert ei.value.args[0] == c["error"]
+            continue
+        n = P.mad_normalise(sig, c["clip"])
+        assert str(n.dtype) == c["norm_dtype"] and np.array_equal(n, arr["norm_" + c["name"]]), c["name"]
+        w, pad = P.get_windows(n, c["chunk"], c["step"])
+        assert pad == c["pad"] and str(w.dtype) == c["win_dtype"] and np.array_equal(w, arr["win_" + c["name"]]), c["name"]
+    for e in g["window_errors"]:
+        with pytest.raises(ValueError) as ei:
+            P.get_windows(np.zeros(100), e["chunk"], e["step"])
+        assert ei.value.args[0] == e["error"]
+
+
+def test_product_stitch_matches_golden(golden_dir):
+    from radian_amd import sequence_assembly as S
+    g = json.load(open(os.path.join(golden_dir, "seq_assembly_cases.json")))
+    for c in g["cases"]:
+        cons = S.simple_assembly(c["fragments"])
+        assert list(cons.shape) == c["consensus_shape"]
+        assert np.array_equal(cons.astype(np.int64), np.array(c["consensus"], dtype=np.int64).reshape(cons.shape))
+        assert S.consensus_sequence(c["fragments"]) == c["seq"]
+
+
+def test_lm_json_loader(tmp_path):
+    from radian_amd import lm
+    rng = np.random.default_rng(0)
+    k = 3
+    raw = {}
+    for i in range(4 ** k):
+        ctx = "".join("ACGT"[(i >> (2 * (k - 1 - j))) & 3] for j in range(k))
+        raw[ctx] = [float(x) for x in rng.dirichlet([0.3] * 4)]
+    p = tmp_path / "lm.json"
+    p.write_text(json.dumps(raw))
+    table, kk = lm.load_json(str(p))
+    assert kk == k and table.shape == (64, 4)
+    # index = base-4 number of the context, first char most significant (tuple keys of basecall.py:56)
+    assert np.array_equal(table[lm.context_index("GTA")], raw["GTA"])
+    assert lm.context_index("GTA") == 2 * 16 + 3 * 4 + 0 == lm.context_index((2, 3, 0))
+    del raw["AAA"]
+    p.write_text(json.dumps(raw))
+    with pytest.raises(ValueError):
+        lm.load_json(str(p))
+
+
+def _have_hdf5():
+    try:
+        from radian_amd import h5
+        h5.lib()
+        return True
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(not _have_hdf5(), reason="libhdf5 not available")
+def test_fast5_reader_roundtrip_and_reference_file(tmp_path, golden_dir):
+    from radian_amd import fast5
+    ids = json.load(open(os.path.join(golden_dir, "reads_fast5_ids.json")))["read_ids"]
+    sig = np.load(os.path.join(golden_dir, "reads_fast5_signals.npz"))
+    sub = tmp_path / "a" / "b"
+    sub.mkdir(parents=True)
+    fast5.write_multi_fast5(str(sub / "x.fast5"), {r: sig[r] for r in ids})
+    got = [(r.read_id, r.get_raw_data()) for r in fast5.iter_directory(str(tmp_path))]  # recursive like rglob
+    assert [g[0] for g in got] == ids
+    assert all(a.dtype == np.int16 and np.array_equal(a, sig[r]) for r, a in got)
+    ref = "/root/reference/radian/data/reads.fast5"   # build container only
+    if os.path.exists(ref):
+        got = [(r.read_id, r.get_raw_data()) for r in fast5.iter_reads(ref)]
+        assert [g[0] for g in got] == ids
+        assert all(np.array_equal(a, sig[r]) for r, a in got)
+
+
+@pytest.mark.skipif(not _have_hdf5(), reason="libhdf5 not available")
+def test_keras_h5_converter_roundtrip(tmp_path):
+    from radian_amd import h5weights, weights
+    w = weights.synthetic_weights(seed=3)
+    p = str(tmp_path / "sig2seq.h5")
+    h5weights.write_keras_weights(p, w)
+    assert np.array_equal(h5weights.read_keras_weights(p), w)
+    with pytest.raises(ValueError):
+        h5weights.read_keras_weights(p, dilations=(1, 2, 4))
+
+
+def test_cli_flags_match_reference():
+    """radian/basecall.py:19-35: names, defaults and types of the 13 flags + 2 positionals."""
+    from radian_amd import basecall
+    a = basecall.build_parser().parse_args(["in", "out"])
+    assert (a.fast5_dir, a.fasta_dir) == ("in", "out")
+    assert a.local is False and a.chunk_len == 1024 and a.step_size == 128 and a.batch_size == 32
+    assert a.outlier_clip == 4 and isinstance(a.outlier_clip, int)
+    assert a.rna_model == "models/rnamodel_12mer_pc.json" and a.sig_model == "models/sig2seq.h5"
+    assert a.sig_config == "models/sig2seq.yaml" and a.beam_width == 6 and a.decode_type == "global"
+    assert a.sig_threshold == 0.5 and a.rna_threshold == 0.5 and a.context_len == 11
+    with pytest.raises(SystemExit):
+        basecall.build_parser().parse_args(["in", "out", "--decode-type", "greedy"])
+
+
+def test_fasta_writer_rotation(tmp_path):
+    from radian_amd.basecall import FastaWriter
+    w = FastaWriter(str(tmp_path))
+    for i in range(2000):
+        w.write(f"r{i}", "ACGT")
+    w.close()
+    files = sorted(os.listdir(tmp_path))
+    assert files == ["reads-0.fasta", "reads-1.fasta", "reads-2.fasta"]  # empty trailing file, like the reference
+    assert open(tmp_path / "reads-0.fasta").read().startswith(">r0\nTGCA\n")  # reversed to 5'->3'
+    assert sum(1 for _ in open(tmp_path / "reads-1.fasta")) == 2000
+    assert os.path.getsize(tmp_path / "reads-2.fasta") == 0
+
+
+@pytest.mark.parametrize("mode", ["chunk", "global"])
+def test_driver_loop_with_test_double(mode, oracle, capsys):
+    """basecall.run: cross-read batching gives the same result as one read per batch; bad reads are skipped with the
+    reference's messages (basecall.py:77-82)."""
+    from radian_amd import basecall, weights
+    from _oracle_backend import OracleBackend
+    from _reads import golden_reads
+    be = OracleBackend()
+    be.load_weights(weights.synthetic_weights(seed=5, dilations=(1, 2)), (1, 2))
+    be.load_lm(np.random.default_rng(9).dirichlet([0.3] * 4, size=16), 2)
+    base = ["a", "b", "--chunk-len", "128", "--step-size", "64", "--beam-width", "3", "--decode-type", mode, "--context-len", "2"]
+    outs = []
+    for gbw in ("1", "40"):
+        args = basecall.build_parser().parse_args(base + ["--gpu-batch-windows", gbw])
+        args._lm_loaded = True
+        outs.append(basecall.run(args, be, reads=golden_reads(700, extra_bad=True), writer=None))
+    assert outs[0] == outs[1]
+    assert len(outs[0]) == 5 and [i for i, _, _ in outs[0]] == [0, 1, 3, 5, 6]
+    text = capsys.readouterr().out
+    assert "flat-signal signal issue, skipping this read." in text
+    assert "('MAD is zero, issue with signal.',)" in text
+    assert "('Signal must not be empty to normalise',)" in text
+    assert text.count("Basecalled read ") == 10
