@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode-group", type=int, default=8, help="batches per beam-search launch in the two-stream pipeline")
     ap.add_argument("--cpu-reads", type=int, default=0, help="reads in the CPU-baseline sample (0: sized to the host core count)")
     args = ap.parse_args()
 
@@ -100,7 +101,9 @@ def main():
     labels = np.zeros((BATCH_WINDOWS, CHUNK), dtype=np.uint8)
     lens = np.zeros(BATCH_WINDOWS, dtype=np.int32)
     # output buffers of the two-stream pipeline (a batch's labels land two submits later / at flush)
-    out = [(np.zeros((BATCH_WINDOWS, CHUNK), dtype=np.uint8), np.full(BATCH_WINDOWS, -1, dtype=np.int32)) for _ in range(2)]
+    be.pipe_config(args.decode_group)
+    out = [(np.zeros((BATCH_WINDOWS, CHUNK), dtype=np.uint8), np.full(BATCH_WINDOWS, -1, dtype=np.int32))
+           for _ in range(2 * args.decode_group)]
 
     def step(i):
         """unpipelined: forward -> decode -> labels on the host, one stream (used for the per-kernel timing pass)"""
@@ -110,7 +113,7 @@ def main():
     def submit(i):
         """pipelined: forward(i) on the compute stream overlaps beam search + copy-out of batch i-1"""
         d, valid, _ = batches[i % n_batches]
-        lab, ln = out[i % 2]
+        lab, ln = out[i % len(out)]
         be.pipe_submit(d, BATCH_WINDOWS, CHUNK, valid, BEAM, lab, ln)
 
     for i in range(args.warmup):
@@ -128,7 +131,7 @@ def main():
     if world > 1:
         be.rccl_barrier()
         elapsed = float(be.rccl_allreduce_max([elapsed])[0])
-    for lab, ln in out[: max(1, min(2, args.steps))]:
+    for lab, ln in out[: max(1, min(len(out), args.steps))]:
         assert ln.min() >= 0 and ln.max() <= CHUNK and ln.sum() > 0
 
     samples_per_step = reads_per_batch * READ_LEN  # input samples basecalled per step per GPU
@@ -189,7 +192,7 @@ def main():
                             "reference basecall.py:110-121) + labels to host; random He-normal weights seed 1234",
                 "chunk_len": CHUNK, "step_size": STEP, "batch_windows": BATCH_WINDOWS, "beam_width": BEAM,
                 "decode_type": "chunk", "samples_per_step_per_gpu": samples_per_step, "sharding": "reads per rank, no data-path collective",
-                "pipelining": "2 HIP streams: forward(i) overlaps beam search + label copy-out of batch i-1; all labels on host at stop",
+                "pipelining": f"2 HIP streams: forwards back to back; beam search + label copy-out of a group of {args.decode_group} batches overlaps the next group's forwards; all labels on host at stop",
             },
             "roofline": roof,
         }

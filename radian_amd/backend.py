@@ -192,6 +192,9 @@ class Backend:
         """Two-stream pipeline (rd_pipe_submit): labels/lens are filled two submits later or at pipe_flush()."""
         self._check(self._L.rd_pipe_submit(self._h, d_windows, n, T, _p(valid_len), int(beam_width), _p(labels), _p(lens)))
 
+    def pipe_config(self, group_batches):
+        self._check(self._L.rd_pipe_config(self._h, int(group_batches)))
+
     def pipe_flush(self):
         self._check(self._L.rd_pipe_flush(self._h))
 

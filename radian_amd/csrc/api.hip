@@ -626,10 +626,19 @@ extern "C" int rd_basecall_global(rd_ctx* ctx, const float* windows, int chunk_l
 
 
 // --------------------------------------------------------------------------------------------- two-stream pipeline
-// Chunk-mode batches flow through two HIP streams: the forward of batch i+1 (MFMA-bound, ctx->stream) overlaps the
-// beam search of batch i (VALU/latency-bound, a second high-priority stream) and its label copy-out.  Two slots of
-// probability / metadata / pinned output buffers; a slot is recycled only after its labels were handed to the caller.
+// Chunk-mode batches flow through two HIP streams: forwards (MFMA-bound) run back to back on ctx->stream; the beam
+// search (one wave per window, latency-bound) of a GROUP of batches runs on a second, high-priority stream together
+// with its label copy-out, overlapped with the forwards of the next group.  Grouping matters because the decoder's
+// throughput comes from waves per SIMD: 4 x 512 windows decode in about the time of 512.  Two slots of probability /
+// metadata / pinned output buffers; a slot is recycled only after its labels were handed to the caller.
 namespace {
+
+struct PipeSub {
+    int n = 0;          // windows of this submitted batch
+    int win0 = 0;       // first window inside the slot
+    uint8_t* user_labels = nullptr;
+    int32_t* user_lens = nullptr;
+};
 
 struct PipeSlot {
     DevBuf probs, meta, labels;
@@ -638,16 +647,18 @@ struct PipeSlot {
     void* h_out = nullptr;
     size_t h_out_cap = 0;
     hipEvent_t fwd_done = nullptr, dec_done = nullptr;
-    bool busy = false;
-    int n = 0, T = 0;
-    uint8_t* user_labels = nullptr;
-    int32_t* user_lens = nullptr;
+    bool busy = false;      // decode launched, labels not yet delivered
+    int T = 0, W = 0, nwin = 0;
+    std::vector<PipeSub> subs;
+    std::vector<int32_t> valid;
 };
 
 struct Pipe {
     hipStream_t s_dec = nullptr;
     PipeSlot slot[2];
-    int next = 0;
+    int cur = 0;
+    int group = 4;          // batches per decode launch
+    int cap_windows = 0;    // probs capacity of a slot, in windows
 };
 
 int pinned_reserve(void** p, size_t* cap, size_t bytes)
@@ -683,18 +694,65 @@ int pipe_collect(PipeSlot& s)
 {
     if (!s.busy) return RD_OK;
     RD_HIP(hipEventSynchronize(s.dec_done));
-    const size_t nT = (size_t)s.n * s.T;
+    const size_t nT = (size_t)s.nwin * s.T;
     const uint8_t* hl = (const uint8_t*)s.h_out;
     const int32_t* hlen = (const int32_t*)((const char*)s.h_out + align_up(nT, 256));
     s.busy = false;
-    for (int i = 0; i < s.n; i++) {
-        if (hlen[i] < 0 || hlen[i] > s.T) {
-            rd_set_error("pipeline: window %d produced an impossible label length %d", i, hlen[i]);
-            return RD_ERR_STATE;
+    int rc = RD_OK;
+    for (const PipeSub& sb : s.subs)
+        for (int i = 0; i < sb.n; i++) {
+            const int w = sb.win0 + i;
+            if (hlen[w] < 0 || hlen[w] > s.T) {
+                rd_set_error("pipeline: window %d produced an impossible label length %d", w, hlen[w]);
+                rc = RD_ERR_STATE;
+                continue;
+            }
+            sb.user_lens[i] = hlen[w];
+            if (hlen[w]) memcpy(sb.user_labels + (size_t)i * s.T, hl + (size_t)w * s.T, (size_t)hlen[w]);
         }
-        s.user_lens[i] = hlen[i];
-        if (hlen[i]) memcpy(s.user_labels + (size_t)i * s.T, hl + (size_t)i * s.T, (size_t)hlen[i]);
+    s.subs.clear();
+    s.valid.clear();
+    s.nwin = 0;
+    return rc;
+}
+
+// launch the beam search + copy-out of everything forwarded into the slot so far
+int pipe_launch_decode(rd_ctx* ctx, Pipe* p, PipeSlot& s)
+{
+    if (s.nwin == 0 || s.busy) return RD_OK;
+    int rc;
+    const size_t n = (size_t)s.nwin, nT = n * s.T;
+    RD_HIP(hipEventRecord(s.fwd_done, ctx->stream));
+    // metadata: [seq_off | node_off | label_off] int64, then seq_len int32, then label_len int32 (device only)
+    const size_t o_node = align_up(n * 8, 256), o_lab = 2 * o_node, o_len = 3 * o_node, o_llen = o_len + align_up(n * 4, 256);
+    const size_t meta_bytes = o_llen + align_up(n * 4, 256);
+    if ((rc = pinned_reserve(&s.h_meta, &s.h_meta_cap, meta_bytes))) return rc;
+    if (s.meta.reserve(meta_bytes)) return RD_ERR_NOMEM;
+    int64_t* h_seq = (int64_t*)s.h_meta;
+    int64_t* h_node = (int64_t*)((char*)s.h_meta + o_node);
+    int64_t* h_lab = (int64_t*)((char*)s.h_meta + o_lab);
+    int32_t* h_len = (int32_t*)((char*)s.h_meta + o_len);
+    int64_t nodes = 0;
+    for (int i = 0; i < s.nwin; i++) {
+        h_seq[i] = (int64_t)i * s.T;
+        h_lab[i] = (int64_t)i * s.T;
+        h_node[i] = nodes;
+        nodes += 1 + (int64_t)s.W * s.valid[i];
+        h_len[i] = s.valid[i];
     }
+    if (s.labels.reserve(nT + 16)) return RD_ERR_NOMEM;
+    if ((rc = pinned_reserve(&s.h_out, &s.h_out_cap, align_up(nT, 256) + n * 4))) return rc;
+    RD_HIP(hipStreamWaitEvent(p->s_dec, s.fwd_done, 0));
+    RD_HIP(hipMemcpyAsync(s.meta.p, s.h_meta, o_llen, hipMemcpyHostToDevice, p->s_dec));
+    char* dm = (char*)s.meta.p;
+    rc = rd_decode_dev(ctx, s.probs.p, 0, (const int64_t*)dm, (const int32_t*)(dm + o_len), (const int64_t*)(dm + o_node),
+                       (const int64_t*)(dm + o_lab), s.nwin, nodes, s.W, 0, 0.0, 0.0, s.labels.as<uint8_t>(),
+                       (int32_t*)(dm + o_llen), nullptr, p->s_dec);
+    if (rc) return rc;
+    RD_HIP(hipMemcpyAsync(s.h_out, s.labels.p, nT, hipMemcpyDeviceToHost, p->s_dec));
+    RD_HIP(hipMemcpyAsync((char*)s.h_out + align_up(nT, 256), dm + o_llen, n * 4, hipMemcpyDeviceToHost, p->s_dec));
+    RD_HIP(hipEventRecord(s.dec_done, p->s_dec));
+    s.busy = true;
     return RD_OK;
 }
 
@@ -722,61 +780,68 @@ void pipe_destroy(rd_ctx* ctx)
 
 void rd_pipe_destroy_internal(rd_ctx* ctx) { pipe_destroy(ctx); }
 
+extern "C" int rd_pipe_config(rd_ctx* ctx, int group_batches)
+{
+    RD_REQUIRE(ctx, "rd_pipe_config: null context");
+    RD_REQUIRE(group_batches >= 1 && group_batches <= 64, "rd_pipe_config: group_batches %d out of range [1,64]", group_batches);
+    RD_HIP(hipSetDevice(ctx->device));
+    Pipe* p = nullptr;
+    int rc = pipe_get(ctx, &p);
+    if (rc) return rc;
+    RD_REQUIRE(p->slot[0].nwin == 0 && p->slot[1].nwin == 0 && !p->slot[0].busy && !p->slot[1].busy,
+               "rd_pipe_config: pipeline not empty (call rd_pipe_flush first)");
+    p->group = group_batches;
+    return RD_OK;
+}
+
 extern "C" int rd_pipe_submit(rd_ctx* ctx, const float* d_windows, int n_windows, int chunk_len, const int32_t* valid_len,
                               int beam_width, uint8_t* labels_out, int32_t* label_len)
 {
     RD_REQUIRE(ctx && d_windows && valid_len && labels_out && label_len, "rd_pipe_submit: null argument");
     RD_REQUIRE(n_windows >= 1 && chunk_len >= 1, "rd_pipe_submit: bad shape");
     RD_REQUIRE(beam_width >= 1 && beam_width <= rd_decode_max_width(), "beam_width %d out of range", beam_width);
+    for (int i = 0; i < n_windows; i++)
+        RD_REQUIRE(valid_len[i] >= 0 && valid_len[i] <= chunk_len, "valid_len[%d]=%d out of range", i, valid_len[i]);
     RD_HIP(hipSetDevice(ctx->device));
     Pipe* p = nullptr;
     int rc = pipe_get(ctx, &p);
     if (rc) return rc;
-    PipeSlot& s = p->slot[p->next];
-    if ((rc = pipe_collect(s))) return rc;  // the slot's previous batch (two submits ago) goes to its caller first
-    const size_t n = (size_t)n_windows, nT = n * chunk_len;
-    if (s.probs.reserve(nT * 20)) return RD_ERR_NOMEM;
-    // forward on the compute stream
-    rc = rd_forward_dev(ctx, d_windows, n_windows, chunk_len, s.probs.as<float>());
-    if (rc) return rc;
-    RD_HIP(hipEventRecord(s.fwd_done, ctx->stream));
-    // metadata: [seq_off | node_off | label_off] int64, then seq_len int32, then label_len int32 (device only)
-    const size_t o_node = align_up(n * 8, 256), o_lab = 2 * o_node, o_len = 3 * o_node, o_llen = o_len + align_up(n * 4, 256);
-    const size_t meta_bytes = o_llen + align_up(n * 4, 256);
-    if ((rc = pinned_reserve(&s.h_meta, &s.h_meta_cap, meta_bytes))) return rc;
-    if (s.meta.reserve(meta_bytes)) return RD_ERR_NOMEM;
-    int64_t* h_seq = (int64_t*)s.h_meta;
-    int64_t* h_node = (int64_t*)((char*)s.h_meta + o_node);
-    int64_t* h_lab = (int64_t*)((char*)s.h_meta + o_lab);
-    int32_t* h_len = (int32_t*)((char*)s.h_meta + o_len);
-    int64_t nodes = 0;
-    for (int i = 0; i < n_windows; i++) {
-        RD_REQUIRE(valid_len[i] >= 0 && valid_len[i] <= chunk_len, "valid_len[%d]=%d out of range", i, valid_len[i]);
-        h_seq[i] = (int64_t)i * chunk_len;
-        h_lab[i] = (int64_t)i * chunk_len;
-        h_node[i] = nodes;
-        nodes += 1 + (int64_t)beam_width * valid_len[i];
-        h_len[i] = valid_len[i];
+    PipeSlot* s = &p->slot[p->cur];
+    // a group is homogeneous in chunk_len and beam width and bounded in size; otherwise close it and move on
+    if (s->nwin > 0 && (s->T != chunk_len || s->W != beam_width || (int)s->subs.size() >= p->group)) {
+        if ((rc = pipe_launch_decode(ctx, p, *s))) return rc;
+        p->cur ^= 1;
+        s = &p->slot[p->cur];
     }
-    if (s.labels.reserve(nT + 16)) return RD_ERR_NOMEM;
-    if ((rc = pinned_reserve(&s.h_out, &s.h_out_cap, align_up(nT, 256) + n * 4))) return rc;
-    // decode stream: wait for the probabilities, upload metadata, search, copy labels out
-    RD_HIP(hipStreamWaitEvent(p->s_dec, s.fwd_done, 0));
-    RD_HIP(hipMemcpyAsync(s.meta.p, s.h_meta, o_llen, hipMemcpyHostToDevice, p->s_dec));
-    char* dm = (char*)s.meta.p;
-    rc = rd_decode_dev(ctx, s.probs.p, 0, (const int64_t*)dm, (const int32_t*)(dm + o_len), (const int64_t*)(dm + o_node),
-                       (const int64_t*)(dm + o_lab), n_windows, nodes, beam_width, 0, 0.0, 0.0, s.labels.as<uint8_t>(),
-                       (int32_t*)(dm + o_llen), nullptr, p->s_dec);
+    if (s->busy && (rc = pipe_collect(*s))) return rc;   // the slot's previous group goes to its callers first
+    const size_t need = (size_t)(s->nwin + n_windows) * chunk_len * 20;
+    if (need > s->probs.cap) {
+        if (s->nwin > 0) {
+            // growing would move probabilities already produced: close the group instead
+            if ((rc = pipe_launch_decode(ctx, p, *s))) return rc;
+            p->cur ^= 1;
+            s = &p->slot[p->cur];
+            if (s->busy && (rc = pipe_collect(*s))) return rc;
+        }
+        const size_t want = (size_t)n_windows * chunk_len * 20 * (size_t)p->group;
+        if (s->probs.reserve(want)) return RD_ERR_NOMEM;
+    }
+    rc = rd_forward_dev(ctx, d_windows, n_windows, chunk_len, s->probs.as<float>() + (size_t)s->nwin * chunk_len * 5);
     if (rc) return rc;
-    RD_HIP(hipMemcpyAsync(s.h_out, s.labels.p, nT, hipMemcpyDeviceToHost, p->s_dec));
-    RD_HIP(hipMemcpyAsync((char*)s.h_out + align_up(nT, 256), dm + o_llen, n * 4, hipMemcpyDeviceToHost, p->s_dec));
-    RD_HIP(hipEventRecord(s.dec_done, p->s_dec));
-    s.busy = true;
-    s.n = n_windows;
-    s.T = chunk_len;
-    s.user_labels = labels_out;
-    s.user_lens = label_len;
-    p->next ^= 1;
+    PipeSub sb;
+    sb.n = n_windows;
+    sb.win0 = s->nwin;
+    sb.user_labels = labels_out;
+    sb.user_lens = label_len;
+    s->subs.push_back(sb);
+    s->valid.insert(s->valid.end(), valid_len, valid_len + n_windows);
+    s->T = chunk_len;
+    s->W = beam_width;
+    s->nwin += n_windows;
+    if ((int)s->subs.size() >= p->group) {
+        if ((rc = pipe_launch_decode(ctx, p, *s))) return rc;
+        p->cur ^= 1;
+    }
     return RD_OK;
 }
 
@@ -786,9 +851,13 @@ extern "C" int rd_pipe_flush(rd_ctx* ctx)
     Pipe* p = (Pipe*)ctx->pipe;
     if (!p) return RD_OK;
     RD_HIP(hipSetDevice(ctx->device));
-    int rc = pipe_collect(p->slot[p->next]);  // older batch first
-    if (rc) return rc;
-    return pipe_collect(p->slot[p->next ^ 1]);
+    int rc;
+    // order of completion on the decode stream: the other slot's group (if any) was launched first
+    PipeSlot& a = p->slot[p->cur ^ 1];
+    PipeSlot& b = p->slot[p->cur];
+    if ((rc = pipe_launch_decode(ctx, p, b))) return rc;
+    if ((rc = pipe_collect(a))) return rc;
+    return pipe_collect(b);
 }
 
 // --------------------------------------------------------------------------------------------- device memory
