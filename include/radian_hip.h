@@ -117,6 +117,23 @@ int rd_basecall_global(rd_ctx* ctx, const float* windows, int chunk_len, int ste
                        const int32_t* pad, int n_reads, int beam_width, int use_lm, double s_thr, double r_thr,
                        uint8_t* labels_out, const int64_t* label_off, int32_t* label_len);
 
+/* ---- reads-level fused paths: windowing happens on the device and each time step is computed once ------------
+ * The loop body of radian/basecall.py:83-121 for a batch of whole reads.  signal = the reads' MAD-normalised samples
+ * (basecall.py:78) packed back to back, read r at [read_off[r], read_off[r+1]) (n_reads+1 offsets, read_off[0] = 0).
+ * Windows are those of get_windows(signal, chunk_len, step) (preprocess.py:4-22).  The causal TCN is evaluated once
+ * over each read ("stream"); a window's rows past the receptive field are the stream's rows and only its first
+ * RF-1 rows are computed separately, so the probabilities -- and the labels -- are bit-identical to the windowed
+ * computation at a fraction of the work.
+ *   chunk : labels of window w (counted across the batch, rd_count_windows per read) at labels_out + w*chunk_len,
+ *           label_len[w]; simple_assembly stays on the host.
+ *   global: labels of read r at labels_out + label_off[r] (capacity >= its number of samples), label_len[r]. */
+int rd_count_windows(int64_t n_samples, int chunk_len, int step);   /* windows get_windows makes of one read */
+int rd_basecall_reads_chunk(rd_ctx* ctx, const float* signal, const int64_t* read_off, int n_reads, int chunk_len,
+                            int step, int beam_width, uint8_t* labels_out, int32_t* label_len);
+int rd_basecall_reads_global(rd_ctx* ctx, const float* signal, const int64_t* read_off, int n_reads, int chunk_len,
+                             int step, int beam_width, int use_lm, double s_thr, double r_thr, uint8_t* labels_out,
+                             const int64_t* label_off, int32_t* label_len);
+
 /* ---- device-resident form (inputs already in HBM; used by bench.py and by pipelined hosts) -- */
 int rd_dev_alloc(rd_ctx* ctx, size_t bytes, void** d_ptr);
 int rd_dev_free(rd_ctx* ctx, void* d_ptr);
@@ -139,6 +156,14 @@ int rd_pipe_config(rd_ctx* ctx, int group_batches);
 int rd_pipe_submit(rd_ctx* ctx, const float* d_windows, int n_windows, int chunk_len, const int32_t* valid_len,
                    int beam_width, uint8_t* labels_out, int32_t* label_len);
 int rd_pipe_flush(rd_ctx* ctx);
+/* reads-level forms with the signal resident in HBM */
+int rd_basecall_reads_chunk_resident(rd_ctx* ctx, const float* d_signal, const int64_t* read_off, int n_reads,
+                                     int chunk_len, int step, int beam_width, uint8_t* labels_out, int32_t* label_len);
+int rd_basecall_reads_global_resident(rd_ctx* ctx, const float* d_signal, const int64_t* read_off, int n_reads,
+                                      int chunk_len, int step, int beam_width, int use_lm, double s_thr, double r_thr,
+                                      uint8_t* labels_out, const int64_t* label_off, int32_t* label_len);
+int rd_pipe_submit_reads(rd_ctx* ctx, const float* d_signal, const int64_t* read_off, int n_reads, int chunk_len,
+                         int step, int beam_width, uint8_t* labels_out, int32_t* label_len);
 
 /* ---- kernel timing on the launch stream (HIP events) --------------------------------------- */
 #define RD_TIMER_CONV 0   /* dilated conv 256->256 (MFMA), the dominant kernel */

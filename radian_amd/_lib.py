@@ -32,6 +32,12 @@ SIGNATURES = {
     "rd_decode_batch": (c_i, [c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp, c_vp]),
     "rd_basecall_chunk": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_i, c_vp, c_vp]),
     "rd_basecall_global": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_vp, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp]),
+    "rd_count_windows": (c_i, [c_i64, c_i, c_i]),
+    "rd_basecall_reads_chunk": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp]),
+    "rd_basecall_reads_global": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp]),
+    "rd_basecall_reads_chunk_resident": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp]),
+    "rd_basecall_reads_global_resident": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp]),
+    "rd_pipe_submit_reads": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp]),
     "rd_dev_alloc": (c_i, [c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "rd_dev_free": (c_i, [c_vp, c_vp]),
     "rd_memcpy_h2d": (c_i, [c_vp, c_vp, c_vp, c_sz]),

@@ -163,6 +163,48 @@ class Backend:
                                                _p(labels), _p(label_off), _p(lens)))
         return [labels[label_off[r]: label_off[r] + lens[r]].copy() for r in range(n_reads)]
 
+    # ------------------------------------------------------------------ reads-level fused paths
+    def count_windows(self, n_samples, chunk_len, step):
+        n = self._L.rd_count_windows(int(n_samples), int(chunk_len), int(step))
+        if n < 0:
+            raise ValueError("bad window geometry")
+        return n
+
+    @staticmethod
+    def _pack_reads(signals):
+        sig = [np.ascontiguousarray(x, dtype=np.float32).ravel() for x in signals]
+        off = np.zeros(len(sig) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([x.shape[0] for x in sig])
+        return (np.concatenate(sig) if sig else np.zeros(0, np.float32)), off
+
+    def basecall_reads_chunk(self, signals, chunk_len, step, beam_width):
+        """Chunk mode over whole (normalised) reads: returns, per read, the list of per-window label arrays
+        (radian/basecall.py:83-121 without the host stitch).  Each time step is computed once (streamed forward)."""
+        flat, off = self._pack_reads(signals)
+        nw = [self.count_windows(off[r + 1] - off[r], chunk_len, step) for r in range(len(signals))]
+        tot = int(sum(nw))
+        labels = np.zeros((tot, chunk_len), dtype=np.uint8)
+        lens = np.zeros(tot, dtype=np.int32)
+        self._check(self._L.rd_basecall_reads_chunk(self._h, _p(flat), _p(off), len(signals), int(chunk_len), int(step),
+                                                    int(beam_width), _p(labels), _p(lens)))
+        out, w = [], 0
+        for n in nw:
+            out.append([labels[w + i, : lens[w + i]].copy() for i in range(n)])
+            w += n
+        return out
+
+    def basecall_reads_global(self, signals, chunk_len, step, beam_width, use_lm, s_threshold=0.0, r_threshold=0.0):
+        """Global mode over whole (normalised) reads (radian/basecall.py:83-109): one label array per read."""
+        flat, off = self._pack_reads(signals)
+        n = len(signals)
+        labels = np.zeros(int(off[-1]) + 1, dtype=np.uint8)
+        lens = np.zeros(n, dtype=np.int32)
+        label_off = np.ascontiguousarray(off[:-1])
+        self._check(self._L.rd_basecall_reads_global(self._h, _p(flat), _p(off), n, int(chunk_len), int(step), int(beam_width),
+                                                     1 if use_lm else 0, float(s_threshold), float(r_threshold), _p(labels),
+                                                     _p(label_off), _p(lens)))
+        return [labels[off[r]: off[r] + lens[r]].copy() for r in range(n)]
+
     # ------------------------------------------------------------------ device-resident (bench)
     def dev_alloc(self, nbytes):
         p = ctypes.c_void_p()
@@ -191,6 +233,15 @@ class Backend:
     def pipe_submit(self, d_windows, n, T, valid_len, beam_width, labels, lens):
         """Two-stream pipeline (rd_pipe_submit): labels/lens are filled two submits later or at pipe_flush()."""
         self._check(self._L.rd_pipe_submit(self._h, d_windows, n, T, _p(valid_len), int(beam_width), _p(labels), _p(lens)))
+
+    def pipe_submit_reads(self, d_signal, read_off, n_reads, chunk_len, step, beam_width, labels, lens):
+        """Pipelined chunk-mode batch of whole reads resident in HBM (rd_pipe_submit_reads)."""
+        self._check(self._L.rd_pipe_submit_reads(self._h, d_signal, _p(read_off), int(n_reads), int(chunk_len), int(step),
+                                                 int(beam_width), _p(labels), _p(lens)))
+
+    def basecall_reads_chunk_resident(self, d_signal, read_off, n_reads, chunk_len, step, beam_width, labels, lens):
+        self._check(self._L.rd_basecall_reads_chunk_resident(self._h, d_signal, _p(read_off), int(n_reads), int(chunk_len),
+                                                             int(step), int(beam_width), _p(labels), _p(lens)))
 
     def pipe_config(self, group_batches):
         self._check(self._L.rd_pipe_config(self._h, int(group_batches)))

@@ -111,6 +111,7 @@ static void timer_free(KernelTimer& t)
 
 extern "C" int rd_rccl_finalize(rd_ctx* ctx);
 void rd_pipe_destroy_internal(rd_ctx* ctx);
+void rd_plan_cache_destroy_internal(rd_ctx* ctx);
 
 extern "C" int rd_destroy(rd_ctx* ctx)
 {
@@ -119,11 +120,12 @@ extern "C" int rd_destroy(rd_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     rd_rccl_finalize(ctx);
     rd_pipe_destroy_internal(ctx);
+    rd_plan_cache_destroy_internal(ctx);
     timer_free(ctx->timer_conv);
     timer_free(ctx->timer_decode);
     timer_free(ctx->timer_head);
     timer_free(ctx->timer_in);
-    DevBuf* bufs[] = {&ctx->ws_in, &ctx->ws_act0, &ctx->ws_act1, &ctx->ws_probs, &ctx->ws_mat, &ctx->ws_seq,
+    DevBuf* bufs[] = {&ctx->ws_tiles, &ctx->ws_in, &ctx->ws_act0, &ctx->ws_act1, &ctx->ws_probs, &ctx->ws_mat, &ctx->ws_seq,
                       &ctx->ws_nodes_child, &ctx->ws_nodes_back, &ctx->ws_labels, &ctx->ws_misc, &ctx->model.storage,
                       &ctx->lm.storage, &ctx->lm.gate_storage};
     for (DevBuf* b : bufs) b->release();
@@ -297,6 +299,13 @@ extern "C" int rd_load_weights(rd_ctx* ctx, const void* blob, size_t nbytes)
     return RD_OK;
 }
 
+int rd_model_halo(const rd_ctx* ctx)
+{
+    int s = 0;
+    for (int b = 0; b < ctx->model.nblocks; b++) s += ctx->model.dil[b];
+    return (RD_K - 1) * 2 * s;
+}
+
 // --------------------------------------------------------------------------------------------- LM
 static void lm_bind(LM& lm)
 {
@@ -343,15 +352,15 @@ namespace {
 
 struct SeqMeta {
     // device pointers inside ctx->ws_seq
-    int64_t *d_seq_off, *d_node_off, *d_label_off;
-    int32_t *d_seq_len, *d_label_len;
+    int64_t *d_seq_off, *d_seq_off2, *d_node_off, *d_label_off;
+    int32_t *d_seq_len, *d_split, *d_label_len;
     double* d_score;
     int64_t total_nodes, total_labels;
 };
 
-// uploads per-sequence metadata; label_off_host may be null (then packed prefix sums are used)
-int prepare_seq_meta(rd_ctx* ctx, const int64_t* seq_off, const int32_t* seq_len, int n_seq, int W, const int64_t* label_off_host,
-                     int64_t label_total_host, SeqMeta& sm, std::vector<int64_t>& label_off_used)
+// uploads per-sequence metadata; seq_off2/split may be null (single source region per sequence)
+int prepare_seq_meta(rd_ctx* ctx, const int64_t* seq_off, const int64_t* seq_off2, const int32_t* split, const int32_t* seq_len,
+                     int n_seq, int W, SeqMeta& sm, std::vector<int64_t>& label_off_used)
 {
     std::vector<int64_t> node_off(n_seq), lab_off(n_seq);
     int64_t nodes = 0, labs = 0;
@@ -362,25 +371,32 @@ int prepare_seq_meta(rd_ctx* ctx, const int64_t* seq_off, const int32_t* seq_len
         lab_off[i] = labs;
         labs += seq_len[i];
     }
-    (void)label_off_host;
-    (void)label_total_host;
     label_off_used = lab_off;
     const size_t n = (size_t)n_seq;
-    size_t bytes = align_up(n * 8, 256) * 3 + align_up(n * 4, 256) * 2 + align_up(n * 8, 256);
-    if (ctx->ws_seq.reserve(bytes)) return RD_ERR_NOMEM;
+    const size_t a8 = align_up(n * 8, 256), a4 = align_up(n * 4, 256);
+    if (ctx->ws_seq.reserve(5 * a8 + 3 * a4)) return RD_ERR_NOMEM;
     char* p = (char*)ctx->ws_seq.p;
-    sm.d_seq_off = (int64_t*)p; p += align_up(n * 8, 256);
-    sm.d_node_off = (int64_t*)p; p += align_up(n * 8, 256);
-    sm.d_label_off = (int64_t*)p; p += align_up(n * 8, 256);
-    sm.d_seq_len = (int32_t*)p; p += align_up(n * 4, 256);
-    sm.d_label_len = (int32_t*)p; p += align_up(n * 4, 256);
-    sm.d_score = (double*)p;
+    sm.d_seq_off = (int64_t*)p; p += a8;
+    sm.d_seq_off2 = (int64_t*)p; p += a8;
+    sm.d_node_off = (int64_t*)p; p += a8;
+    sm.d_label_off = (int64_t*)p; p += a8;
+    sm.d_score = (double*)p; p += a8;
+    sm.d_seq_len = (int32_t*)p; p += a4;
+    sm.d_split = (int32_t*)p; p += a4;
+    sm.d_label_len = (int32_t*)p;
     sm.total_nodes = nodes;
     sm.total_labels = labs;
     RD_HIP(hipMemcpyAsync(sm.d_seq_off, seq_off, n * 8, hipMemcpyHostToDevice, ctx->stream));
     RD_HIP(hipMemcpyAsync(sm.d_seq_len, seq_len, n * 4, hipMemcpyHostToDevice, ctx->stream));
     RD_HIP(hipMemcpyAsync(sm.d_node_off, node_off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
     RD_HIP(hipMemcpyAsync(sm.d_label_off, lab_off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (seq_off2) {
+        RD_HIP(hipMemcpyAsync(sm.d_seq_off2, seq_off2, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        RD_HIP(hipMemcpyAsync(sm.d_split, split, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        sm.d_seq_off2 = nullptr;
+        sm.d_split = nullptr;
+    }
     // the host vectors must outlive the async copies
     RD_HIP(hipStreamSynchronize(ctx->stream));
     return RD_OK;
@@ -389,17 +405,18 @@ int prepare_seq_meta(rd_ctx* ctx, const int64_t* seq_off, const int32_t* seq_len
 // decode sequences over device rows and deliver labels to host buffers
 int decode_and_fetch(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* seq_off, const int32_t* seq_len, int n_seq,
                      int W, int use_lm, double s_thr, double r_thr, uint8_t* labels_out, const int64_t* label_off,
-                     int32_t* label_len, double* best_score)
+                     int32_t* label_len, double* best_score, const int64_t* seq_off2 = nullptr, const int32_t* split = nullptr)
 {
     if (n_seq == 0) return RD_OK;
     SeqMeta sm;
     std::vector<int64_t> lab_off;
-    int rc = prepare_seq_meta(ctx, seq_off, seq_len, n_seq, W, nullptr, 0, sm, lab_off);
+    int rc = prepare_seq_meta(ctx, seq_off, seq_off2, split, seq_len, n_seq, W, sm, lab_off);
     if (rc) return rc;
     if (ctx->ws_labels.reserve((size_t)sm.total_labels + 16)) return RD_ERR_NOMEM;
     uint8_t* d_labels = ctx->ws_labels.as<uint8_t>();
     rc = rd_decode_dev(ctx, d_probs, is_f64, sm.d_seq_off, sm.d_seq_len, sm.d_node_off, sm.d_label_off, n_seq, sm.total_nodes, W,
-                       use_lm, s_thr, r_thr, d_labels, sm.d_label_len, best_score ? sm.d_score : nullptr);
+                       use_lm, s_thr, r_thr, d_labels, sm.d_label_len, best_score ? sm.d_score : nullptr, nullptr, sm.d_seq_off2,
+                       sm.d_split);
     if (rc) return rc;
     std::vector<uint8_t> hl((size_t)sm.total_labels + 16);
     RD_HIP(hipMemcpyAsync(hl.data(), d_labels, (size_t)sm.total_labels, hipMemcpyDeviceToHost, ctx->stream));
@@ -625,6 +642,105 @@ extern "C" int rd_basecall_global(rd_ctx* ctx, const float* windows, int chunk_l
 }
 
 
+// --------------------------------------------------------------------------------------------- reads-level paths
+// The reference windows every read (chunk_len rows every step samples, preprocess.py:4-22) and runs the model on every
+// window, although the TCN is causal with a finite receptive field RF = 1 + (K-1)*2*sum(dilations) (253 samples):
+// row r >= RF-1 of a window does not depend on where the window starts.  So the forward is run ONCE over the whole read
+// (the "stream"); a window's rows >= halo = RF-1 are the stream's rows, and only its first `halo` rows -- the ones that
+// see the window's own zero left-padding -- are computed separately ("heads").  Results are bit-identical to the
+// windowed computation (each output row is the same fp32 fma chain over the same values; tests/test_gpu_reads.py), at
+// N + (nW-1)*halo rows per read instead of nW*chunk_len (chunk mode), or N rows (global mode, where only the earliest
+// covering window's row of each time step is ever used, matrix_assembly.py:46-53; valid when step <= chunk_len - halo).
+namespace {
+
+inline int count_windows(int64_t N, int chunk, int step) { return (N < chunk ? 0 : (int)((N - chunk) / step) + 1) + 1; }
+
+struct WindowGeom {
+    int nW, pad;
+};
+inline WindowGeom window_geom(int64_t N, int chunk, int step)
+{
+    WindowGeom g;
+    g.nW = count_windows(N, chunk, step);
+    const int64_t last_start = (int64_t)(g.nW - 1) * step;
+    g.pad = (int)(chunk - (N - last_start));   // >= 1 always (preprocess.py:17-19)
+    return g;
+}
+
+struct ReadsPlan {
+    std::vector<TileDesc> tiles;
+    // per decoded sequence (chunk mode: window; global mode: read)
+    std::vector<int64_t> off1, off2;
+    std::vector<int32_t> split, valid;
+    std::vector<int32_t> read_win_off;   // n_reads + 1
+    std::vector<int64_t> read_row;       // first stream row of each read
+    int64_t total_rows = 0;
+    int n_windows = 0;
+};
+
+void add_segment(ReadsPlan& P, int64_t seg_row, int64_t src_row, int len)
+{
+    for (int t0 = 0; t0 < len; t0 += 128) {
+        TileDesc td;
+        td.seg_row = seg_row;
+        td.src_row = src_row;
+        td.t0 = t0;
+        td.seg_len = len;
+        P.tiles.push_back(td);
+    }
+}
+
+// chunk mode: one stream per read + one head per window i >= 1
+int plan_reads_chunk(const int64_t* read_off, int n_reads, int chunk, int step, int halo, ReadsPlan& P)
+{
+    int64_t row = 0;
+    P.read_win_off.assign(1, 0);
+    for (int r = 0; r < n_reads; r++) {
+        const int64_t N = read_off[r + 1] - read_off[r];
+        RD_REQUIRE(N >= 1, "read %d is empty", r);
+        const WindowGeom g = window_geom(N, chunk, step);
+        const int64_t stream_row = row;
+        P.read_row.push_back(stream_row);
+        add_segment(P, stream_row, read_off[r], (int)N);
+        row += N;
+        for (int i = 0; i < g.nW; i++) {
+            const int valid = (i < g.nW - 1) ? chunk : chunk - g.pad;
+            const int h = (i == 0) ? 0 : (halo < valid ? halo : valid);
+            int64_t o1 = stream_row + (int64_t)i * step;
+            if (h > 0) {
+                o1 = row;
+                add_segment(P, row, read_off[r] + (int64_t)i * step, h);
+                row += h;
+            }
+            P.off1.push_back(o1);
+            P.off2.push_back(stream_row + (int64_t)i * step);
+            P.split.push_back(h);
+            P.valid.push_back(valid);
+        }
+        P.n_windows += g.nW;
+        P.read_win_off.push_back(P.n_windows);
+    }
+    P.total_rows = row;
+    return RD_OK;
+}
+
+struct PlanCache {
+    int chunk = -1, step = -1, halo = -1, mode = -1;
+    std::vector<int64_t> lens;
+    ReadsPlan plan;
+    bool streamed = false;
+    DevBuf d_tiles;
+};
+
+// plan + device tile descriptors for a batch of reads, cached while consecutive batches have the same read lengths
+}  // namespace
+
+extern "C" int rd_count_windows(int64_t n_samples, int chunk_len, int step)
+{
+    if (n_samples < 0 || chunk_len < 1 || step < 1 || step > chunk_len) return -1;
+    return count_windows(n_samples, chunk_len, step);
+}
+
 // --------------------------------------------------------------------------------------------- two-stream pipeline
 // Chunk-mode batches flow through two HIP streams: forwards (MFMA-bound) run back to back on ctx->stream; the beam
 // search (one wave per window, latency-bound) of a GROUP of batches runs on a second, high-priority stream together
@@ -649,8 +765,10 @@ struct PipeSlot {
     hipEvent_t fwd_done = nullptr, dec_done = nullptr;
     bool busy = false;      // decode launched, labels not yet delivered
     int T = 0, W = 0, nwin = 0;
+    int64_t rows = 0;       // probability rows produced into this slot so far
     std::vector<PipeSub> subs;
-    std::vector<int32_t> valid;
+    std::vector<int64_t> off1, off2;   // per window: source rows (see DecodeArgs)
+    std::vector<int32_t> split, valid;
 };
 
 struct Pipe {
@@ -658,7 +776,6 @@ struct Pipe {
     PipeSlot slot[2];
     int cur = 0;
     int group = 4;          // batches per decode launch
-    int cap_windows = 0;    // probs capacity of a slot, in windows
 };
 
 int pinned_reserve(void** p, size_t* cap, size_t bytes)
@@ -690,6 +807,17 @@ int pipe_get(rd_ctx* ctx, Pipe** out)
     return RD_OK;
 }
 
+void pipe_reset(PipeSlot& s)
+{
+    s.subs.clear();
+    s.off1.clear();
+    s.off2.clear();
+    s.split.clear();
+    s.valid.clear();
+    s.nwin = 0;
+    s.rows = 0;
+}
+
 int pipe_collect(PipeSlot& s)
 {
     if (!s.busy) return RD_OK;
@@ -710,9 +838,7 @@ int pipe_collect(PipeSlot& s)
             sb.user_lens[i] = hlen[w];
             if (hlen[w]) memcpy(sb.user_labels + (size_t)i * s.T, hl + (size_t)w * s.T, (size_t)hlen[w]);
         }
-    s.subs.clear();
-    s.valid.clear();
-    s.nwin = 0;
+    pipe_reset(s);
     return rc;
 }
 
@@ -723,22 +849,24 @@ int pipe_launch_decode(rd_ctx* ctx, Pipe* p, PipeSlot& s)
     int rc;
     const size_t n = (size_t)s.nwin, nT = n * s.T;
     RD_HIP(hipEventRecord(s.fwd_done, ctx->stream));
-    // metadata: [seq_off | node_off | label_off] int64, then seq_len int32, then label_len int32 (device only)
-    const size_t o_node = align_up(n * 8, 256), o_lab = 2 * o_node, o_len = 3 * o_node, o_llen = o_len + align_up(n * 4, 256);
-    const size_t meta_bytes = o_llen + align_up(n * 4, 256);
+    // metadata: [off1 | off2 | node_off | label_off] int64, then [seq_len | split] int32, then label_len int32 (device only)
+    const size_t a8 = align_up(n * 8, 256), a4 = align_up(n * 4, 256);
+    const size_t o_off2 = a8, o_node = 2 * a8, o_lab = 3 * a8, o_len = 4 * a8, o_split = o_len + a4, o_llen = o_split + a4;
+    const size_t meta_bytes = o_llen + a4;
     if ((rc = pinned_reserve(&s.h_meta, &s.h_meta_cap, meta_bytes))) return rc;
     if (s.meta.reserve(meta_bytes)) return RD_ERR_NOMEM;
-    int64_t* h_seq = (int64_t*)s.h_meta;
-    int64_t* h_node = (int64_t*)((char*)s.h_meta + o_node);
-    int64_t* h_lab = (int64_t*)((char*)s.h_meta + o_lab);
-    int32_t* h_len = (int32_t*)((char*)s.h_meta + o_len);
+    char* hm = (char*)s.h_meta;
+    int64_t* h_node = (int64_t*)(hm + o_node);
+    int64_t* h_lab = (int64_t*)(hm + o_lab);
+    memcpy(hm, s.off1.data(), n * 8);
+    memcpy(hm + o_off2, s.off2.data(), n * 8);
+    memcpy(hm + o_len, s.valid.data(), n * 4);
+    memcpy(hm + o_split, s.split.data(), n * 4);
     int64_t nodes = 0;
     for (int i = 0; i < s.nwin; i++) {
-        h_seq[i] = (int64_t)i * s.T;
         h_lab[i] = (int64_t)i * s.T;
         h_node[i] = nodes;
         nodes += 1 + (int64_t)s.W * s.valid[i];
-        h_len[i] = s.valid[i];
     }
     if (s.labels.reserve(nT + 16)) return RD_ERR_NOMEM;
     if ((rc = pinned_reserve(&s.h_out, &s.h_out_cap, align_up(nT, 256) + n * 4))) return rc;
@@ -747,12 +875,51 @@ int pipe_launch_decode(rd_ctx* ctx, Pipe* p, PipeSlot& s)
     char* dm = (char*)s.meta.p;
     rc = rd_decode_dev(ctx, s.probs.p, 0, (const int64_t*)dm, (const int32_t*)(dm + o_len), (const int64_t*)(dm + o_node),
                        (const int64_t*)(dm + o_lab), s.nwin, nodes, s.W, 0, 0.0, 0.0, s.labels.as<uint8_t>(),
-                       (int32_t*)(dm + o_llen), nullptr, p->s_dec);
+                       (int32_t*)(dm + o_llen), nullptr, p->s_dec, (const int64_t*)(dm + o_off2), (const int32_t*)(dm + o_split));
     if (rc) return rc;
     RD_HIP(hipMemcpyAsync(s.h_out, s.labels.p, nT, hipMemcpyDeviceToHost, p->s_dec));
     RD_HIP(hipMemcpyAsync((char*)s.h_out + align_up(nT, 256), dm + o_llen, n * 4, hipMemcpyDeviceToHost, p->s_dec));
     RD_HIP(hipEventRecord(s.dec_done, p->s_dec));
     s.busy = true;
+    return RD_OK;
+}
+
+// slot that can take `rows` more probability rows for windows of T rows decoded at width W; closes / recycles groups
+int pipe_open_slot(rd_ctx* ctx, Pipe* p, int T, int W, int64_t rows, PipeSlot** out)
+{
+    int rc;
+    PipeSlot* s = &p->slot[p->cur];
+    // a group is homogeneous in chunk_len and beam width and bounded in size; otherwise close it and move on
+    if (s->nwin > 0 && (s->T != T || s->W != W || (int)s->subs.size() >= p->group)) {
+        if ((rc = pipe_launch_decode(ctx, p, *s))) return rc;
+        p->cur ^= 1;
+        s = &p->slot[p->cur];
+    }
+    if (s->busy && (rc = pipe_collect(*s))) return rc;   // the slot's previous group goes to its callers first
+    const size_t need = (size_t)(s->rows + rows) * 20;
+    if (need > s->probs.cap) {
+        if (s->nwin > 0) {
+            // growing would move probabilities already produced: close the group instead
+            if ((rc = pipe_launch_decode(ctx, p, *s))) return rc;
+            p->cur ^= 1;
+            s = &p->slot[p->cur];
+            if (s->busy && (rc = pipe_collect(*s))) return rc;
+        }
+        if (s->probs.reserve((size_t)rows * 20 * (size_t)p->group)) return RD_ERR_NOMEM;
+    }
+    s->T = T;
+    s->W = W;
+    *out = s;
+    return RD_OK;
+}
+
+int pipe_close_if_full(rd_ctx* ctx, Pipe* p, PipeSlot* s)
+{
+    if ((int)s->subs.size() >= p->group) {
+        int rc = pipe_launch_decode(ctx, p, *s);
+        if (rc) return rc;
+        p->cur ^= 1;
+    }
     return RD_OK;
 }
 
@@ -806,27 +973,10 @@ extern "C" int rd_pipe_submit(rd_ctx* ctx, const float* d_windows, int n_windows
     Pipe* p = nullptr;
     int rc = pipe_get(ctx, &p);
     if (rc) return rc;
-    PipeSlot* s = &p->slot[p->cur];
-    // a group is homogeneous in chunk_len and beam width and bounded in size; otherwise close it and move on
-    if (s->nwin > 0 && (s->T != chunk_len || s->W != beam_width || (int)s->subs.size() >= p->group)) {
-        if ((rc = pipe_launch_decode(ctx, p, *s))) return rc;
-        p->cur ^= 1;
-        s = &p->slot[p->cur];
-    }
-    if (s->busy && (rc = pipe_collect(*s))) return rc;   // the slot's previous group goes to its callers first
-    const size_t need = (size_t)(s->nwin + n_windows) * chunk_len * 20;
-    if (need > s->probs.cap) {
-        if (s->nwin > 0) {
-            // growing would move probabilities already produced: close the group instead
-            if ((rc = pipe_launch_decode(ctx, p, *s))) return rc;
-            p->cur ^= 1;
-            s = &p->slot[p->cur];
-            if (s->busy && (rc = pipe_collect(*s))) return rc;
-        }
-        const size_t want = (size_t)n_windows * chunk_len * 20 * (size_t)p->group;
-        if (s->probs.reserve(want)) return RD_ERR_NOMEM;
-    }
-    rc = rd_forward_dev(ctx, d_windows, n_windows, chunk_len, s->probs.as<float>() + (size_t)s->nwin * chunk_len * 5);
+    PipeSlot* s = nullptr;
+    const int64_t rows = (int64_t)n_windows * chunk_len;
+    if ((rc = pipe_open_slot(ctx, p, chunk_len, beam_width, rows, &s))) return rc;
+    rc = rd_forward_dev(ctx, d_windows, n_windows, chunk_len, s->probs.as<float>() + (size_t)s->rows * 5);
     if (rc) return rc;
     PipeSub sb;
     sb.n = n_windows;
@@ -834,15 +984,15 @@ extern "C" int rd_pipe_submit(rd_ctx* ctx, const float* d_windows, int n_windows
     sb.user_labels = labels_out;
     sb.user_lens = label_len;
     s->subs.push_back(sb);
-    s->valid.insert(s->valid.end(), valid_len, valid_len + n_windows);
-    s->T = chunk_len;
-    s->W = beam_width;
-    s->nwin += n_windows;
-    if ((int)s->subs.size() >= p->group) {
-        if ((rc = pipe_launch_decode(ctx, p, *s))) return rc;
-        p->cur ^= 1;
+    for (int i = 0; i < n_windows; i++) {
+        s->off1.push_back(s->rows + (int64_t)i * chunk_len);
+        s->off2.push_back(s->rows + (int64_t)i * chunk_len);
+        s->split.push_back(0);
+        s->valid.push_back(valid_len[i]);
     }
-    return RD_OK;
+    s->nwin += n_windows;
+    s->rows += rows;
+    return pipe_close_if_full(ctx, p, s);
 }
 
 extern "C" int rd_pipe_flush(rd_ctx* ctx)
@@ -858,6 +1008,256 @@ extern "C" int rd_pipe_flush(rd_ctx* ctx)
     if ((rc = pipe_launch_decode(ctx, p, b))) return rc;
     if ((rc = pipe_collect(a))) return rc;
     return pipe_collect(b);
+}
+
+// --------------------------------------------------------------------------------------------- reads-level entry points
+namespace {
+
+// global mode: one stream per read when the geometry allows it, else per-window segments in a uniform row layout
+int plan_reads_global(const int64_t* read_off, int n_reads, int chunk, int step, int halo, ReadsPlan& P, bool* streamed)
+{
+    const bool st = step <= chunk - halo;
+    *streamed = st;
+    int64_t row = 0;
+    P.read_win_off.assign(1, 0);
+    for (int r = 0; r < n_reads; r++) {
+        const int64_t N = read_off[r + 1] - read_off[r];
+        RD_REQUIRE(N >= 1, "read %d is empty", r);
+        const WindowGeom g = window_geom(N, chunk, step);
+        P.read_row.push_back(row);
+        if (st) {
+            add_segment(P, row, read_off[r], (int)N);
+            row += N;
+        } else {
+            for (int i = 0; i < g.nW; i++) {
+                const int valid = (i < g.nW - 1) ? chunk : chunk - g.pad;
+                if (valid > 0) add_segment(P, row + (int64_t)i * chunk, read_off[r] + (int64_t)i * step, valid);
+            }
+            row += (int64_t)g.nW * chunk;
+        }
+        P.valid.push_back(g.pad);   // per read: the pad of its last window
+        P.n_windows += g.nW;
+        P.read_win_off.push_back(P.n_windows);
+    }
+    P.total_rows = row;
+    return RD_OK;
+}
+
+int get_plan(rd_ctx* ctx, const int64_t* read_off, int n_reads, int chunk, int step, int mode, const ReadsPlan** out,
+             const TileDesc** d_tiles, bool* streamed)
+{
+    PlanCache* pc = (PlanCache*)ctx->plan_cache[mode];
+    if (!pc) {
+        pc = new PlanCache();
+        ctx->plan_cache[mode] = pc;
+    }
+    const int halo = rd_model_halo(ctx);
+    std::vector<int64_t> lens(n_reads);
+    for (int r = 0; r < n_reads; r++) lens[r] = read_off[r + 1] - read_off[r];
+    bool hit = pc->chunk == chunk && pc->step == step && pc->halo == halo && pc->mode == mode && pc->lens == lens &&
+               read_off[0] == 0 && pc->d_tiles.p;
+    if (!hit) {
+        RD_REQUIRE(read_off[0] == 0, "read_off[0] must be 0");
+        pc->plan = ReadsPlan();
+        int rc = mode == 0 ? plan_reads_chunk(read_off, n_reads, chunk, step, halo, pc->plan)
+                           : plan_reads_global(read_off, n_reads, chunk, step, halo, pc->plan, &pc->streamed);
+        if (rc) return rc;
+        const size_t bytes = pc->plan.tiles.size() * sizeof(TileDesc);
+        if (pc->d_tiles.reserve(bytes ? bytes : 16)) return RD_ERR_NOMEM;
+        // make sure no forward still reads the previous descriptors
+        RD_HIP(hipStreamSynchronize(ctx->stream));
+        if (bytes) RD_HIP(hipMemcpy(pc->d_tiles.p, pc->plan.tiles.data(), bytes, hipMemcpyHostToDevice));
+        pc->chunk = chunk;
+        pc->step = step;
+        pc->halo = halo;
+        pc->mode = mode;
+        pc->lens = lens;
+    }
+    *out = &pc->plan;
+    *d_tiles = pc->d_tiles.as<TileDesc>();
+    if (streamed) *streamed = pc->streamed;
+    return RD_OK;
+}
+
+int check_reads_args(rd_ctx* ctx, const void* signal, const int64_t* read_off, int n_reads, int chunk_len, int step, int W)
+{
+    RD_REQUIRE(ctx && signal && read_off, "null argument");
+    RD_REQUIRE(n_reads >= 1 && chunk_len >= 1, "bad shape");
+    RD_REQUIRE(step >= 1 && step <= chunk_len, "step %d must be in [1, chunk_len]", step);
+    RD_REQUIRE(W >= 1 && W <= rd_decode_max_width(), "beam_width %d out of range", W);
+    if (!ctx->model.loaded) {
+        rd_set_error("no weights loaded (rd_load_weights)");
+        return RD_ERR_STATE;
+    }
+    return RD_OK;
+}
+
+}  // namespace
+
+void rd_plan_cache_destroy_internal(rd_ctx* ctx)
+{
+    for (int m = 0; m < 2; m++) {
+        PlanCache* pc = (PlanCache*)ctx->plan_cache[m];
+        if (pc) {
+            pc->d_tiles.release();
+            delete pc;
+        }
+        ctx->plan_cache[m] = nullptr;
+    }
+}
+
+extern "C" int rd_basecall_reads_chunk_resident(rd_ctx* ctx, const float* d_signal, const int64_t* read_off, int n_reads,
+                                                int chunk_len, int step, int beam_width, uint8_t* labels_out,
+                                                int32_t* label_len)
+{
+    int rc = check_reads_args(ctx, d_signal, read_off, n_reads, chunk_len, step, beam_width);
+    if (rc) return rc;
+    RD_REQUIRE(labels_out && label_len, "rd_basecall_reads_chunk: null output");
+    RD_HIP(hipSetDevice(ctx->device));
+    const ReadsPlan* P = nullptr;
+    const TileDesc* d_tiles = nullptr;
+    if ((rc = get_plan(ctx, read_off, n_reads, chunk_len, step, 0, &P, &d_tiles, nullptr))) return rc;
+    if (ctx->ws_probs.reserve((size_t)P->total_rows * 20)) return RD_ERR_NOMEM;
+    rc = rd_forward_tiles_dev(ctx, d_signal, d_tiles, (int)P->tiles.size(), P->total_rows, ctx->ws_probs.as<float>());
+    if (rc) return rc;
+    std::vector<int64_t> lab_off(P->n_windows);
+    for (int w = 0; w < P->n_windows; w++) lab_off[w] = (int64_t)w * chunk_len;
+    return decode_and_fetch(ctx, ctx->ws_probs.p, 0, P->off1.data(), P->valid.data(), P->n_windows, beam_width, 0, 0.0, 0.0,
+                            labels_out, lab_off.data(), label_len, nullptr, P->off2.data(), P->split.data());
+}
+
+extern "C" int rd_basecall_reads_chunk(rd_ctx* ctx, const float* signal, const int64_t* read_off, int n_reads, int chunk_len,
+                                       int step, int beam_width, uint8_t* labels_out, int32_t* label_len)
+{
+    int rc = check_reads_args(ctx, signal, read_off, n_reads, chunk_len, step, beam_width);
+    if (rc) return rc;
+    RD_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)read_off[n_reads];
+    if (ctx->ws_in.reserve(n * 4 + 16)) return RD_ERR_NOMEM;
+    RD_HIP(hipMemcpyAsync(ctx->ws_in.p, signal, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    return rd_basecall_reads_chunk_resident(ctx, ctx->ws_in.as<float>(), read_off, n_reads, chunk_len, step, beam_width, labels_out,
+                                            label_len);
+}
+
+namespace {
+
+// assembly + decode of a batch of reads given the forward's probabilities (streamed or windowed row layout)
+int global_finish(rd_ctx* ctx, const float* d_probs, bool streamed, const ReadsPlan& P, const int64_t* read_off, int n_reads,
+                  int chunk_len, int step, int beam_width, int use_lm, double s_thr, double r_thr, uint8_t* labels_out,
+                  const int64_t* label_off, int32_t* label_len)
+{
+    std::vector<int64_t> off64(n_reads), off32(n_reads);
+    std::vector<int32_t> seq_len(n_reads);
+    std::vector<int> is64(n_reads);
+    int64_t rows64 = 0;
+    for (int r = 0; r < n_reads; r++) {
+        const int nW = P.read_win_off[r + 1] - P.read_win_off[r];
+        const int pad = P.valid[r];
+        const int64_t N = assembled_rows(nW, chunk_len, pad, step);
+        RD_REQUIRE(N == read_off[r + 1] - read_off[r], "internal: assembled length mismatch for read %d", r);
+        seq_len[r] = (int32_t)N;
+        is64[r] = assembled_is_f64(nW, chunk_len, pad, step);
+        off64[r] = rows64;
+        off32[r] = P.read_row[r];   // single coverage: window rows (or stream rows) are consecutive time steps
+        if (is64[r]) rows64 += N;
+    }
+    if (ctx->ws_mat.reserve((size_t)(rows64 + 1) * 40)) return RD_ERR_NOMEM;
+    int rc;
+    for (int r = 0; r < n_reads; r++) {
+        if (!is64[r]) continue;
+        const int nW = P.read_win_off[r + 1] - P.read_win_off[r];
+        rc = rd_assemble_dev(ctx, d_probs + (size_t)P.read_row[r] * 5, nW, chunk_len, P.valid[r], step,
+                             ctx->ws_mat.as<double>() + off64[r] * 5, seq_len[r], streamed ? 1 : 0);
+        if (rc) return rc;
+    }
+    for (int pass = 0; pass < 2; pass++) {
+        std::vector<int64_t> so, lo;
+        std::vector<int32_t> sl;
+        std::vector<int> idx;
+        for (int r = 0; r < n_reads; r++)
+            if (is64[r] == (pass == 0)) {
+                so.push_back(pass == 0 ? off64[r] : off32[r]);
+                sl.push_back(seq_len[r]);
+                lo.push_back(label_off[r]);
+                idx.push_back(r);
+            }
+        if (idx.empty()) continue;
+        std::vector<int32_t> ll(idx.size());
+        rc = decode_and_fetch(ctx, pass == 0 ? (const void*)ctx->ws_mat.p : (const void*)d_probs, pass == 0 ? 1 : 0, so.data(), sl.data(),
+                              (int)idx.size(), beam_width, use_lm, s_thr, r_thr, labels_out, lo.data(), ll.data(), nullptr);
+        if (rc) return rc;
+        for (size_t i = 0; i < idx.size(); i++) label_len[idx[i]] = ll[i];
+    }
+    return RD_OK;
+}
+
+}  // namespace
+
+extern "C" int rd_basecall_reads_global_resident(rd_ctx* ctx, const float* d_signal, const int64_t* read_off, int n_reads,
+                                                 int chunk_len, int step, int beam_width, int use_lm, double s_thr, double r_thr,
+                                                 uint8_t* labels_out, const int64_t* label_off, int32_t* label_len)
+{
+    int rc = check_reads_args(ctx, d_signal, read_off, n_reads, chunk_len, step, beam_width);
+    if (rc) return rc;
+    RD_REQUIRE(labels_out && label_off && label_len, "rd_basecall_reads_global: null output");
+    RD_HIP(hipSetDevice(ctx->device));
+    const ReadsPlan* P = nullptr;
+    const TileDesc* d_tiles = nullptr;
+    bool streamed = false;
+    if ((rc = get_plan(ctx, read_off, n_reads, chunk_len, step, 1, &P, &d_tiles, &streamed))) return rc;
+    if (ctx->ws_probs.reserve((size_t)P->total_rows * 20)) return RD_ERR_NOMEM;
+    rc = rd_forward_tiles_dev(ctx, d_signal, d_tiles, (int)P->tiles.size(), P->total_rows, ctx->ws_probs.as<float>());
+    if (rc) return rc;
+    return global_finish(ctx, ctx->ws_probs.as<float>(), streamed, *P, read_off, n_reads, chunk_len, step, beam_width, use_lm, s_thr,
+                         r_thr, labels_out, label_off, label_len);
+}
+
+extern "C" int rd_basecall_reads_global(rd_ctx* ctx, const float* signal, const int64_t* read_off, int n_reads, int chunk_len,
+                                        int step, int beam_width, int use_lm, double s_thr, double r_thr, uint8_t* labels_out,
+                                        const int64_t* label_off, int32_t* label_len)
+{
+    int rc = check_reads_args(ctx, signal, read_off, n_reads, chunk_len, step, beam_width);
+    if (rc) return rc;
+    RD_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)read_off[n_reads];
+    if (ctx->ws_in.reserve(n * 4 + 16)) return RD_ERR_NOMEM;
+    RD_HIP(hipMemcpyAsync(ctx->ws_in.p, signal, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    return rd_basecall_reads_global_resident(ctx, ctx->ws_in.as<float>(), read_off, n_reads, chunk_len, step, beam_width, use_lm,
+                                             s_thr, r_thr, labels_out, label_off, label_len);
+}
+
+// pipelined chunk-mode batches of whole reads (same overlap scheme as rd_pipe_submit)
+extern "C" int rd_pipe_submit_reads(rd_ctx* ctx, const float* d_signal, const int64_t* read_off, int n_reads, int chunk_len,
+                                    int step, int beam_width, uint8_t* labels_out, int32_t* label_len)
+{
+    int rc = check_reads_args(ctx, d_signal, read_off, n_reads, chunk_len, step, beam_width);
+    if (rc) return rc;
+    RD_REQUIRE(labels_out && label_len, "rd_pipe_submit_reads: null output");
+    RD_HIP(hipSetDevice(ctx->device));
+    const ReadsPlan* P = nullptr;
+    const TileDesc* d_tiles = nullptr;
+    if ((rc = get_plan(ctx, read_off, n_reads, chunk_len, step, 0, &P, &d_tiles, nullptr))) return rc;
+    Pipe* p = nullptr;
+    if ((rc = pipe_get(ctx, &p))) return rc;
+    PipeSlot* s = nullptr;
+    if ((rc = pipe_open_slot(ctx, p, chunk_len, beam_width, P->total_rows, &s))) return rc;
+    rc = rd_forward_tiles_dev(ctx, d_signal, d_tiles, (int)P->tiles.size(), P->total_rows, s->probs.as<float>() + (size_t)s->rows * 5);
+    if (rc) return rc;
+    PipeSub sb;
+    sb.n = P->n_windows;
+    sb.win0 = s->nwin;
+    sb.user_labels = labels_out;
+    sb.user_lens = label_len;
+    s->subs.push_back(sb);
+    for (int w = 0; w < P->n_windows; w++) {
+        s->off1.push_back(P->off1[w] + s->rows);
+        s->off2.push_back(P->off2[w] + s->rows);
+        s->split.push_back(P->split[w]);
+        s->valid.push_back(P->valid[w]);
+    }
+    s->nwin += P->n_windows;
+    s->rows += P->total_rows;
+    return pipe_close_if_full(ctx, p, s);
 }
 
 // --------------------------------------------------------------------------------------------- device memory

@@ -78,6 +78,14 @@ struct LM {
     DevBuf storage, gate_storage;   // storage = table followed by d_entropy (one RCCL broadcast)
 };
 
+// One workgroup's tile of the forward: rows [t0, t0+128) of a segment that starts at global row seg_row.
+struct TileDesc {
+    int64_t seg_row;   // global row (activations / probabilities) of the segment's time step 0
+    int64_t src_row;   // index of the segment's sample 0 in the signal buffer
+    int32_t t0;        // first time step of this tile
+    int32_t seg_len;   // time steps in the segment
+};
+
 struct KernelTimer {
     // HIP-event timing of one kernel family on the launch stream (bench.py roofline leg)
     bool enabled = false;
@@ -93,6 +101,8 @@ struct rd_ctx {
     Model model;
     LM lm;
     // workspaces
+    DevBuf ws_tiles;
+    int tiles_nW = -1, tiles_T = -1;   // shape the cached uniform tile descriptors were built for
     DevBuf ws_in, ws_act0, ws_act1, ws_probs, ws_mat, ws_seq, ws_nodes_child, ws_nodes_back, ws_labels, ws_misc;
     // pinned host staging
     void* h_stage = nullptr;
@@ -100,17 +110,23 @@ struct rd_ctx {
     KernelTimer timer_conv, timer_decode, timer_head, timer_in;
     void* rccl = nullptr;  // RcclState*
     void* pipe = nullptr;  // Pipe* (two-stream forward/decode software pipeline)
+    void* plan_cache[2] = {nullptr, nullptr};  // PlanCache* for chunk / global reads-level plans
 };
 
 // forward.hip
 int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_probs);
+int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileDesc* d_tiles, int n_tiles, int64_t total_rows,
+                         float* d_probs);
+int rd_model_halo(const rd_ctx* ctx);  // receptive field - 1 = (K-1) * 2 * sum(dilations)
 // decode.hip
 int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* d_seq_off, const int32_t* d_seq_len,
                   const int64_t* d_node_off, const int64_t* d_label_off, int n_seq, int64_t total_nodes, int W, int use_lm,
                   double s_thr, double r_thr, uint8_t* d_labels, int32_t* d_label_len, double* d_best_score,
-                  hipStream_t stream = nullptr /* default: ctx->stream */);
+                  hipStream_t stream = nullptr /* default: ctx->stream */, const int64_t* d_seq_off2 = nullptr,
+                  const int32_t* d_seq_split = nullptr);
 // assemble.hip
-int rd_assemble_dev(rd_ctx* ctx, const float* d_probs, int nW, int T, int pad, int step, double* d_out, int64_t N);
+int rd_assemble_dev(rd_ctx* ctx, const float* d_probs, int nW, int T, int pad, int step, double* d_out, int64_t N,
+                    int streamed = 0 /* 1: d_probs is the streamed forward [N][5]; row t is taken from row t */);
 
 extern "C" int rd_decode_max_width(void);
 

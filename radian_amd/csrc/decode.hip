@@ -56,6 +56,8 @@ struct Cfg {
 struct DecodeArgs {
     const void* probs;
     const int64_t* seq_off;
+    const int64_t* seq_off2;   // nullable: rows t >= seq_split[i] come from row seq_off2[i] + t (streamed forward)
+    const int32_t* seq_split;
     const int32_t* seq_len;
     const int64_t* node_off;
     const int64_t* label_off;
@@ -82,7 +84,10 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
     const int lane = threadIdx.x;
     const int seq = blockIdx.x;
     const int T = a.seq_len[seq];
-    const PT* __restrict__ probs = (const PT*)a.probs + a.seq_off[seq] * 5;
+    const PT* __restrict__ probs = (const PT*)a.probs;
+    const int64_t row_a = a.seq_off[seq];
+    const int64_t row_b = a.seq_off2 ? a.seq_off2[seq] : row_a;
+    const int split = a.seq_off2 ? a.seq_split[seq] : 0;
     int4* __restrict__ childtab = a.childtab + a.node_off[seq];
     int* __restrict__ backptr = a.backptr + a.node_off[seq];
     const int W = a.W;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
             if (t < T) {
                 double p[5];
 #pragma unroll
-                for (int c = 0; c < 5; c++) p[c] = (double)probs[(int64_t)t * 5 + c];
+                for (int c = 0; c < 5; c++) p[c] = (double)probs[((t < split ? row_a : row_b) + t) * 5 + c];
 #pragma unroll
                 for (int c = 0; c < 5; c++) lp[lane][c] = safe_log(p[c]);
                 if constexpr (LM) {
@@ -472,7 +477,8 @@ static int ensure_lm_gate(rd_ctx* ctx, double r_thr)
 
 int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* d_seq_off, const int32_t* d_seq_len,
                   const int64_t* d_node_off, const int64_t* d_label_off, int n_seq, int64_t total_nodes, int W, int use_lm,
-                  double s_thr, double r_thr, uint8_t* d_labels, int32_t* d_label_len, double* d_best_score, hipStream_t stream)
+                  double s_thr, double r_thr, uint8_t* d_labels, int32_t* d_label_len, double* d_best_score, hipStream_t stream,
+                  const int64_t* d_seq_off2, const int32_t* d_seq_split)
 {
     hipStream_t st = stream ? stream : ctx->stream;
     RD_REQUIRE(W >= 1 && W <= Cfg<4>::WM, "beam_width %d out of range [1,%d]", W, Cfg<4>::WM);
@@ -490,6 +496,8 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* d
     DecodeArgs a;
     a.probs = d_probs;
     a.seq_off = d_seq_off;
+    a.seq_off2 = d_seq_off2;
+    a.seq_split = d_seq_split;
     a.seq_len = d_seq_len;
     a.node_off = d_node_off;
     a.label_off = d_label_off;

@@ -51,9 +51,8 @@ struct ConvArgs {
     const float* b2;      // EPI_HEAD: [5]
     float* probs;         // EPI_HEAD: [nW][T][5]
     const float* zeros;   // >= 32 zero floats (source of the causal left padding for the LDS-DMA)
-    int T;
+    const TileDesc* tiles; // one per workgroup
     int dil;
-    int tiles_per_win;
 };
 
 // LDS image of a K-chunk tile: [row][32 floats] (128-B rows, no padding -- LDS-DMA writes 1 KiB per
@@ -84,10 +83,13 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1;   // wave row (64 time steps)
     const int wn = wave & 1;    // wave col (NT*32 channels)
-    const int win = blockIdx.x / a.tiles_per_win;
-    const int t0 = (blockIdx.x - win * a.tiles_per_win) * BM;
-    const int T = a.T;
-    const float* __restrict__ inw = a.in + (size_t)win * T * RD_C;
+    // tile descriptor (wave-uniform scalar loads): the segment's first global row, this tile's first local time
+    // step, the segment length.  A segment is a window, a whole read, or the first rows of a window.
+    const TileDesc td = a.tiles[blockIdx.x];
+    const int64_t seg_row = td.seg_row;
+    const int t0 = td.t0;
+    const int T = td.seg_len;
+    const float* __restrict__ inw = a.in + (size_t)seg_row * RD_C;
 
     // DMA roles: a wave-instruction moves 8 rows x 128 B; lane -> (row-in-piece, physical 16-B slot)
     const int dma_r = lane >> 3;
@@ -166,8 +168,8 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
     if constexpr (EPI != EPI_HEAD) {
         // out may alias resid (in-place residual): each element is read, then written, by the same thread only, so the
         // restrict-qualified views just let the compiler batch a row's loads ahead of the previous row's stores.
-        float* __restrict__ outw = a.out + (size_t)win * T * RD_C;
-        const float* __restrict__ resw = (EPI == EPI_RES_IDENT) ? a.resid + (size_t)win * T * RD_C : nullptr;
+        float* __restrict__ outw = a.out + (size_t)seg_row * RD_C;
+        const float* __restrict__ resw = (EPI == EPI_RES_IDENT) ? a.resid + (size_t)seg_row * RD_C : nullptr;
         float bias[NT], wmt[NT], bmt[NT];
 #pragma unroll
         for (int n = 0; n < NT; n++) {
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
                     const int t = t0 + row;
                     if (GUARD && t >= T) continue;
                     float xv = 0.f;
-                    if constexpr (EPI == EPI_RES_MATCH) xv = a.x[(size_t)win * T + t];
+                    if constexpr (EPI == EPI_RES_MATCH) xv = a.x[(size_t)td.src_row + t];
                     float* orow = outw + (size_t)t * RD_C + wn * NT * 32 + fr;
                     float rv[NT];
                     if constexpr (EPI == EPI_RES_IDENT) {
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
                     e[o] = expf(lg[o] - mx);
                     s += e[o];
                 }
-                float* pr = a.probs + ((size_t)win * T + t) * 5;
+                float* pr = a.probs + ((size_t)seg_row + t) * 5;
 #pragma unroll
                 for (int o = 0; o < 5; o++) pr[o] = e[o] / s;
             }
@@ -266,16 +268,19 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
 }
 
 // Block 0, first conv: C_in = 1 (VALU; memory-bound 1 KiB write per time step), fused bias + ReLU.
+// One workgroup per tile descriptor: 4 rows per pass (64 lanes x float4 = one 1 KiB row per wave).
 __global__ __launch_bounds__(256) void tcn_in_kernel(const float* __restrict__ x, const float* __restrict__ w /*[3][256]*/,
-                                                      const float* __restrict__ b, float* __restrict__ out, int T, int dil,
-                                                      size_t total_rows)
+                                                      const float* __restrict__ b, float* __restrict__ out,
+                                                      const TileDesc* __restrict__ tiles, int dil)
 {
+    const TileDesc td = tiles[blockIdx.x];
     const int c4 = (threadIdx.x & 63) * 4;
     const float4 w0 = *(const float4*)(w + c4), w1 = *(const float4*)(w + 256 + c4), w2 = *(const float4*)(w + 512 + c4);
     const float4 bb = *(const float4*)(b + c4);
-    for (size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < total_rows; row += (size_t)gridDim.x * 4) {
-        const int t = (int)(row % (size_t)T);
-        const float* xw = x + (row - t);
+    const float* xw = x + td.src_row;
+    float* ow = out + (size_t)td.seg_row * RD_C;
+    const int tend = td.t0 + BM < td.seg_len ? td.t0 + BM : td.seg_len;
+    for (int t = td.t0 + (threadIdx.x >> 6); t < tend; t += 4) {
         const float x2 = xw[t];
         const float x1 = t - dil >= 0 ? xw[t - dil] : 0.f;
         const float x0 = t - 2 * dil >= 0 ? xw[t - 2 * dil] : 0.f;
@@ -288,10 +293,9 @@ __global__ __launch_bounds__(256) void tcn_in_kernel(const float* __restrict__ x
         v.y = v.y > 0.f ? v.y : 0.f;
         v.z = v.z > 0.f ? v.z : 0.f;
         v.w = v.w > 0.f ? v.w : 0.f;
-        *(float4*)(out + row * RD_C + c4) = v;
+        *(float4*)(ow + (size_t)t * RD_C + c4) = v;
     }
 }
-
 
 int timer_begin(rd_ctx* ctx, KernelTimer& tm)
 {
@@ -311,49 +315,46 @@ int timer_end(rd_ctx* ctx, KernelTimer& tm, double flops, double bytes)
 
 }  // namespace
 
-// d_windows [nW][T] fp32 (already MAD-normalised) -> d_probs [nW][T][5] fp32; all on ctx->stream.
-int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_probs)
+// Forward over a set of independent SEGMENTS packed in one row space: d_signal [total_rows] fp32 (already
+// MAD-normalised), d_tiles [n_tiles] (every segment cut into tiles of <= 128 rows) -> d_probs [total_rows][5].
+// A segment is causally zero-padded at its own start; nothing leaks between segments.
+int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileDesc* d_tiles, int n_tiles, int64_t total_rows,
+                         float* d_probs)
 {
     Model& m = ctx->model;
     if (!m.loaded) {
         rd_set_error("rd_forward: no weights loaded (rd_load_weights)");
         return RD_ERR_STATE;
     }
-    RD_REQUIRE(nW >= 0 && T >= 1, "rd_forward: bad shape nW=%d T=%d", nW, T);
-    if (nW == 0) return RD_OK;
+    if (n_tiles == 0 || total_rows == 0) return RD_OK;
     int rc = RD_OK;
-    const size_t act_bytes = (size_t)nW * T * RD_C * sizeof(float);
+    const size_t act_bytes = (size_t)total_rows * RD_C * sizeof(float);
     if (ctx->ws_act0.reserve(act_bytes) || ctx->ws_act1.reserve(act_bytes)) return RD_ERR_NOMEM;
     float* X = ctx->ws_act0.as<float>();    // block input / output (residual added in place)
     float* MID = ctx->ws_act1.as<float>();  // activation between the two convs of a block
-    const size_t rows = (size_t)nW * T;
-    const int tiles = (T + BM - 1) / BM;
-    const int grid = nW * tiles;
-    const double conv_flops = 2.0 * (double)rows * RD_C * RD_C * RD_K;
-    const double conv_bytes = 2.0 * (double)rows * RD_C * 4.0;
+    const double rows = (double)total_rows;
+    const int grid = n_tiles;
+    const double conv_flops = 2.0 * rows * RD_C * RD_C * RD_K;
+    const double conv_bytes = 2.0 * rows * RD_C * 4.0;
 
     for (int b = 0; b < m.nblocks; b++) {
         const int d = m.dil[b];
         ConvArgs a = {};
         a.zeros = m.zeros;
-        a.T = T;
+        a.tiles = d_tiles;
         a.dil = d;
-        a.tiles_per_win = tiles;
         if (b == 0) {
             // conv0: 1 -> 256 on the VALU
-            size_t g = (rows + 3) / 4;
-            if (g > 256 * 64) g = 256 * 64;
             if ((rc = timer_begin(ctx, ctx->timer_in))) return rc;
-            hipLaunchKernelGGL(tcn_in_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, d_windows, m.w_in, m.b_in, MID, T, d,
-                               rows);
+            hipLaunchKernelGGL(tcn_in_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_signal, m.w_in, m.b_in, MID, d_tiles, d);
             RD_HIP(hipGetLastError());
-            if ((rc = timer_end(ctx, ctx->timer_in, 2.0 * rows * RD_C * RD_K, (double)rows * (RD_C * 4.0 + 4.0)))) return rc;
+            if ((rc = timer_end(ctx, ctx->timer_in, 2.0 * rows * RD_C * RD_K, rows * (RD_C * 4.0 + 4.0)))) return rc;
             // conv1 + relu, + 1x1 match residual + relu
             a.in = MID;
             a.out = X;
             a.wpk = m.w_conv[1];
             a.bias = m.b_conv[1];
-            a.x = d_windows;
+            a.x = d_signal;
             a.wmatch = m.w_match;
             a.bmatch = m.b_match;
             if ((rc = timer_begin(ctx, ctx->timer_conv))) return rc;
@@ -377,14 +378,13 @@ int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_
             if ((rc = timer_begin(ctx, ctx->timer_conv))) return rc;
             hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_IDENT>), dim3(grid), dim3(256), 0, ctx->stream, a);
             RD_HIP(hipGetLastError());
-            if ((rc = timer_end(ctx, ctx->timer_conv, conv_flops, conv_bytes + (double)rows * RD_C * 4.0))) return rc;
+            if ((rc = timer_end(ctx, ctx->timer_conv, conv_flops, conv_bytes + rows * RD_C * 4.0))) return rc;
         }
     }
     ConvArgs h = {};
     h.zeros = m.zeros;
-    h.T = T;
+    h.tiles = d_tiles;
     h.dil = 0;
-    h.tiles_per_win = tiles;
     h.in = X;
     h.wpk = m.w_d1;
     h.bias = m.b_d1;
@@ -394,7 +394,44 @@ int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_
     if ((rc = timer_begin(ctx, ctx->timer_head))) return rc;
     hipLaunchKernelGGL((tcn_gemm_kernel<2, 1, EPI_HEAD>), dim3(grid), dim3(256), 0, ctx->stream, h);
     RD_HIP(hipGetLastError());
-    if ((rc = timer_end(ctx, ctx->timer_head, 2.0 * rows * (RD_C * RD_H + RD_H * 5), (double)rows * (RD_C * 4.0 + 20.0))))
-        return rc;
+    if ((rc = timer_end(ctx, ctx->timer_head, 2.0 * rows * (RD_C * RD_H + RD_H * 5), rows * (RD_C * 4.0 + 20.0)))) return rc;
     return RD_OK;
+}
+
+// Tile descriptors of nW uniform windows of T rows; cached on the device per (nW, T).
+int rd_uniform_tiles(rd_ctx* ctx, int nW, int T, const TileDesc** d_tiles, int* n_tiles)
+{
+    const int tiles = (T + BM - 1) / BM;
+    const size_t n = (size_t)nW * tiles;
+    if (ctx->tiles_nW != nW || ctx->tiles_T != T) {
+        std::vector<TileDesc> h(n);
+        for (int w = 0; w < nW; w++)
+            for (int k = 0; k < tiles; k++) {
+                TileDesc& td = h[(size_t)w * tiles + k];
+                td.seg_row = (int64_t)w * T;
+                td.src_row = (int64_t)w * T;
+                td.t0 = k * BM;
+                td.seg_len = T;
+            }
+        if (ctx->ws_tiles.reserve(n * sizeof(TileDesc))) return RD_ERR_NOMEM;
+        RD_HIP(hipMemcpyAsync(ctx->ws_tiles.p, h.data(), n * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream));
+        RD_HIP(hipStreamSynchronize(ctx->stream));  // h is a stack-owned vector
+        ctx->tiles_nW = nW;
+        ctx->tiles_T = T;
+    }
+    *d_tiles = ctx->ws_tiles.as<TileDesc>();
+    *n_tiles = (int)n;
+    return RD_OK;
+}
+
+// d_windows [nW][T] fp32 (already MAD-normalised) -> d_probs [nW][T][5] fp32; all on ctx->stream.
+int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_probs)
+{
+    RD_REQUIRE(nW >= 0 && T >= 1, "rd_forward: bad shape nW=%d T=%d", nW, T);
+    if (nW == 0) return RD_OK;
+    const TileDesc* d_tiles = nullptr;
+    int n_tiles = 0;
+    int rc = rd_uniform_tiles(ctx, nW, T, &d_tiles, &n_tiles);
+    if (rc) return rc;
+    return rd_forward_tiles_dev(ctx, d_windows, d_tiles, n_tiles, (int64_t)nW * T, d_probs);
 }

@@ -1,0 +1,124 @@
+"""Reads-level fused paths (streamed forward: every time step computed once) must be BIT-IDENTICAL to the windowed
+computation the reference performs (radian/basecall.py:83-121)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    from radian_amd import Backend, weights
+    b = Backend(0)
+    b.load_weights(weights.synthetic_weights(seed=1234))
+    yield b
+    b.close()
+
+
+def _reads(rng, lengths):
+    return [np.clip(rng.normal(size=n), -4, 4).astype(np.float32) for n in lengths]
+
+
+def _windows(sig, chunk, step):
+    from radian_amd.preprocess import get_windows
+    w, pad = get_windows(sig, chunk, step)
+    valid = np.full(w.shape[0], chunk, dtype=np.int32)
+    valid[-1] = chunk - pad
+    return w.astype(np.float32), valid, pad
+
+
+def test_stream_rows_equal_window_rows_bitwise(be):
+    """rows >= 252 of a window == rows of one forward pass over the whole read (receptive field 253)."""
+    rng = np.random.default_rng(0)
+    sig = _reads(rng, [3000])[0]
+    stream = be.forward(sig[None, :])[0]          # one segment of 3000 rows
+    w, valid, pad = _windows(sig, 1024, 512)
+    probs = be.forward(w)
+    halo = 252
+    for i in range(w.shape[0]):
+        n = valid[i]
+        assert np.array_equal(probs[i, halo:n], stream[i * 512 + halo: i * 512 + n]), i
+    assert np.array_equal(probs[0, :1024], stream[:1024])
+    # and rows < 252 of a later window do differ (they see the window's zero left-padding)
+    assert not np.array_equal(probs[1, :halo], stream[512: 512 + halo])
+
+
+@pytest.mark.parametrize("chunk,step", [(1024, 512), (1024, 128), (1024, 1024), (1024, 900), (300, 100), (256, 256)])
+def test_reads_chunk_equals_windowed(be, chunk, step):
+    rng = np.random.default_rng(chunk * 7 + step)
+    lengths = [4096, 700, chunk, chunk + step, chunk + 3 * step + 17, 1, 2500, chunk - 1, chunk + 1]
+    sigs = _reads(rng, lengths)
+    W = 10
+    got = be.basecall_reads_chunk(sigs, chunk, step, W)
+    assert len(got) == len(sigs)
+    for r, sig in enumerate(sigs):
+        w, valid, _ = _windows(sig, chunk, step)
+        exp = be.basecall_chunk(w, valid, W)
+        assert len(got[r]) == len(exp) == be.count_windows(len(sig), chunk, step)
+        for i in range(len(exp)):
+            assert np.array_equal(got[r][i], exp[i]), (r, i, lengths[r])
+
+
+@pytest.mark.parametrize("chunk,step", [(1024, 512), (1024, 128), (1024, 772), (1024, 773), (1024, 1024), (300, 40)])
+def test_reads_global_equals_windowed(be, chunk, step):
+    rng = np.random.default_rng(chunk + step)
+    k = 3
+    be.load_lm(rng.dirichlet([0.3] * 4, size=4 ** k), k)
+    lengths = [4096, 700, chunk, chunk + step, 3000, 5, chunk + 1]
+    sigs = _reads(rng, lengths)
+    got = be.basecall_reads_global(sigs, chunk, step, 6, True, 0.5, 0.5)
+    wins, offs, pads = [], [0], []
+    for sig in sigs:
+        w, _, pad = _windows(sig, chunk, step)
+        wins.append(w)
+        offs.append(offs[-1] + w.shape[0])
+        pads.append(pad)
+    exp = be.basecall_global(np.concatenate(wins), np.array(offs, dtype=np.int32), np.array(pads, dtype=np.int32), step, 6, True, 0.5, 0.5)
+    for r in range(len(sigs)):
+        assert np.array_equal(got[r], exp[r]), (r, lengths[r])
+    be.load_lm(None, 0)
+
+
+def test_reads_global_vs_oracle_end_to_end(be, oracle):
+    """reads-level global path == oracle assembly + decode of the windowed GPU probabilities (default geometry)."""
+    rng = np.random.default_rng(5)
+    k = 3
+    table = rng.dirichlet([0.3] * 4, size=4 ** k)
+    be.load_lm(table, k)
+    sig = _reads(rng, [5000])[0]
+    got = be.basecall_reads_global([sig], 1024, 128, 6, True, 0.5, 0.5)[0]
+    w, valid, pad = _windows(sig, 1024, 128)
+    probs = be.forward(w)
+    mat = oracle.assemble_matrices(probs, pad, 128)
+    exp, _ = oracle.beam_search_labels(mat, 6, table, 0.5, 0.5, k)
+    assert np.array_equal(got, exp)
+    be.load_lm(None, 0)
+
+
+def test_pipe_submit_reads_equals_unpipelined(be):
+    rng = np.random.default_rng(9)
+    n_reads, N, chunk, step, W = 6, 4096, 1024, 512, 10
+    batches = [np.stack(_reads(rng, [N] * n_reads)) for _ in range(5)]
+    read_off = np.arange(n_reads + 1, dtype=np.int64) * N
+    nwin = n_reads * be.count_windows(N, chunk, step)
+    ref = [be.basecall_reads_chunk(list(b), chunk, step, W) for b in batches]
+    dptr = []
+    for b in batches:
+        d = be.dev_alloc(b.nbytes)
+        be.h2d(d, b)
+        dptr.append(d)
+    be.pipe_config(2)
+    outs = [(np.zeros((nwin, chunk), dtype=np.uint8), np.full(nwin, -1, dtype=np.int32)) for _ in batches]
+    for b in range(len(batches)):
+        be.pipe_submit_reads(dptr[b], read_off, n_reads, chunk, step, W, outs[b][0], outs[b][1])
+    be.pipe_flush()
+    for b in range(len(batches)):
+        lab, ln = outs[b]
+        w = 0
+        for r in range(n_reads):
+            for frag in ref[b][r]:
+                assert ln[w] == len(frag) and np.array_equal(lab[w, : ln[w]], frag), (b, r, w)
+                w += 1
+    for d in dptr:
+        be.dev_free(d)
+    be.pipe_config(4)
