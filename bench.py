@@ -72,6 +72,7 @@ def main():
         args.gpus = world
 
     from radian_amd import Backend, weights, synthetic
+    synthetic.mad_normalise = __import__('radian_amd.preprocess', fromlist=['mad_normalise']).mad_normalise
     from radian_amd.backend import RD_TIMER_CONV, RD_TIMER_DECODE, RD_TIMER_HEAD
 
     be = Backend(local_rank)
@@ -97,7 +98,10 @@ def main():
         assert win.shape == (BATCH_WINDOWS, CHUNK)
         d = be.dev_alloc(win.nbytes)
         be.h2d(d, win)
-        batches.append((d, valid, win))
+        norm = np.stack([synthetic.mad_normalise(r, 4) for r in reads]).astype(np.float32)   # [64][4096] normalised reads
+        dn = be.dev_alloc(norm.nbytes)
+        be.h2d(dn, norm)
+        batches.append((d, valid, win, dn))
     labels = np.zeros((BATCH_WINDOWS, CHUNK), dtype=np.uint8)
     lens = np.zeros(BATCH_WINDOWS, dtype=np.int32)
     # output buffers of the two-stream pipeline (a batch's labels land two submits later / at flush)
@@ -105,37 +109,55 @@ def main():
     out = [(np.zeros((BATCH_WINDOWS, CHUNK), dtype=np.uint8), np.full(BATCH_WINDOWS, -1, dtype=np.int32))
            for _ in range(2 * args.decode_group)]
 
+    read_off = np.arange(reads_per_batch + 1, dtype=np.int64) * READ_LEN
+
     def step(i):
         """unpipelined: forward -> decode -> labels on the host, one stream (used for the per-kernel timing pass)"""
-        d, valid, _ = batches[i % n_batches]
-        be.basecall_chunk_resident(d, BATCH_WINDOWS, CHUNK, valid, BEAM, labels, lens)
+        be.basecall_reads_chunk_resident(batches[i % n_batches][3], read_off, reads_per_batch, CHUNK, STEP, BEAM, labels, lens)
 
     def submit(i):
-        """pipelined: forward(i) on the compute stream overlaps beam search + copy-out of batch i-1"""
-        d, valid, _ = batches[i % n_batches]
+        """pipelined, reads-level: the batch's 64 normalised reads are windowed on the device and every time step is
+        computed once (bit-identical to evaluating all 512 windows; tests/test_gpu_reads.py)"""
+        lab, ln = out[i % len(out)]
+        be.pipe_submit_reads(batches[i % n_batches][3], read_off, reads_per_batch, CHUNK, STEP, BEAM, lab, ln)
+
+    def submit_windowed(i):
+        """pipelined, window-level: all 512 windows through the model, as the reference does"""
+        d, valid = batches[i % n_batches][0], batches[i % n_batches][1]
         lab, ln = out[i % len(out)]
         be.pipe_submit(d, BATCH_WINDOWS, CHUNK, valid, BEAM, lab, ln)
 
-    for i in range(args.warmup):
-        submit(i)
-    be.pipe_flush()
-    be.sync()
-    if world > 1:
-        be.rccl_barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        submit(i)
-    be.pipe_flush()   # every batch's labels are on the host when the clock stops
-    be.sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        be.rccl_barrier()
-        elapsed = float(be.rccl_allreduce_max([elapsed])[0])
+    def timed(fn):
+        for i in range(args.warmup):
+            fn(i)
+        be.pipe_flush()
+        be.sync()
+        if world > 1:
+            be.rccl_barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            fn(i)
+        be.pipe_flush()   # every batch's labels are on the host when the clock stops
+        be.sync()
+        el = time.perf_counter() - t0
+        if world > 1:
+            be.rccl_barrier()
+            el = float(be.rccl_allreduce_max([el])[0])
+        return el
+
+    elapsed_windowed = timed(submit_windowed)
+    ref_lab, ref_len = out[0][0].copy(), out[0][1].copy()
+    elapsed = timed(submit)
+    # same batches in the same output slots: the reads-level path must reproduce the window-level labels exactly
+    assert np.array_equal(ref_len, out[0][1]) and np.array_equal(ref_lab, out[0][0]), "streamed != windowed labels"
     for lab, ln in out[: max(1, min(len(out), args.steps))]:
         assert ln.min() >= 0 and ln.max() <= CHUNK and ln.sum() > 0
 
     samples_per_step = reads_per_batch * READ_LEN  # input samples basecalled per step per GPU
     value = world * args.steps * samples_per_step / elapsed
+    value_windowed = world * args.steps * samples_per_step / elapsed_windowed
+    halo = 252
+    rows_streamed = reads_per_batch * (READ_LEN + 7 * halo)   # time steps the model evaluates per step
 
     # ---- roofline of the dominant kernel (dilated conv on fp32 MFMA), HIP events on the launch stream
     roof = None
@@ -154,7 +176,7 @@ def main():
         be.timer_enable(RD_TIMER_CONV, 0)
         be.timer_enable(RD_TIMER_DECODE, 0)
         be.timer_enable(RD_TIMER_HEAD, 0)
-        rows = BATCH_WINDOWS * CHUNK
+        rows = rows_streamed
         flop_per_launch = rows * FLOP_PER_CONV_ROW
         avg_s = tc["total_ms"] / max(1, tc["launches"]) * 1e-3
         achieved = flop_per_launch / avg_s / 1e12
@@ -188,13 +210,18 @@ def main():
             "config": {
                 "workload": "BASELINE configs[2]: synthetic Gaussian int16 reads x 4096 samples (round(N(500,80))), "
                             "MAD-normalised, chunk=1024 step=512 -> 8 windows/read; step = 512 windows (64 reads): "
-                            "TCN forward fp32 + chunk-mode CTC beam search W=10 (LM unused in chunk mode, "
-                            "reference basecall.py:110-121) + labels to host; random He-normal weights seed 1234",
+                            "TCN forward fp32 + chunk-mode CTC beam search W=10 over every window (LM unused in chunk "
+                            "mode, reference basecall.py:110-121) + labels to host; random He-normal weights seed 1234",
+                "forward": "streamed: each read's time steps are evaluated once (4096 + 7*252 rows per read instead of "
+                           "8*1024; probabilities and labels bit-identical to the windowed evaluation, tests/test_gpu_reads.py); "
+                           "value_windowed is the same job with all 512 windows through the model",
+                "model_rows_per_step": rows_streamed,
                 "chunk_len": CHUNK, "step_size": STEP, "batch_windows": BATCH_WINDOWS, "beam_width": BEAM,
                 "decode_type": "chunk", "samples_per_step_per_gpu": samples_per_step, "sharding": "reads per rank, no data-path collective",
                 "pipelining": f"2 HIP streams: forwards back to back; beam search + label copy-out of a group of {args.decode_group} batches overlaps the next group's forwards; all labels on host at stop",
             },
             "roofline": roof,
+            "value_windowed": value_windowed, "ms_per_step_windowed": elapsed_windowed / args.steps * 1e3,
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
@@ -202,8 +229,9 @@ def main():
         print(json.dumps(out))
         if uid_path and os.path.exists(uid_path):
             os.remove(uid_path)
-    for d, _, _ in batches:
-        be.dev_free(d)
+    for b in batches:
+        be.dev_free(b[0])
+        be.dev_free(b[3])
     be.close()
 
 

@@ -7,7 +7,8 @@
 
 Flags, defaults, read order, FASTA naming/rotation and the stdout lines follow radian/basecall.py:19-141.
 What differs (results do not): reads are batched ACROSS reads for the GPU (the forward is batch independent,
-SURVEY F10), so `--batch-size` only bounds nothing any more (`--gpu-batch-windows` sizes device batches);
+SURVEY F10), so `--batch-size` no longer sizes anything (`--gpu-batch-windows` bounds a device batch); windows are formed on the
+device and every time step is evaluated once (bit-identical to evaluating all windows, DESIGN.md section 4.6);
 `--rna-model None` disables the LM in global mode instead of crashing at decode.py:83; `--sig-model` also
 accepts `synthetic[:seed]` (seeded He-normal weights: the reference's sig2seq.h5 is not distributed with
 the source tree) and packed `.rdnw` blobs; extra flags `--device`, `--gpus`.
@@ -20,7 +21,7 @@ from time import time
 import numpy as np
 
 from . import fast5, lm as lm_mod, weights as weights_mod
-from .preprocess import mad_normalise, get_windows
+from .preprocess import mad_normalise
 from .sequence_assembly import consensus_sequence, labels_to_str
 
 
@@ -103,7 +104,9 @@ class FastaWriter:
 
 
 def preprocess_read(read, args):
-    """basecall.py:76-83.  Returns (windows float32 [nW, chunk], pad) or None when the read is skipped."""
+    """basecall.py:76-83 up to the windowing, which happens on the device: returns the normalised signal as float32
+    (what `sig_model.predict` would cast each window to) and the number of windows get_windows would make, or None
+    when the read is skipped."""
     raw_signal = read.get_raw_data()
     try:
         norm_signal = mad_normalise(raw_signal, args.outlier_clip)
@@ -111,29 +114,25 @@ def preprocess_read(read, args):
         print(e.args)
         print(f"{read.read_id} signal issue, skipping this read.")
         return None
-    windows, pad = get_windows(norm_signal, args.chunk_len, args.step_size)
-    return windows.astype(np.float32), pad
+    if args.step_size <= 0:
+        raise ValueError("Step size must be > 0")            # preprocess.py:5-8
+    if args.step_size > args.chunk_len:
+        raise ValueError("Step size must be <= window size")
+    n = norm_signal.shape[0]
+    n_win = (0 if n < args.chunk_len else (n - args.chunk_len) // args.step_size + 1) + 1
+    return norm_signal.astype(np.float32), n_win
 
 
 def basecall_batch(be, batch, args, use_lm):
-    """batch: list of (read_id, windows, pad).  Returns the sequences (un-reversed) in batch order."""
-    windows = np.concatenate([w for _, w, _ in batch], axis=0)
+    """batch: list of (read_id, normalised signal float32, n_windows).  Returns the sequences (un-reversed) in batch
+    order.  Whole reads go to the device; windows are formed there and every time step is evaluated once."""
+    signals = [sig for _, sig, _ in batch]
     if args.decode_type == "global":
-        off = np.zeros(len(batch) + 1, dtype=np.int32)
-        off[1:] = np.cumsum([w.shape[0] for _, w, _ in batch])
-        pads = np.array([p for _, _, p in batch], dtype=np.int32)
-        labels = be.basecall_global(windows, off, pads, args.step_size, args.beam_width, use_lm,
-                                    args.sig_threshold, args.rna_threshold)
+        labels = be.basecall_reads_global(signals, args.chunk_len, args.step_size, args.beam_width, use_lm,
+                                          args.sig_threshold, args.rna_threshold)
         return [labels_to_str(l) for l in labels]
-    valid = np.concatenate([np.r_[np.full(w.shape[0] - 1, args.chunk_len, dtype=np.int32), np.int32(args.chunk_len - p)]
-                            for _, w, p in batch]).astype(np.int32)
-    frags = be.basecall_chunk(windows, valid, args.beam_width)
-    out, i = [], 0
-    for _, w, _ in batch:
-        read_fragments = [labels_to_str(f) for f in frags[i:i + w.shape[0]]]
-        i += w.shape[0]
-        out.append(consensus_sequence(read_fragments))  # basecall.py:122-123
-    return out
+    frags = be.basecall_reads_chunk(signals, args.chunk_len, args.step_size, args.beam_width)
+    return [consensus_sequence([labels_to_str(f) for f in fr]) for fr in frags]  # basecall.py:122-123
 
 
 def run(args, be, reads=None, writer=None, shard=(0, 1)):
@@ -167,12 +166,12 @@ def run(args, be, reads=None, writer=None, shard=(0, 1)):
         pre = preprocess_read(read, args)
         if pre is None:
             continue
-        w, pad = pre
-        if batch and n_win + w.shape[0] > args.gpu_batch_windows:
+        sig, nw = pre
+        if batch and n_win + nw > args.gpu_batch_windows:
             flush()
-        batch.append((read.read_id, w, pad))
+        batch.append((read.read_id, sig, nw))
         batch_idx.append(idx)
-        n_win += w.shape[0]
+        n_win += nw
     flush()
     return results
 

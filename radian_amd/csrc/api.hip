@@ -149,7 +149,7 @@ constexpr size_t CONV_PK = (size_t)RD_K * RD_C * RD_C;  // 196608 floats
 constexpr size_t D1_PK = (size_t)RD_C * RD_H;
 
 struct ModelLayout {
-    size_t zeros, w_in, b_in, w_match, b_match, w_conv[2 * RD_MAX_BLOCKS], b_conv[2 * RD_MAX_BLOCKS], w_d1, b_d1, w_d2, b_d2, total;
+    size_t zeros, sink, w_in, b_in, w_match, b_match, w_conv[2 * RD_MAX_BLOCKS], b_conv[2 * RD_MAX_BLOCKS], w_d1, b_d1, w_d2, b_d2, total;
 };
 
 ModelLayout model_layout(int nblocks)
@@ -162,6 +162,7 @@ ModelLayout model_layout(int nblocks)
         return o;
     };
     L.zeros = take(64);
+    L.sink = take(256);
     L.w_in = take(RD_K * RD_C);
     L.b_in = take(RD_C);
     L.w_match = take(RD_C);
@@ -184,6 +185,7 @@ void model_bind(Model& m, const ModelLayout& L)
 {
     float* base = m.storage.as<float>();
     m.zeros = base + L.zeros;
+    m.sink = base + L.sink;
     m.w_in = base + L.w_in;
     m.b_in = base + L.b_in;
     m.w_match = base + L.w_match;

@@ -51,6 +51,7 @@ struct ConvArgs {
     const float* b2;      // EPI_HEAD: [5]
     float* probs;         // EPI_HEAD: [nW][T][5]
     const float* zeros;   // >= 32 zero floats (source of the causal left padding for the LDS-DMA)
+    float* sink;          // 256 floats nobody reads: target of the stores past a segment's end
     const TileDesc* tiles; // one per workgroup
     int dil;
 };
@@ -181,22 +182,25 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
                 bmt[n] = a.bmatch[co];
             }
         }
-        // one code path without per-element bounds checks for interior tiles (no branch / wait per store)
+        // Tiles that end inside the segment store every row; a tile that straddles the segment end redirects the rows
+        // past it to a per-lane sink word instead of branching (no divergence, no wait between stores).
         auto emit = [&](auto guard_tag) {
             constexpr bool GUARD = decltype(guard_tag)::value;
+            float* sink = a.sink + threadIdx.x;
 #pragma unroll
             for (int m = 0; m < 2; m++) {
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const int row = wm * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
                     const int t = t0 + row;
-                    if (GUARD && t >= T) continue;
+                    const bool inb = !GUARD || t < T;
+                    const int tc = inb ? t : T - 1;
                     float xv = 0.f;
-                    if constexpr (EPI == EPI_RES_MATCH) xv = a.x[(size_t)td.src_row + t];
-                    float* orow = outw + (size_t)t * RD_C + wn * NT * 32 + fr;
+                    if constexpr (EPI == EPI_RES_MATCH) xv = a.x[(size_t)td.src_row + tc];
+                    float* orow = outw + (size_t)tc * RD_C + wn * NT * 32 + fr;
                     float rv[NT];
                     if constexpr (EPI == EPI_RES_IDENT) {
-                        const float* rrow = resw + (size_t)t * RD_C + wn * NT * 32 + fr;
+                        const float* rrow = resw + (size_t)tc * RD_C + wn * NT * 32 + fr;
 #pragma unroll
                         for (int n = 0; n < NT; n++) rv[n] = rrow[n * 32];
                     }
@@ -211,7 +215,8 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
                             v = (bmt[n] + xv * wmt[n]) + v;
                             v = v > 0.f ? v : 0.f;
                         }
-                        orow[n * 32] = v;
+                        float* dst = inb ? orow + n * 32 : sink;
+                        *dst = v;
                     }
                 }
             }
@@ -341,6 +346,7 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileDesc* d_t
         const int d = m.dil[b];
         ConvArgs a = {};
         a.zeros = m.zeros;
+        a.sink = m.sink;
         a.tiles = d_tiles;
         a.dil = d;
         if (b == 0) {
@@ -383,6 +389,7 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileDesc* d_t
     }
     ConvArgs h = {};
     h.zeros = m.zeros;
+    h.sink = m.sink;
     h.tiles = d_tiles;
     h.dil = 0;
     h.in = X;

@@ -36,5 +36,26 @@ class OracleBackend:
             out.append(lab)
         return out
 
+    def _windows(self, sig, chunk, step):
+        w, pad = orc.get_windows(np.asarray(sig, dtype=np.float32), chunk, step)
+        valid = np.full(w.shape[0], chunk, dtype=np.int32)
+        valid[-1] = chunk - pad
+        return w.astype(np.float32), valid, pad
+
+    def basecall_reads_chunk(self, signals, chunk_len, step, beam_width):
+        out = []
+        for sig in signals:
+            w, valid, _ = self._windows(sig, chunk_len, step)
+            out.append(self.basecall_chunk(w, valid, beam_width))
+        return out
+
+    def basecall_reads_global(self, signals, chunk_len, step, beam_width, use_lm, s_threshold=0.0, r_threshold=0.0):
+        out = []
+        for sig in signals:
+            w, _, pad = self._windows(sig, chunk_len, step)
+            out.append(self.basecall_global(w, np.array([0, w.shape[0]]), np.array([pad]), step, beam_width, use_lm,
+                                            s_threshold, r_threshold)[0])
+        return out
+
     def close(self):
         pass
