@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--windowed", action="store_true", help="evaluate all 512 windows per step like the reference (default: streamed forward)")
+    ap.add_argument("--check", action="store_true", help="untimed cross-check: streamed labels == windowed labels on one batch")
     ap.add_argument("--decode-group", type=int, default=8, help="batches per beam-search launch in the two-stream pipeline")
     ap.add_argument("--cpu-reads", type=int, default=0, help="reads in the CPU-baseline sample (0: sized to the host core count)")
     args = ap.parse_args()
@@ -113,7 +115,10 @@ def main():
 
     def step(i):
         """unpipelined: forward -> decode -> labels on the host, one stream (used for the per-kernel timing pass)"""
-        be.basecall_reads_chunk_resident(batches[i % n_batches][3], read_off, reads_per_batch, CHUNK, STEP, BEAM, labels, lens)
+        if args.windowed:
+            be.basecall_chunk_resident(batches[i % n_batches][0], BATCH_WINDOWS, CHUNK, batches[i % n_batches][1], BEAM, labels, lens)
+        else:
+            be.basecall_reads_chunk_resident(batches[i % n_batches][3], read_off, reads_per_batch, CHUNK, STEP, BEAM, labels, lens)
 
     def submit(i):
         """pipelined, reads-level: the batch's 64 normalised reads are windowed on the device and every time step is
@@ -145,19 +150,22 @@ def main():
             el = float(be.rccl_allreduce_max([el])[0])
         return el
 
-    elapsed_windowed = timed(submit_windowed)
-    ref_lab, ref_len = out[0][0].copy(), out[0][1].copy()
-    elapsed = timed(submit)
-    # same batches in the same output slots: the reads-level path must reproduce the window-level labels exactly
-    assert np.array_equal(ref_len, out[0][1]) and np.array_equal(ref_lab, out[0][0]), "streamed != windowed labels"
+    if args.check:
+        # untimed: the reads-level (streamed) path must reproduce the window-level labels exactly
+        la, na = np.zeros_like(labels), np.zeros_like(lens)
+        be.basecall_chunk_resident(batches[0][0], BATCH_WINDOWS, CHUNK, batches[0][1], BEAM, la, na)
+        step(0)
+        assert np.array_equal(na, lens) and all(np.array_equal(la[i, :na[i]], labels[i, :na[i]]) for i in range(BATCH_WINDOWS)), \
+            "streamed != windowed labels"
+    elapsed = timed(submit_windowed if args.windowed else submit)
     for lab, ln in out[: max(1, min(len(out), args.steps))]:
         assert ln.min() >= 0 and ln.max() <= CHUNK and ln.sum() > 0
 
     samples_per_step = reads_per_batch * READ_LEN  # input samples basecalled per step per GPU
     value = world * args.steps * samples_per_step / elapsed
-    value_windowed = world * args.steps * samples_per_step / elapsed_windowed
     halo = 252
-    rows_streamed = reads_per_batch * (READ_LEN + 7 * halo)   # time steps the model evaluates per step
+    # time steps the model evaluates per step: every window row (windowed) or every time step once (streamed)
+    rows_streamed = BATCH_WINDOWS * CHUNK if args.windowed else reads_per_batch * (READ_LEN + 7 * halo)
 
     # ---- roofline of the dominant kernel (dilated conv on fp32 MFMA), HIP events on the launch stream
     roof = None
@@ -212,16 +220,16 @@ def main():
                             "MAD-normalised, chunk=1024 step=512 -> 8 windows/read; step = 512 windows (64 reads): "
                             "TCN forward fp32 + chunk-mode CTC beam search W=10 over every window (LM unused in chunk "
                             "mode, reference basecall.py:110-121) + labels to host; random He-normal weights seed 1234",
-                "forward": "streamed: each read's time steps are evaluated once (4096 + 7*252 rows per read instead of "
-                           "8*1024; probabilities and labels bit-identical to the windowed evaluation, tests/test_gpu_reads.py); "
-                           "value_windowed is the same job with all 512 windows through the model",
+                "forward": ("windowed: all 512 windows x 1024 rows through the model, as the reference does" if args.windowed else
+                            "streamed: each read's time steps are evaluated once (4096 + 7*252 rows per read instead of "
+                            "8*1024); probabilities and labels bit-identical to the windowed evaluation "
+                            "(tests/test_gpu_reads.py; bench.py --check; --windowed runs the windowed job)"),
                 "model_rows_per_step": rows_streamed,
                 "chunk_len": CHUNK, "step_size": STEP, "batch_windows": BATCH_WINDOWS, "beam_width": BEAM,
                 "decode_type": "chunk", "samples_per_step_per_gpu": samples_per_step, "sharding": "reads per rank, no data-path collective",
                 "pipelining": f"2 HIP streams: forwards back to back; beam search + label copy-out of a group of {args.decode_group} batches overlaps the next group's forwards; all labels on host at stop",
             },
             "roofline": roof,
-            "value_windowed": value_windowed, "ms_per_step_windowed": elapsed_windowed / args.steps * 1e3,
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
