@@ -134,6 +134,21 @@ int rd_basecall_reads_global(rd_ctx* ctx, const float* signal, const int64_t* re
                              int step, int beam_width, int use_lm, double s_thr, double r_thr, uint8_t* labels_out,
                              const int64_t* label_off, int32_t* label_len);
 
+/* ---- the step before the hot path on the device: mad_normalise -- radian/preprocess.py:24-49, basecall.py:78 ----
+ * raw = unscaled int16 DAQ samples of the reads packed back to back (read r at [read_off[r], read_off[r+1])).
+ * status[r]: 0 ok; 1 "MAD is zero, issue with signal." (output zeros); 2 "Signal must not be empty to normalise" --
+ * the two ValueErrors after which basecall.py:77-82 skips the read.  Output = float32(mad_normalise(raw, clip)),
+ * bit-identical to NumPy (exact order statistics, IEEE float64 arithmetic, np.vectorize's int64 quirk included). */
+int rd_normalise_reads(rd_ctx* ctx, const int16_t* raw, const int64_t* read_off, int n_reads, int outlier_clip,
+                       float* norm_out /* nullable */, int32_t* status);
+/* normalise + reads-level chunk / global basecall in one call; reads with status 1 are computed on zeros and must be
+ * dropped by the caller, empty reads are rejected (filter them first). */
+int rd_basecall_raw_chunk(rd_ctx* ctx, const int16_t* raw, const int64_t* read_off, int n_reads, int outlier_clip,
+                          int chunk_len, int step, int beam_width, uint8_t* labels_out, int32_t* label_len, int32_t* status);
+int rd_basecall_raw_global(rd_ctx* ctx, const int16_t* raw, const int64_t* read_off, int n_reads, int outlier_clip,
+                           int chunk_len, int step, int beam_width, int use_lm, double s_thr, double r_thr,
+                           uint8_t* labels_out, const int64_t* label_off, int32_t* label_len, int32_t* status);
+
 /* ---- device-resident form (inputs already in HBM; used by bench.py and by pipelined hosts) -- */
 int rd_dev_alloc(rd_ctx* ctx, size_t bytes, void** d_ptr);
 int rd_dev_free(rd_ctx* ctx, void* d_ptr);

@@ -38,6 +38,9 @@ SIGNATURES = {
     "rd_basecall_reads_chunk_resident": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp]),
     "rd_basecall_reads_global_resident": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp]),
     "rd_pipe_submit_reads": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp]),
+    "rd_normalise_reads": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_vp, c_vp]),
+    "rd_basecall_raw_chunk": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
+    "rd_basecall_raw_global": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp, c_vp]),
     "rd_dev_alloc": (c_i, [c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "rd_dev_free": (c_i, [c_vp, c_vp]),
     "rd_memcpy_h2d": (c_i, [c_vp, c_vp, c_vp, c_sz]),

@@ -205,6 +205,55 @@ class Backend:
                                                      _p(label_off), _p(lens)))
         return [labels[off[r]: off[r] + lens[r]].copy() for r in range(n)]
 
+    # ------------------------------------------------------------------ raw int16 reads (normalisation on the device)
+    STATUS_MESSAGES = {1: "MAD is zero, issue with signal.", 2: "Signal must not be empty to normalise"}  # preprocess.py:25-26,47-48
+
+    @staticmethod
+    def _pack_raw(raws):
+        sig = [np.ascontiguousarray(x, dtype=np.int16).ravel() for x in raws]
+        off = np.zeros(len(sig) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([x.shape[0] for x in sig])
+        flat = np.concatenate(sig) if sig else np.zeros(0, np.int16)
+        if flat.size == 0:
+            flat = np.zeros(1, np.int16)
+        return flat, off
+
+    def normalise_reads(self, raws, outlier_clip):
+        """float32(mad_normalise(raw, clip)) per read (radian/preprocess.py:24-49) + status per read (0 ok, 1 MAD zero, 2 empty)."""
+        flat, off = self._pack_raw(raws)
+        out = np.zeros(max(1, int(off[-1])), dtype=np.float32)
+        status = np.zeros(len(raws), dtype=np.int32)
+        self._check(self._L.rd_normalise_reads(self._h, _p(flat), _p(off), len(raws), int(outlier_clip), _p(out), _p(status)))
+        return [out[off[r]:off[r + 1]].copy() for r in range(len(raws))], status
+
+    def basecall_raw_chunk(self, raws, outlier_clip, chunk_len, step, beam_width):
+        """raw int16 reads -> (per read list of per-window label arrays, status per read)."""
+        flat, off = self._pack_raw(raws)
+        nw = [self.count_windows(off[r + 1] - off[r], chunk_len, step) for r in range(len(raws))]
+        tot = int(sum(nw))
+        labels = np.zeros((tot, chunk_len), dtype=np.uint8)
+        lens = np.zeros(tot, dtype=np.int32)
+        status = np.zeros(len(raws), dtype=np.int32)
+        self._check(self._L.rd_basecall_raw_chunk(self._h, _p(flat), _p(off), len(raws), int(outlier_clip), int(chunk_len), int(step),
+                                                  int(beam_width), _p(labels), _p(lens), _p(status)))
+        out, w = [], 0
+        for n in nw:
+            out.append([labels[w + i, : lens[w + i]].copy() for i in range(n)])
+            w += n
+        return out, status
+
+    def basecall_raw_global(self, raws, outlier_clip, chunk_len, step, beam_width, use_lm, s_threshold=0.0, r_threshold=0.0):
+        flat, off = self._pack_raw(raws)
+        n = len(raws)
+        labels = np.zeros(int(off[-1]) + 1, dtype=np.uint8)
+        lens = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        label_off = np.ascontiguousarray(off[:-1])
+        self._check(self._L.rd_basecall_raw_global(self._h, _p(flat), _p(off), n, int(outlier_clip), int(chunk_len), int(step),
+                                                   int(beam_width), 1 if use_lm else 0, float(s_threshold), float(r_threshold),
+                                                   _p(labels), _p(label_off), _p(lens), _p(status)))
+        return [labels[off[r]: off[r] + lens[r]].copy() for r in range(n)], status
+
     # ------------------------------------------------------------------ device-resident (bench)
     def dev_alloc(self, nbytes):
         p = ctypes.c_void_p()

@@ -21,7 +21,6 @@ from time import time
 import numpy as np
 
 from . import fast5, lm as lm_mod, weights as weights_mod
-from .preprocess import mad_normalise
 from .sequence_assembly import consensus_sequence, labels_to_str
 
 
@@ -103,36 +102,26 @@ class FastaWriter:
         self.f.close()
 
 
-def preprocess_read(read, args):
-    """basecall.py:76-83 up to the windowing, which happens on the device: returns the normalised signal as float32
-    (what `sig_model.predict` would cast each window to) and the number of windows get_windows would make, or None
-    when the read is skipped."""
-    raw_signal = read.get_raw_data()
-    try:
-        norm_signal = mad_normalise(raw_signal, args.outlier_clip)
-    except ValueError as e:
-        print(e.args)
-        print(f"{read.read_id} signal issue, skipping this read.")
-        return None
-    if args.step_size <= 0:
-        raise ValueError("Step size must be > 0")            # preprocess.py:5-8
-    if args.step_size > args.chunk_len:
-        raise ValueError("Step size must be <= window size")
-    n = norm_signal.shape[0]
-    n_win = (0 if n < args.chunk_len else (n - args.chunk_len) // args.step_size + 1) + 1
-    return norm_signal.astype(np.float32), n_win
+STATUS_MESSAGES = {1: "MAD is zero, issue with signal.", 2: "Signal must not be empty to normalise"}  # preprocess.py:25-26,47-48
+
+
+def report_skipped(read_id, status):
+    """What basecall.py:79-82 prints when mad_normalise raises ValueError."""
+    print((STATUS_MESSAGES[int(status)],))
+    print(f"{read_id} signal issue, skipping this read.")
 
 
 def basecall_batch(be, batch, args, use_lm):
-    """batch: list of (read_id, normalised signal float32, n_windows).  Returns the sequences (un-reversed) in batch
-    order.  Whole reads go to the device; windows are formed there and every time step is evaluated once."""
-    signals = [sig for _, sig, _ in batch]
+    """batch: list of (read_id, raw int16 signal).  Returns (sequences un-reversed, status per read).  Raw reads go to
+    the device: MAD normalisation, windowing, forward (every time step evaluated once), assembly and beam search run
+    there; only the chunk-mode string stitch (basecall.py:122-123) is host work."""
+    raws = [raw for _, raw in batch]
     if args.decode_type == "global":
-        labels = be.basecall_reads_global(signals, args.chunk_len, args.step_size, args.beam_width, use_lm,
-                                          args.sig_threshold, args.rna_threshold)
-        return [labels_to_str(l) for l in labels]
-    frags = be.basecall_reads_chunk(signals, args.chunk_len, args.step_size, args.beam_width)
-    return [consensus_sequence([labels_to_str(f) for f in fr]) for fr in frags]  # basecall.py:122-123
+        labels, status = be.basecall_raw_global(raws, args.outlier_clip, args.chunk_len, args.step_size, args.beam_width, use_lm,
+                                                args.sig_threshold, args.rna_threshold)
+        return [labels_to_str(l) for l in labels], status
+    frags, status = be.basecall_raw_chunk(raws, args.outlier_clip, args.chunk_len, args.step_size, args.beam_width)
+    return [consensus_sequence([labels_to_str(f) for f in fr]) for fr in frags], status
 
 
 def run(args, be, reads=None, writer=None, shard=(0, 1)):
@@ -141,6 +130,10 @@ def run(args, be, reads=None, writer=None, shard=(0, 1)):
     [(read_index, read_id, sequence)] instead of writing when writer is None."""
     if reads is None:
         reads = fast5.iter_directory(args.fast5_dir)
+    if args.step_size <= 0:
+        raise ValueError("Step size must be > 0")            # preprocess.py:5-8
+    if args.step_size > args.chunk_len:
+        raise ValueError("Step size must be <= window size")
     use_lm = getattr(args, "_lm_loaded", False) and args.decode_type == "global"
     rank, world = shard
     results = []
@@ -151,9 +144,12 @@ def run(args, be, reads=None, writer=None, shard=(0, 1)):
         if not batch:
             return
         t0 = time()
-        seqs = basecall_batch(be, batch, args, use_lm)
+        seqs, status = basecall_batch(be, batch, args, use_lm)
         dur = (time() - t0) / len(batch)
-        for (rid, _, _), idx, seq in zip(batch, batch_idx, seqs):
+        for (rid, _), idx, seq, st in zip(batch, batch_idx, seqs, status):
+            if st != 0:
+                report_skipped(rid, st)
+                continue
             if writer is not None:
                 writer.write(rid, seq)
             results.append((idx, rid, seq))
@@ -163,13 +159,15 @@ def run(args, be, reads=None, writer=None, shard=(0, 1)):
     for idx, read in enumerate(reads):
         if idx % world != rank:
             continue
-        pre = preprocess_read(read, args)
-        if pre is None:
+        raw = np.asarray(read.get_raw_data())
+        n = raw.shape[0]
+        if n == 0:
+            report_skipped(read.read_id, 2)
             continue
-        sig, nw = pre
+        nw = (0 if n < args.chunk_len else (n - args.chunk_len) // args.step_size + 1) + 1
         if batch and n_win + nw > args.gpu_batch_windows:
             flush()
-        batch.append((read.read_id, sig, nw))
+        batch.append((read.read_id, raw))
         batch_idx.append(idx)
         n_win += nw
     flush()

@@ -125,7 +125,7 @@ extern "C" int rd_destroy(rd_ctx* ctx)
     timer_free(ctx->timer_decode);
     timer_free(ctx->timer_head);
     timer_free(ctx->timer_in);
-    DevBuf* bufs[] = {&ctx->ws_tiles, &ctx->ws_in, &ctx->ws_act0, &ctx->ws_act1, &ctx->ws_probs, &ctx->ws_mat, &ctx->ws_seq,
+    DevBuf* bufs[] = {&ctx->ws_tiles, &ctx->ws_raw, &ctx->ws_in, &ctx->ws_act0, &ctx->ws_act1, &ctx->ws_probs, &ctx->ws_mat, &ctx->ws_seq,
                       &ctx->ws_nodes_child, &ctx->ws_nodes_back, &ctx->ws_labels, &ctx->ws_misc, &ctx->model.storage,
                       &ctx->lm.storage, &ctx->lm.gate_storage};
     for (DevBuf* b : bufs) b->release();
@@ -1224,6 +1224,69 @@ extern "C" int rd_basecall_reads_global(rd_ctx* ctx, const float* signal, const 
     const size_t n = (size_t)read_off[n_reads];
     if (ctx->ws_in.reserve(n * 4 + 16)) return RD_ERR_NOMEM;
     RD_HIP(hipMemcpyAsync(ctx->ws_in.p, signal, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    return rd_basecall_reads_global_resident(ctx, ctx->ws_in.as<float>(), read_off, n_reads, chunk_len, step, beam_width, use_lm,
+                                             s_thr, r_thr, labels_out, label_off, label_len);
+}
+
+// ---- raw int16 reads in: normalisation on the device, then the reads-level paths --------------------------------
+namespace {
+
+// uploads raw samples + offsets, runs mad_normalise_kernel into ctx->ws_in, returns per-read status on the host
+int normalise_upload(rd_ctx* ctx, const int16_t* raw, const int64_t* read_off, int n_reads, int clip, int32_t* status)
+{
+    RD_REQUIRE(ctx && raw && read_off && status, "null argument");
+    RD_REQUIRE(n_reads >= 1 && read_off[0] == 0, "bad read offsets");
+    for (int r = 0; r < n_reads; r++) RD_REQUIRE(read_off[r + 1] >= read_off[r], "read offsets must be non-decreasing");
+    RD_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)read_off[n_reads];
+    const size_t o_off = align_up(n * 2 + 16, 256), o_st = o_off + align_up((size_t)(n_reads + 1) * 8, 256);
+    if (ctx->ws_raw.reserve(o_st + (size_t)n_reads * 4 + 16) || ctx->ws_in.reserve(n * 4 + 16)) return RD_ERR_NOMEM;
+    char* base = (char*)ctx->ws_raw.p;
+    if (n) RD_HIP(hipMemcpyAsync(base, raw, n * 2, hipMemcpyHostToDevice, ctx->stream));
+    RD_HIP(hipMemcpyAsync(base + o_off, read_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    int rc = rd_normalise_dev(ctx, (const int16_t*)base, (const int64_t*)(base + o_off), n_reads, clip, ctx->ws_in.as<float>(),
+                              (int32_t*)(base + o_st));
+    if (rc) return rc;
+    RD_HIP(hipMemcpyAsync(status, base + o_st, (size_t)n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    return RD_OK;
+}
+
+}  // namespace
+
+extern "C" int rd_normalise_reads(rd_ctx* ctx, const int16_t* raw, const int64_t* read_off, int n_reads, int outlier_clip,
+                                  float* norm_out, int32_t* status)
+{
+    int rc = normalise_upload(ctx, raw, read_off, n_reads, outlier_clip, status);
+    if (rc) return rc;
+    const size_t n = (size_t)read_off[n_reads];
+    if (norm_out && n) {
+        RD_HIP(hipMemcpyAsync(norm_out, ctx->ws_in.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RD_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return RD_OK;
+}
+
+extern "C" int rd_basecall_raw_chunk(rd_ctx* ctx, const int16_t* raw, const int64_t* read_off, int n_reads, int outlier_clip,
+                                     int chunk_len, int step, int beam_width, uint8_t* labels_out, int32_t* label_len,
+                                     int32_t* status)
+{
+    int rc = normalise_upload(ctx, raw, read_off, n_reads, outlier_clip, status);
+    if (rc) return rc;
+    for (int r = 0; r < n_reads; r++)
+        RD_REQUIRE(status[r] != 2, "rd_basecall_raw_chunk: read %d is empty (the caller skips empty reads, basecall.py:77-82)", r);
+    return rd_basecall_reads_chunk_resident(ctx, ctx->ws_in.as<float>(), read_off, n_reads, chunk_len, step, beam_width, labels_out,
+                                            label_len);
+}
+
+extern "C" int rd_basecall_raw_global(rd_ctx* ctx, const int16_t* raw, const int64_t* read_off, int n_reads, int outlier_clip,
+                                      int chunk_len, int step, int beam_width, int use_lm, double s_thr, double r_thr,
+                                      uint8_t* labels_out, const int64_t* label_off, int32_t* label_len, int32_t* status)
+{
+    int rc = normalise_upload(ctx, raw, read_off, n_reads, outlier_clip, status);
+    if (rc) return rc;
+    for (int r = 0; r < n_reads; r++)
+        RD_REQUIRE(status[r] != 2, "rd_basecall_raw_global: read %d is empty (the caller skips empty reads, basecall.py:77-82)", r);
     return rd_basecall_reads_global_resident(ctx, ctx->ws_in.as<float>(), read_off, n_reads, chunk_len, step, beam_width, use_lm,
                                              s_thr, r_thr, labels_out, label_off, label_len);
 }

@@ -102,7 +102,7 @@ struct rd_ctx {
     Model model;
     LM lm;
     // workspaces
-    DevBuf ws_tiles;
+    DevBuf ws_tiles, ws_raw;
     int tiles_nW = -1, tiles_T = -1;   // shape the cached uniform tile descriptors were built for
     DevBuf ws_in, ws_act0, ws_act1, ws_probs, ws_mat, ws_seq, ws_nodes_child, ws_nodes_back, ws_labels, ws_misc;
     // pinned host staging
@@ -125,6 +125,9 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* d
                   double s_thr, double r_thr, uint8_t* d_labels, int32_t* d_label_len, double* d_best_score,
                   hipStream_t stream = nullptr /* default: ctx->stream */, const int64_t* d_seq_off2 = nullptr,
                   const int32_t* d_seq_split = nullptr);
+// preprocess.hip
+int rd_normalise_dev(rd_ctx* ctx, const int16_t* d_raw, const int64_t* d_read_off, int n_reads, int clip, float* d_out,
+                     int32_t* d_status);
 // assemble.hip
 int rd_assemble_dev(rd_ctx* ctx, const float* d_probs, int nW, int T, int pad, int step, double* d_out, int64_t N,
                     int streamed = 0 /* 1: d_probs is the streamed forward [N][5]; row t is taken from row t */);

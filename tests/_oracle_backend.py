@@ -57,5 +57,24 @@ class OracleBackend:
                                             s_threshold, r_threshold)[0])
         return out
 
+    def _normalise(self, raws, clip):
+        sigs, status = [], []
+        for raw in raws:
+            try:
+                sigs.append(orc.mad_normalise(np.asarray(raw), clip).astype(np.float32))
+                status.append(0)
+            except ValueError as e:
+                sigs.append(np.zeros(len(raw), dtype=np.float32))
+                status.append(1 if "MAD" in e.args[0] else 2)
+        return sigs, np.array(status, dtype=np.int32)
+
+    def basecall_raw_chunk(self, raws, outlier_clip, chunk_len, step, beam_width):
+        sigs, status = self._normalise(raws, outlier_clip)
+        return self.basecall_reads_chunk(sigs, chunk_len, step, beam_width), status
+
+    def basecall_raw_global(self, raws, outlier_clip, chunk_len, step, beam_width, use_lm, s_threshold=0.0, r_threshold=0.0):
+        sigs, status = self._normalise(raws, outlier_clip)
+        return self.basecall_reads_global(sigs, chunk_len, step, beam_width, use_lm, s_threshold, r_threshold), status
+
     def close(self):
         pass

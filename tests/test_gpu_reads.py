@@ -122,3 +122,58 @@ def test_pipe_submit_reads_equals_unpipelined(be):
     for d in dptr:
         be.dev_free(d)
     be.pipe_config(4)
+
+
+def test_normalise_on_device_matches_golden_and_numpy(be, golden_dir):
+    """rd_normalise_reads == float32(mad_normalise(...)) bit for bit, incl. the int64 quirk and the two error statuses."""
+    import json
+    import os
+    from radian_amd.preprocess import mad_normalise
+    g = json.load(open(os.path.join(golden_dir, "preprocess_cases.json")))
+    arr = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    raws, exp, exp_status, clips = [], [], [], []
+    for c in g["cases"]:
+        raws.append(arr["sig_" + c["name"]])
+        clips.append(c["clip"])
+        if "error" in c:
+            exp.append(None)
+            exp_status.append(1 if "MAD" in c["error"] else 2)
+        else:
+            exp.append(arr["norm_" + c["name"]].astype(np.float32))
+            exp_status.append(0)
+    for clip in sorted(set(clips)):
+        idx = [i for i, c in enumerate(clips) if c == clip]
+        got, status = be.normalise_reads([raws[i] for i in idx], clip)
+        for j, i in enumerate(idx):
+            assert status[j] == exp_status[i], g["cases"][i]["name"]
+            if exp[i] is not None:
+                assert np.array_equal(got[j], exp[i]), g["cases"][i]["name"]
+    # random reads of many lengths / parities against the NumPy implementation
+    rng = np.random.default_rng(3)
+    reads = [np.round(rng.normal(500, 80, size=n)).astype(np.int16) for n in (1, 2, 3, 4, 5, 100, 101, 4096, 12833, 70001)]
+    reads.append(np.array([-32768, 32767, 0, 5, -7, 32767, -32768, 9], dtype=np.int16))
+    reads.append((rng.integers(-32768, 32768, size=5000)).astype(np.int16))
+    got, status = be.normalise_reads(reads, 4)
+    for r, sig in enumerate(reads):
+        try:
+            e = mad_normalise(sig, 4).astype(np.float32)
+            assert status[r] == 0 and np.array_equal(got[r], e), (r, len(sig))
+        except ValueError:
+            assert status[r] == 1
+
+
+def test_raw_paths_equal_normalised_paths(be):
+    from radian_amd.preprocess import mad_normalise
+    rng = np.random.default_rng(4)
+    reads = [np.round(rng.normal(500, 80, size=n)).astype(np.int16) for n in (4096, 700, 3000)]
+    reads.insert(1, np.full(300, 512, dtype=np.int16))   # MAD == 0
+    frags, status = be.basecall_raw_chunk(reads, 4, 1024, 512, 10)
+    assert status.tolist() == [0, 1, 0, 0]
+    good = [i for i in range(4) if status[i] == 0]
+    exp = be.basecall_reads_chunk([mad_normalise(reads[i], 4).astype(np.float32) for i in good], 1024, 512, 10)
+    for j, i in enumerate(good):
+        assert len(frags[i]) == len(exp[j]) and all(np.array_equal(a, b) for a, b in zip(frags[i], exp[j]))
+    labs, status = be.basecall_raw_global(reads, 4, 1024, 128, 6, False)
+    exp = be.basecall_reads_global([mad_normalise(reads[i], 4).astype(np.float32) for i in good], 1024, 128, 6, False)
+    for j, i in enumerate(good):
+        assert np.array_equal(labs[i], exp[j])
