@@ -162,7 +162,7 @@ ModelLayout model_layout(int nblocks)
         return o;
     };
     L.zeros = take(64);
-    L.sink = take(256);
+    L.sink = take(1024);
     L.w_in = take(RD_K * RD_C);
     L.b_in = take(RD_C);
     L.w_match = take(RD_C);

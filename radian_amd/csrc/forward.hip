@@ -51,7 +51,7 @@ struct ConvArgs {
     const float* b2;      // EPI_HEAD: [5]
     float* probs;         // EPI_HEAD: [nW][T][5]
     const float* zeros;   // >= 32 zero floats (source of the causal left padding for the LDS-DMA)
-    float* sink;          // 256 floats nobody reads: target of the stores past a segment's end
+    float* sink;          // 1024 floats nobody reads: target of the stores past a segment's end
     const TileDesc* tiles; // one per workgroup
     int dil;
 };
@@ -162,67 +162,82 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
             }
         }
     }
-    if constexpr (EPI == EPI_HEAD) __syncthreads();   // staging LDS is reused by the head epilogue
+    __syncthreads();   // every wave is done with the staging LDS: the epilogues reuse it
 
     // ---------------- epilogue ----------------
     // C/D layout of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     if constexpr (EPI != EPI_HEAD) {
-        // out may alias resid (in-place residual): each element is read, then written, by the same thread only, so the
-        // restrict-qualified views just let the compiler batch a row's loads ahead of the previous row's stores.
-        float* __restrict__ outw = a.out + (size_t)seg_row * RD_C;
-        const float* __restrict__ resw = (EPI == EPI_RES_IDENT) ? a.resid + (size_t)seg_row * RD_C : nullptr;
-        float bias[NT], wmt[NT], bmt[NT];
+        // The accumulator layout gives a lane ONE channel of 16 rows: stored directly that is 128 dword stores per lane
+        // (store-issue bound, ~10 % of the kernel).  Instead each wave transposes its tile through a private LDS patch,
+        // 32 rows x 64 channels at a time, and leaves with 16-B-per-lane accesses: 4 x 256-B row segments per
+        // instruction, 32 store (and 32 residual load) instructions per lane instead of 128.
+        constexpr int TSTR = 68;                       // patch row stride in floats (64 + 4: conflict-free, 16-B aligned)
+        float* ts = smem + wave * (32 * TSTR);
+        float* outw = a.out + (size_t)seg_row * RD_C;  // may alias a.resid: each element is read then written by one lane
+        const float* resw = a.resid + (size_t)seg_row * RD_C;
+        const bool interior = t0 + BM <= T;
+        float4* sink4 = (float4*)a.sink + threadIdx.x;
+        const int rrow = lane >> 4;                    // 0..3: row inside a 4-row store group
+        const int c4 = (lane & 15) * 4;                // channel offset inside the 64-channel patch
 #pragma unroll
-        for (int n = 0; n < NT; n++) {
-            const int co = wn * NT * 32 + n * 32 + fr;
-            bias[n] = a.bias[co];
-            wmt[n] = bmt[n] = 0.f;
-            if constexpr (EPI == EPI_RES_MATCH) {
-                wmt[n] = a.wmatch[co];
-                bmt[n] = a.bmatch[co];
-            }
-        }
-        // Tiles that end inside the segment store every row; a tile that straddles the segment end redirects the rows
-        // past it to a per-lane sink word instead of branching (no divergence, no wait between stores).
-        auto emit = [&](auto guard_tag) {
-            constexpr bool GUARD = decltype(guard_tag)::value;
-            float* sink = a.sink + threadIdx.x;
+        for (int m = 0; m < 2; m++) {
 #pragma unroll
-            for (int m = 0; m < 2; m++) {
+            for (int np = 0; np < NT / 2; np++) {
+                // ---- accumulators (+ bias, ReLU) -> LDS patch
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int row = wm * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                    const int t = t0 + row;
-                    const bool inb = !GUARD || t < T;
-                    const int tc = inb ? t : T - 1;
-                    float xv = 0.f;
-                    if constexpr (EPI == EPI_RES_MATCH) xv = a.x[(size_t)td.src_row + tc];
-                    float* orow = outw + (size_t)tc * RD_C + wn * NT * 32 + fr;
-                    float rv[NT];
-                    if constexpr (EPI == EPI_RES_IDENT) {
-                        const float* rrow = resw + (size_t)tc * RD_C + wn * NT * 32 + fr;
+                for (int j = 0; j < 2; j++) {
+                    const int n = 2 * np + j;
+                    const float bias = a.bias[wn * NT * 32 + n * 32 + fr];
 #pragma unroll
-                        for (int n = 0; n < NT; n++) rv[n] = rrow[n * 32];
-                    }
-#pragma unroll
-                    for (int n = 0; n < NT; n++) {
-                        float v = acc[m][n][e] + bias[n];
-                        v = v > 0.f ? v : 0.f;
-                        if constexpr (EPI == EPI_RES_IDENT) {
-                            v += rv[n];
-                            v = v > 0.f ? v : 0.f;
-                        } else if constexpr (EPI == EPI_RES_MATCH) {
-                            v = (bmt[n] + xv * wmt[n]) + v;
-                            v = v > 0.f ? v : 0.f;
-                        }
-                        float* dst = inb ? orow + n * 32 : sink;
-                        *dst = v;
+                    for (int e = 0; e < 16; e++) {
+                        const int rl = (e & 3) + 8 * (e >> 2) + 4 * fh;
+                        float v = acc[m][n][e] + bias;
+                        ts[rl * TSTR + j * 32 + fr] = v > 0.f ? v : 0.f;
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // ---- LDS patch -> (residual) -> global, 16 B per lane
+                const int ch = wn * NT * 32 + np * 64 + c4;
+                float4 wm4 = make_float4(0.f, 0.f, 0.f, 0.f), bm4 = wm4;
+                if constexpr (EPI == EPI_RES_MATCH) {
+                    wm4 = *(const float4*)(a.wmatch + ch);
+                    bm4 = *(const float4*)(a.bmatch + ch);
+                }
+                float4 rv[8];
+                int tt[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int t = t0 + wm * 64 + m * 32 + i * 4 + rrow;
+                    tt[i] = t;
+                    if constexpr (EPI == EPI_RES_IDENT) {
+                        const int tc = (interior || t < T) ? t : T - 1;
+                        rv[i] = *(const float4*)(resw + (size_t)tc * RD_C + ch);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    float4 v = *(const float4*)(ts + (i * 4 + rrow) * TSTR + c4);
+                    const int t = tt[i];
+                    const bool inb = interior || t < T;
+                    if constexpr (EPI == EPI_RES_IDENT) {
+                        v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
+                        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                    } else if constexpr (EPI == EPI_RES_MATCH) {
+                        const float xv = a.x[(size_t)td.src_row + (inb ? t : T - 1)];
+                        v.x = (bm4.x + xv * wm4.x) + v.x; v.y = (bm4.y + xv * wm4.y) + v.y;
+                        v.z = (bm4.z + xv * wm4.z) + v.z; v.w = (bm4.w + xv * wm4.w) + v.w;
+                        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                    }
+                    float4* dst = inb ? (float4*)(outw + (size_t)t * RD_C + ch) : sink4;
+                    *dst = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-        };
-        if (t0 + BM <= T) emit(std::false_type{});
-        else emit(std::true_type{});
+        }
     } else {
         // Dense(128) bias + ReLU into LDS, then Dense(5) + softmax   (model.py:72-75)
         constexpr int LDH = RD_H + 1;
