@@ -78,15 +78,21 @@ def main():
     from radian_amd.backend import RD_TIMER_CONV, RD_TIMER_DECODE, RD_TIMER_HEAD
 
     be = Backend(local_rank)
-    uid_path = None
+    comm_kind = "single"
+    comm = None
     if world > 1:
         from radian_amd import dist
-        uid_path = dist.uid_path()
-        uid = dist.exchange_uid(be.rccl_unique_id, rank, uid_path)   # 128-byte id through a file; no PyTorch here
-        be.rccl_init(rank, world, uid)
-        if rank == 0:
+        try:
+            # the one collective of the job: rank 0 loads + repacks the weights, RCCL broadcasts the 8.8 MB device image
+            # over xGMI; the 128-byte RCCL id goes through a file keyed by the launcher's pid (no PyTorch in this process)
+            comm = dist.RcclComm(be, rank, world, dist.uid_path())
+            comm.bcast_artifacts(be, lambda b: b.load_weights(weights.synthetic_weights(seed=1234)))
+            comm_kind = "rccl"
+        except Exception as e:  # keep the scaling run alive: file-based barrier, every rank loads its own weights
+            print(f"[bench rank {rank}] RCCL start-up failed ({e}); falling back to file-based barrier", file=sys.stderr)
+            comm = dist.FileComm(rank, world, dist.uid_path() + ".fc")
             be.load_weights(weights.synthetic_weights(seed=1234))
-        be.rccl_bcast_model(0)  # the one collective of the job: 8.8 MB of packed weights over xGMI
+            comm_kind = "file-fallback"
     else:
         be.load_weights(weights.synthetic_weights(seed=1234))
 
@@ -138,7 +144,7 @@ def main():
         be.pipe_flush()
         be.sync()
         if world > 1:
-            be.rccl_barrier()
+            comm.barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             fn(i)
@@ -146,8 +152,8 @@ def main():
         be.sync()
         el = time.perf_counter() - t0
         if world > 1:
-            be.rccl_barrier()
-            el = float(be.rccl_allreduce_max([el])[0])
+            comm.barrier()
+            el = float(comm.allreduce_max([el])[0])
         return el
 
     if args.check:
@@ -226,7 +232,7 @@ def main():
                             "(tests/test_gpu_reads.py; bench.py --check; --windowed runs the windowed job)"),
                 "model_rows_per_step": rows_streamed,
                 "chunk_len": CHUNK, "step_size": STEP, "batch_windows": BATCH_WINDOWS, "beam_width": BEAM,
-                "decode_type": "chunk", "samples_per_step_per_gpu": samples_per_step, "sharding": "reads per rank, no data-path collective",
+                "decode_type": "chunk", "samples_per_step_per_gpu": samples_per_step, "sharding": "reads per rank, no data-path collective", "startup_comm": comm_kind,
                 "pipelining": f"2 HIP streams: forwards back to back; beam search + label copy-out of a group of {args.decode_group} batches overlaps the next group's forwards; all labels on host at stop",
             },
             "roofline": roof,
@@ -235,8 +241,8 @@ def main():
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = value / cpu["value"]
         print(json.dumps(out))
-        if uid_path and os.path.exists(uid_path):
-            os.remove(uid_path)
+    if comm is not None:
+        comm.close()
     for b in batches:
         be.dev_free(b[0])
         be.dev_free(b[3])

@@ -93,6 +93,51 @@ class RcclComm:
             os.remove(self._uid_file)
 
 
+class FileComm:
+    """Last-resort transport through a shared directory on one node (no collective library): used by bench.py only if
+    the RCCL communicator cannot be created, so that a scaling run still reports.  Every rank loads the artefacts itself."""
+
+    def __init__(self, rank, world, base):
+        self.rank, self.world, self._base, self._seq = rank, world, base, 0
+
+    def _exchange(self, value):
+        self._seq += 1
+        mine = f"{self._base}.x{self._seq}.{self.rank}"
+        with open(mine + ".tmp", "w") as f:
+            f.write(repr(float(value)))
+        os.replace(mine + ".tmp", mine)
+        vals = []
+        t0 = time.time()
+        for r in range(self.world):
+            p = f"{self._base}.x{self._seq}.{r}"
+            while not os.path.exists(p):
+                if time.time() - t0 > 600:
+                    raise RuntimeError("FileComm: timed out waiting for rank %d" % r)
+                time.sleep(0.0005)
+            with open(p) as f:
+                vals.append(float(f.read()))
+        return vals
+
+    def barrier(self):
+        self._exchange(0.0)
+
+    def allreduce_max(self, values):
+        return np.asarray([max(self._exchange(v)) for v in np.asarray(values, dtype=np.float64).ravel()])
+
+    def bcast_artifacts(self, be, load_fn):
+        load_fn(be)
+
+    def close(self):
+        self.barrier()
+        # once everyone has passed exchange k, every file of exchanges < k has been read by all ranks; the files of the
+        # last exchange stay (a few bytes, named after the launcher's pid + start time, never reused)
+        for q in range(1, self._seq):
+            try:
+                os.remove(f"{self._base}.x{q}.{self.rank}")
+            except OSError:
+                pass
+
+
 class GlooComm:
     """torch.distributed gloo; artefacts travel as host bytes and every rank loads them itself."""
 

@@ -56,3 +56,28 @@ def test_two_rank_gloo_equals_single(tmp_path, mode, oracle):
     assert [tuple(x) for x in merged] == [tuple(x) for x in single]
     assert [i for i, _, _ in merged] == [0, 1, 2, 3, 4]
     assert all(len(s) > 0 for _, _, s in merged)
+
+
+def test_uid_rendezvous_and_filecomm_under_torchrun(tmp_path):
+    """torch.distributed.run (the driver's launcher) with 3 ranks on CPU: the launcher-pid-keyed rendezvous file gives
+    every rank the same id, and the file-based fallback transport computes barrier + max correctly."""
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import os, sys, hashlib\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from radian_amd import dist\n"
+        "rank, lr, world = dist.env_rank_world()\n"
+        "p = dist.uid_path()\n"
+        "uid = dist.exchange_uid(lambda: os.urandom(128), rank, p)\n"
+        "c = dist.FileComm(rank, world, p + '.fc')\n"
+        "c.barrier()\n"
+        "m = c.allreduce_max([float(rank), 10.0 - rank])\n"
+        "assert list(m) == [world - 1.0, 10.0], m\n"
+        "c.close()\n"
+        f"open(os.path.join({str(tmp_path)!r}, f'uid{{rank}}'), 'w').write(hashlib.md5(uid).hexdigest())\n")
+    port = _free_port()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=150)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    uids = {open(tmp_path / f"uid{i}").read() for i in range(3)}
+    assert len(uids) == 1
