@@ -77,7 +77,7 @@ def main():
     synthetic.mad_normalise = __import__('radian_amd.preprocess', fromlist=['mad_normalise']).mad_normalise
     from radian_amd.backend import RD_TIMER_CONV, RD_TIMER_DECODE, RD_TIMER_HEAD
 
-    be = Backend(local_rank)
+    be = Backend(int(os.environ.get("RD_BENCH_DEVICE", local_rank)))   # override only for rehearsals on a 1-GPU box
     comm_kind = "single"
     comm = None
     if world > 1:
