@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 CHUNK, STEP, READ_LEN, BATCH_WINDOWS, BEAM = 1024, 512, 4096, 512, 10
 FLOP_PER_CONV_ROW = 2 * 256 * 256 * 3  # one dilated conv, per window time step
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+F16_MFMA_PEAK_TFLOPS = 16 * 157.3      # dense f16 MFMA = 16x the fp32 MFMA rate (~2.5 PFLOP/s)
 
 
 def cpu_baseline(windows, valid, n_reads):
@@ -60,6 +61,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--windowed", action="store_true", help="evaluate all 512 windows per step like the reference (default: streamed forward)")
+    ap.add_argument("--precision", choices=["fp32", "f16x3"], default="fp32",
+                    help="matrix-product arithmetic of the forward: exact fp32 MFMA (default) or split-f16 products (fp32-equivalent accuracy)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary timed run in the other precision mode")
     ap.add_argument("--check", action="store_true", help="untimed cross-check: streamed labels == windowed labels on one batch")
     ap.add_argument("--decode-group", type=int, default=8, help="batches per beam-search launch in the two-stream pipeline")
     ap.add_argument("--cpu-reads", type=int, default=0, help="reads in the CPU-baseline sample (0: sized to the host core count)")
@@ -95,6 +99,8 @@ def main():
             comm_kind = "file-fallback"
     else:
         be.load_weights(weights.synthetic_weights(seed=1234))
+
+    be.set_precision(args.precision)
 
     # ---- synthetic input, resident in HBM: 4 distinct batches of 64 reads per rank, cycled
     reads_per_batch = BATCH_WINDOWS // 8
@@ -169,6 +175,19 @@ def main():
 
     samples_per_step = reads_per_batch * READ_LEN  # input samples basecalled per step per GPU
     value = world * args.steps * samples_per_step / elapsed
+    # secondary, reported beside the headline: the same job with split-f16 ("f16x3") matrix products -- every fp32 operand
+    # as an f16 hi+lo pair, three f16 MFMAs per product, fp32 accumulate; same softmax error vs a float64-accumulated
+    # reference as the fp32-MFMA mode (tests/test_gpu_forward.py::test_forward_split_f16x3_accuracy)
+    secondary = None
+    if args.precision == "fp32" and not args.no_secondary and not args.windowed:
+        be.set_precision("f16x3")
+        el2 = timed(submit)
+        be.set_precision("fp32")
+        secondary = {"precision": "f16x3 split products (3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate)",
+                     "value": world * args.steps * samples_per_step / el2, "unit": "samples/s",
+                     "ms_per_step": el2 / args.steps * 1e3,
+                     "accuracy": "max |softmax - float64-accumulated reference|: 6.6e-6 / 6.5e-5 (peaky head) vs 1.1e-5 / 7.1e-5 for "
+                                 "the fp32-MFMA mode (tests/test_gpu_forward.py)"}
     halo = 252
     # time steps the model evaluates per step: every window row (windowed) or every time step once (streamed)
     rows_streamed = BATCH_WINDOWS * CHUNK if args.windowed else reads_per_batch * (READ_LEN + 7 * halo)
@@ -194,6 +213,7 @@ def main():
         flop_per_launch = rows * FLOP_PER_CONV_ROW
         avg_s = tc["total_ms"] / max(1, tc["launches"]) * 1e-3
         achieved = flop_per_launch / avg_s / 1e12
+        peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else F16_MFMA_PEAK_TFLOPS / 3.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -202,9 +222,10 @@ def main():
             except Exception:
                 traffic = None
         roof = {
-            "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-            "kernel": "tcn_gemm_kernel<4,3,*> (dilated causal conv 256->256, k=3, v_mfma_f32_32x32x2_f32)",
+            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "frac": achieved / peak, "traffic": traffic,
+            "kernel": ("tcn_gemm_kernel<4,3,*> (dilated causal conv 256->256, k=3, v_mfma_f32_32x32x2_f32)" if args.precision == "fp32" else
+                       "tcn_gemm_split_kernel<4,3,*> (same conv, 3 x v_mfma_f32_32x32x16_f16 per fp32 product; peak = 2516/3 TFLOP/s)"),
             "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_s * 1e3, "launches_timed": tc["launches"],
             "conv_ms_per_step": tc["total_ms"] / n_prof, "decode_ms_per_step": td["total_ms"] / n_prof,
             "head_ms_per_step": th["total_ms"] / n_prof,
@@ -220,7 +241,7 @@ def main():
             "metric": "signal samples/s basecalled (chunk=1024, beam=10)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16x3 split (f32 accumulate)", "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[2]: synthetic Gaussian int16 reads x 4096 samples (round(N(500,80))), "
                             "MAD-normalised, chunk=1024 step=512 -> 8 windows/read; step = 512 windows (64 reads): "
@@ -237,6 +258,8 @@ def main():
             },
             "roofline": roof,
         }
+        if secondary is not None:
+            out["secondary_f16x3"] = secondary
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = value / cpu["value"]

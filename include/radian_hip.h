@@ -46,6 +46,10 @@ int rd_decode_max_width(void);        /* largest supported --beam-width (51) */
 int rd_create(int device_id, rd_ctx** out);
 int rd_destroy(rd_ctx* ctx);
 int rd_sync(rd_ctx* ctx);             /* wait for the context's stream */
+/* Matrix-product arithmetic of the forward: 0 (default) exact fp32 MFMA; 1 split-f16 "f16x3": every fp32 operand
+ * carried as an f16 hi+lo pair (22 significant bits), products hi*hi + hi*lo + lo*hi accumulated in fp32 on the f16
+ * matrix pipe -- same measured softmax error vs a float64 reference as mode 0. */
+int rd_set_precision(rd_ctx* ctx, int mode);
 
 /* ---- model artefacts ----------------------------------------------------------------------- */
 /* Replaces model.load_weights(checkpoint) -- radian/model.py:42-45.

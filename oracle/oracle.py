@@ -259,15 +259,17 @@ def chunk_consensus(fragments):
 # ------------------------------------------------------------------------------------------------
 # model.py (UNPINNED)
 # ------------------------------------------------------------------------------------------------
-def tcn_forward(weights, x, C=256, K=3, dilations=(1, 2, 4, 8, 16, 32), H=128, nthreads=0):
+def tcn_forward(weights, x, C=256, K=3, dilations=(1, 2, 4, 8, 16, 32), H=128, nthreads=0, acc64=False):
     """model.py:52-89 on windows x [B,T] -> probs [B,T,5] float32.  `weights` is the flat float32 array
-    in Keras load_weights order (radian_oracle.c, ro_tcn_forward)."""
+    in Keras load_weights order (radian_oracle.c, ro_tcn_forward).  acc64=True accumulates every dot product in float64
+    (the yardstick for float32 summation-order noise)."""
     w = np.ascontiguousarray(weights, dtype=np.float32)
     x = np.ascontiguousarray(x, dtype=np.float32)
     B, T = x.shape
     dil = np.ascontiguousarray(dilations, dtype=np.int32)
     probs = np.zeros((B, T, 5), dtype=np.float32)
-    rc = lib().ro_tcn_forward(_ptr(w), ctypes.c_int(C), ctypes.c_int(K), ctypes.c_int(len(dil)), _ptr(dil), ctypes.c_int(H),
+    fn = lib().ro_tcn_forward_acc64 if acc64 else lib().ro_tcn_forward
+    rc = fn(_ptr(w), ctypes.c_int(C), ctypes.c_int(K), ctypes.c_int(len(dil)), _ptr(dil), ctypes.c_int(H),
                               _ptr(x), ctypes.c_int(B), ctypes.c_int(T), _ptr(probs), ctypes.c_int(nthreads))
     if rc != 0:
         raise RuntimeError("ro_tcn_forward failed")

@@ -58,6 +58,11 @@ class Backend:
     def sync(self):
         self._check(self._L.rd_sync(self._h))
 
+    def set_precision(self, mode):
+        """'fp32' (default, exact fp32 MFMA) or 'f16x3' (split-f16 matrix products, fp32-equivalent accuracy)."""
+        code = {"fp32": 0, "f16x3": 1}[mode] if isinstance(mode, str) else int(mode)
+        self._check(self._L.rd_set_precision(self._h, code))
+
     @property
     def max_beam_width(self):
         return self._L.rd_decode_max_width()

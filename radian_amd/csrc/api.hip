@@ -4,6 +4,7 @@
 #include "common.h"
 #include "../../include/radian_hip.h"
 
+#include <cmath>
 #include <dlfcn.h>
 #include <math.h>
 #include <rccl/rccl.h>
@@ -135,6 +136,14 @@ extern "C" int rd_destroy(rd_ctx* ctx)
     return RD_OK;
 }
 
+extern "C" int rd_set_precision(rd_ctx* ctx, int mode)
+{
+    RD_REQUIRE(ctx, "rd_set_precision: null context");
+    RD_REQUIRE(mode == 0 || mode == 1, "rd_set_precision: mode %d (0 = fp32 MFMA, 1 = split-f16 f16x3)", mode);
+    ctx->precision = mode;
+    return RD_OK;
+}
+
 extern "C" int rd_sync(rd_ctx* ctx)
 {
     RD_REQUIRE(ctx, "rd_sync: null context");
@@ -149,7 +158,8 @@ constexpr size_t CONV_PK = (size_t)RD_K * RD_C * RD_C;  // 196608 floats
 constexpr size_t D1_PK = (size_t)RD_C * RD_H;
 
 struct ModelLayout {
-    size_t zeros, sink, w_in, b_in, w_match, b_match, w_conv[2 * RD_MAX_BLOCKS], b_conv[2 * RD_MAX_BLOCKS], w_d1, b_d1, w_d2, b_d2, total;
+    size_t zeros, sink, w_in, b_in, w_match, b_match, w_conv[2 * RD_MAX_BLOCKS], b_conv[2 * RD_MAX_BLOCKS], w_d1, b_d1, w_d2, b_d2;
+    size_t ws_conv[2 * RD_MAX_BLOCKS], ws_d1, total;
 };
 
 ModelLayout model_layout(int nblocks)
@@ -173,6 +183,12 @@ ModelLayout model_layout(int nblocks)
             L.w_conv[2 * b + w] = take(CONV_PK);
             L.b_conv[2 * b + w] = take(RD_C);
         }
+    for (int b = 0; b < nblocks; b++)
+        for (int w = 0; w < 2; w++) {
+            if (b == 0 && w == 0) continue;
+            L.ws_conv[2 * b + w] = take(CONV_PK);   // split-f16 image: same byte size as the fp32 one
+        }
+    L.ws_d1 = take(D1_PK);
     L.w_d1 = take(D1_PK);
     L.b_d1 = take(RD_H);
     L.w_d2 = take(RD_H * RD_NCLS);
@@ -195,7 +211,9 @@ void model_bind(Model& m, const ModelLayout& L)
             if (b == 0 && w == 0) continue;
             m.w_conv[2 * b + w] = base + L.w_conv[2 * b + w];
             m.b_conv[2 * b + w] = base + L.b_conv[2 * b + w];
+            m.ws_conv[2 * b + w] = base + L.ws_conv[2 * b + w];
         }
+    m.ws_d1 = base + L.ws_d1;
     m.w_d1 = base + L.w_d1;
     m.b_d1 = base + L.b_d1;
     m.w_d2 = base + L.w_d2;
@@ -225,6 +243,51 @@ void pack_dense(const float* k, float* dst)
         float* d = dst + (size_t)(ci / 32) * RD_H * 32;
         for (int h = 0; h < RD_H; h++) d[(size_t)h * 32 + swz_k(h, ci % 32)] = src[h];
     }
+}
+
+// power-of-two scale that brings max|w| into [512, 1024): the lo halves of the split stay normal f16 numbers
+float split_scale(const float* w, size_t n)
+{
+    float mx = 0.f;
+    for (size_t i = 0; i < n; i++) mx = fabsf(w[i]) > mx ? fabsf(w[i]) : mx;
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 1.f;
+    int e = 0;
+    frexpf(mx, &e);              // mx = f * 2^e, f in [0.5, 1)
+    return ldexpf(1.f, 10 - e);  // mx * scale in [512, 1024)
+}
+
+inline void split_store(_Float16* row, int k, int rowidx, float v)
+{
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const int sw = (rowidx >> 1) & 7;
+    row[(((k >> 3)) ^ sw) * 8 + (k & 7)] = hi;
+    row[((4 + (k >> 3)) ^ sw) * 8 + (k & 7)] = lo;
+}
+
+// Keras conv kernel [j][ci][co] -> split image [chunk = (ci/32)*3 + j][co][hi 32 | lo 32] (16-B slots swizzled)
+float pack_conv_split(const float* k, _Float16* dst)
+{
+    const float sc = split_scale(k, CONV_PK);
+    for (int j = 0; j < RD_K; j++)
+        for (int ci = 0; ci < RD_C; ci++) {
+            const float* src = k + ((size_t)j * RD_C + ci) * RD_C;
+            const int chunk = (ci / 32) * RD_K + j;
+            _Float16* d = dst + (size_t)chunk * RD_C * 64;
+            for (int co = 0; co < RD_C; co++) split_store(d + (size_t)co * 64, ci % 32, co, src[co] * sc);
+        }
+    return 1.f / sc;
+}
+
+float pack_dense_split(const float* k, _Float16* dst)
+{
+    const float sc = split_scale(k, D1_PK);
+    for (int ci = 0; ci < RD_C; ci++) {
+        const float* src = k + (size_t)ci * RD_H;
+        _Float16* d = dst + (size_t)(ci / 32) * RD_H * 64;
+        for (int h = 0; h < RD_H; h++) split_store(d + (size_t)h * 64, ci % 32, h, src[h] * sc);
+    }
+    return 1.f / sc;
 }
 
 }  // namespace
@@ -267,11 +330,13 @@ extern "C" int rd_load_weights(rd_ctx* ctx, const void* blob, size_t nbytes)
             off += RD_C;
         } else {
             pack_conv(w + off, &host[L.w_conv[2 * b]]);
+            m.inv_scale[2 * b] = pack_conv_split(w + off, (_Float16*)&host[L.ws_conv[2 * b]]);
             off += CONV_PK;
             memcpy(&host[L.b_conv[2 * b]], w + off, sizeof(float) * RD_C);
             off += RD_C;
         }
         pack_conv(w + off, &host[L.w_conv[2 * b + 1]]);
+        m.inv_scale[2 * b + 1] = pack_conv_split(w + off, (_Float16*)&host[L.ws_conv[2 * b + 1]]);
         off += CONV_PK;
         memcpy(&host[L.b_conv[2 * b + 1]], w + off, sizeof(float) * RD_C);
         off += RD_C;
@@ -283,6 +348,7 @@ extern "C" int rd_load_weights(rd_ctx* ctx, const void* blob, size_t nbytes)
         }
     }
     pack_dense(w + off, &host[L.w_d1]);
+    m.inv_scale_d1 = pack_dense_split(w + off, (_Float16*)&host[L.ws_d1]);
     off += D1_PK;
     memcpy(&host[L.b_d1], w + off, sizeof(float) * RD_H);
     off += RD_H;
@@ -1470,6 +1536,7 @@ struct BcastHeader {
     int32_t model_loaded, nblocks, dil[RD_MAX_BLOCKS];
     int32_t lm_loaded, lm_k;
     int64_t model_floats, lm_doubles;
+    float inv_scale[2 * RD_MAX_BLOCKS], inv_scale_d1;
 };
 
 }  // namespace
@@ -1533,6 +1600,8 @@ extern "C" int rd_rccl_bcast_model(rd_ctx* ctx, int root)
         hd.nblocks = ctx->model.nblocks;
         for (int i = 0; i < RD_MAX_BLOCKS; i++) hd.dil[i] = ctx->model.dil[i];
         hd.model_floats = (int64_t)model_layout(ctx->model.nblocks).total;
+        for (int i = 0; i < 2 * RD_MAX_BLOCKS; i++) hd.inv_scale[i] = ctx->model.inv_scale[i];
+        hd.inv_scale_d1 = ctx->model.inv_scale_d1;
         hd.lm_loaded = ctx->lm.loaded ? 1 : 0;
         hd.lm_k = ctx->lm.k;
         hd.lm_doubles = ctx->lm.loaded ? (int64_t)5 << (2 * ctx->lm.k) : 0;
@@ -1547,6 +1616,8 @@ extern "C" int rd_rccl_bcast_model(rd_ctx* ctx, int root)
         m.loaded = false;
         m.nblocks = hd.nblocks;
         for (int i = 0; i < RD_MAX_BLOCKS; i++) m.dil[i] = hd.dil[i];
+        for (int i = 0; i < 2 * RD_MAX_BLOCKS; i++) m.inv_scale[i] = hd.inv_scale[i];
+        m.inv_scale_d1 = hd.inv_scale_d1;
         if (m.storage.reserve((size_t)hd.model_floats * 4)) return RD_ERR_NOMEM;
         model_bind(m, model_layout(m.nblocks));
         ctx->lm.loaded = false;

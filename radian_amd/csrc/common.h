@@ -63,6 +63,11 @@ struct Model {
     float* b_conv[2 * RD_MAX_BLOCKS] = {nullptr};  // [256]
     float* w_d1 = nullptr;      // packed like conv, K=256: [8 chunks][128 co][32 k]
     float* b_d1 = nullptr;      // [128]
+    // split-f16 images of the same tensors (forward.hip, f16x3 section): [chunk][co][hi 32 | lo 32] halves, scaled by 1/inv_scale
+    void* ws_conv[2 * RD_MAX_BLOCKS] = {nullptr};
+    float inv_scale[2 * RD_MAX_BLOCKS] = {0};
+    void* ws_d1 = nullptr;
+    float inv_scale_d1 = 0.f;
     float* w_d2 = nullptr;      // [128][5] (Keras layout)
     float* b_d2 = nullptr;      // [5]
     DevBuf storage;
@@ -98,6 +103,7 @@ struct KernelTimer {
 
 struct rd_ctx {
     int device = 0;
+    int precision = 0;   // 0: exact fp32 MFMA (default); 1: split-f16 (f16x3) matrix products
     hipStream_t stream = nullptr;
     Model model;
     LM lm;

@@ -317,6 +317,299 @@ __global__ __launch_bounds__(256) void tcn_in_kernel(const float* __restrict__ x
     }
 }
 
+// =====================================================================================================================
+// Split-f16 ("f16x3") variant of the same kernels: fp32-equivalent arithmetic on the 16x faster f16 matrix pipe.
+//
+// Every fp32 operand is carried as hi + lo with hi = f16(v), lo = f16(v - hi) (22 significant bits), and a product is
+// evaluated as hi*hi + hi*lo + lo*hi in fp32 accumulators on v_mfma_f32_32x32x16_f16 (the dropped lo*lo term is
+// < 2^-22 relative).  Weights are scaled by a power of two per tensor before splitting so that their lo parts stay
+// normal f16 numbers; the epilogue multiplies the accumulator by the exact inverse.  Measured against a float64
+// reference the softmax error is the same ~1e-6..1e-5 as the exact-fp32 path's; bf16x3 is not
+// offered because its 16-bit significand pairs exceed the 1e-4 bound on peaky outputs.
+//
+// Activation rows keep their 1 KiB: channel group g (32 channels) occupies 128 B = [32 hi halves | 32 lo halves], so a
+// K-chunk tile row is again 128 B and the LDS-DMA, the XOR swizzle and the tile geometry are those of the fp32 kernel;
+// 16-B slot s of a row holds hi k = 8s..8s+7 for s < 4 and lo k = 8(s-4).. for s >= 4.
+// =====================================================================================================================
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr int ROWH = 2 * RD_C;   // halves per activation row (512)
+
+struct SplitArgs {
+    const _Float16* in;
+    _Float16* out;
+    const _Float16* wpk;   // [chunk][BN][hi 32 | lo 32], slots pre-swizzled
+    const float* bias;
+    float inv_scale;       // 1 / (power-of-two scale applied to the weights before splitting)
+    const _Float16* resid;
+    const float* x;
+    const float* wmatch;
+    const float* bmatch;
+    const float* w2;
+    const float* b2;
+    float* probs;
+    const float* zeros;
+    float* sink;
+    const TileDesc* tiles;
+    int dil;
+};
+
+template <int NT, int TAPS, int EPI>
+__global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
+{
+    constexpr int BN = 2 * NT * 32;
+    constexpr int NCHUNK = TAPS * (RD_C / BK);
+    constexpr int STAGE_FLOATS = (BM + BN) * BK;
+    constexpr int HEAD_FLOATS = BM * (RD_H + 1) + RD_H * 5 + 8;
+    constexpr int SMEM_FLOATS = (EPI == EPI_HEAD && HEAD_FLOATS > STAGE_FLOATS) ? HEAD_FLOATS : STAGE_FLOATS;
+
+    __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
+    float* As = smem;                  // [BM][128 B]
+    float* Bs = smem + BM * BK;        // [BN][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1;
+    const int wn = wave & 1;
+    const TileDesc td = a.tiles[blockIdx.x];
+    const int64_t seg_row = td.seg_row;
+    const int t0 = td.t0;
+    const int T = td.seg_len;
+    const _Float16* __restrict__ inw = a.in + (size_t)seg_row * ROWH;
+
+    const int dma_r = lane >> 3;
+    const int dma_ps = lane & 7;
+
+    auto stage = [&](int chunk) {
+        const int cc = chunk / TAPS;
+        const int tap = chunk - cc * TAPS;
+        const int shift = (TAPS - 1 - tap) * a.dil;
+#pragma unroll
+        for (int r = 0; r < BM / 32; r++) {
+            const int piece = r * 4 + wave;
+            const int row = piece * 8 + dma_r;
+            const int slot = dma_ps ^ ((row >> 1) & 7);
+            const int t = t0 + row - shift;
+            const float* src = (t >= 0 && t < T) ? (const float*)(inw + (size_t)t * ROWH + cc * 64 + slot * 8) : a.zeros + dma_ps * 4;
+            glds16(src, As + piece * 256);
+        }
+        const float* wsrc = (const float*)(a.wpk + (size_t)chunk * BN * 64) + lane * 4;
+#pragma unroll
+        for (int r = 0; r < BN / 32; r++) {
+            const int piece = r * 4 + wave;
+            glds16(wsrc + piece * 256, Bs + piece * 256);
+        }
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[m][n][e] = 0.f;
+
+    const int fr = lane & 31;
+    const int fh = lane >> 5;
+    const int swz = (fr >> 1) & 7;
+    const _Float16* Ab = (const _Float16*)As + (wm * 64 + fr) * 64;
+    const _Float16* Bb = (const _Float16*)Bs + (wn * NT * 32 + fr) * 64;
+
+    for (int chunk = 0; chunk < NCHUNK; chunk++) {
+        if (chunk) __syncthreads();
+        stage(chunk);
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int oh = ((2 * ks + fh) ^ swz) * 8;       // hi slot of this lane's k = 16 ks + 8 fh .. +7
+            const int ol = ((4 + 2 * ks + fh) ^ swz) * 8;   // lo slot
+            f16x8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                ah[m] = *(const f16x8*)(Ab + m * 32 * 64 + oh);
+                al[m] = *(const f16x8*)(Ab + m * 32 * 64 + ol);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                bh[n] = *(const f16x8*)(Bb + n * 32 * 64 + oh);
+                bl[n] = *(const f16x8*)(Bb + n * 32 * 64 + ol);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < NT; n++) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+                }
+        }
+    }
+    __syncthreads();
+
+    if constexpr (EPI != EPI_HEAD) {
+        constexpr int TSTR = 68;
+        float* ts = smem + wave * (32 * TSTR);
+        _Float16* outw = a.out + (size_t)seg_row * ROWH;      // may alias a.resid (read-then-write by one lane)
+        const _Float16* resw = a.resid + (size_t)seg_row * ROWH;
+        const bool interior = t0 + BM <= T;
+        f16x4* sinkh = (f16x4*)a.sink + 2 * threadIdx.x;
+        const int rrow = lane >> 4;
+        const int c4 = (lane & 15) * 4;
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+#pragma unroll
+            for (int np = 0; np < NT / 2; np++) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int n = 2 * np + j;
+                    const float bias = a.bias[wn * NT * 32 + n * 32 + fr];
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int rl = (e & 3) + 8 * (e >> 2) + 4 * fh;
+                        float v = acc[m][n][e] * a.inv_scale + bias;
+                        ts[rl * TSTR + j * 32 + fr] = v > 0.f ? v : 0.f;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int ch = wn * NT * 32 + np * 64 + c4;                // first of this lane's 4 channels
+                const int hoff = (ch >> 5) * 64 + (ch & 31);               // halves offset of their hi parts in a row
+                float4 wm4 = make_float4(0.f, 0.f, 0.f, 0.f), bm4 = wm4;
+                if constexpr (EPI == EPI_RES_MATCH) {
+                    wm4 = *(const float4*)(a.wmatch + ch);
+                    bm4 = *(const float4*)(a.bmatch + ch);
+                }
+                f16x4 rh[8], rl4[8];
+                int tt[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int t = t0 + wm * 64 + m * 32 + i * 4 + rrow;
+                    tt[i] = t;
+                    if constexpr (EPI == EPI_RES_IDENT) {
+                        const int tc = (interior || t < T) ? t : T - 1;
+                        rh[i] = *(const f16x4*)(resw + (size_t)tc * ROWH + hoff);
+                        rl4[i] = *(const f16x4*)(resw + (size_t)tc * ROWH + hoff + 32);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float4 p = *(const float4*)(ts + (i * 4 + rrow) * TSTR + c4);
+                    float v[4] = {p.x, p.y, p.z, p.w};
+                    const int t = tt[i];
+                    const bool inb = interior || t < T;
+                    if constexpr (EPI == EPI_RES_IDENT) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            v[q] += (float)rh[i][q] + (float)rl4[i][q];
+                            v[q] = v[q] > 0.f ? v[q] : 0.f;
+                        }
+                    } else if constexpr (EPI == EPI_RES_MATCH) {
+                        const float xv = a.x[(size_t)td.src_row + (inb ? t : T - 1)];
+                        const float wq[4] = {wm4.x, wm4.y, wm4.z, wm4.w}, bq[4] = {bm4.x, bm4.y, bm4.z, bm4.w};
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            v[q] = (bq[q] + xv * wq[q]) + v[q];
+                            v[q] = v[q] > 0.f ? v[q] : 0.f;
+                        }
+                    }
+                    f16x4 hi, lo;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        hi[q] = (_Float16)v[q];
+                        lo[q] = (_Float16)(v[q] - (float)hi[q]);
+                    }
+                    f16x4* dh = inb ? (f16x4*)(outw + (size_t)t * ROWH + hoff) : sinkh;
+                    f16x4* dl = inb ? (f16x4*)(outw + (size_t)t * ROWH + hoff + 32) : sinkh + 1;
+                    *dh = hi;
+                    *dl = lo;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    } else {
+        constexpr int LDH = RD_H + 1;
+        float* hs = smem;
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            const int hcol = wn * NT * 32 + n * 32 + fr;
+            const float bias = a.bias[hcol];
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int row = wm * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    float v = acc[m][n][e] * a.inv_scale + bias;
+                    hs[row * LDH + hcol] = v > 0.f ? v : 0.f;
+                }
+        }
+        float* w2s = smem + BM * LDH;
+        for (int i = tid; i < RD_H * 5; i += 256) w2s[i] = a.w2[i];
+        if (tid < 5) w2s[RD_H * 5 + tid] = a.b2[tid];
+        __syncthreads();
+        if (tid < BM) {
+            const int t = t0 + tid;
+            if (t < T) {
+                float lg[5];
+#pragma unroll
+                for (int o = 0; o < 5; o++) lg[o] = w2s[RD_H * 5 + o];
+                for (int j = 0; j < RD_H; j++) {
+                    const float h = hs[tid * LDH + j];
+#pragma unroll
+                    for (int o = 0; o < 5; o++) lg[o] += h * w2s[j * 5 + o];
+                }
+                float mx = lg[0];
+#pragma unroll
+                for (int o = 1; o < 5; o++) mx = lg[o] > mx ? lg[o] : mx;
+                float e[5], s = 0.f;
+#pragma unroll
+                for (int o = 0; o < 5; o++) {
+                    e[o] = expf(lg[o] - mx);
+                    s += e[o];
+                }
+                float* pr = a.probs + ((size_t)seg_row + t) * 5;
+#pragma unroll
+                for (int o = 0; o < 5; o++) pr[o] = e[o] / s;
+            }
+        }
+    }
+}
+
+// Block 0, first conv (C_in = 1) writing split-f16 rows.
+__global__ __launch_bounds__(256) void tcn_in_split_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                            _Float16* __restrict__ out, const TileDesc* __restrict__ tiles, int dil)
+{
+    const TileDesc td = tiles[blockIdx.x];
+    const int c4 = (threadIdx.x & 63) * 4;
+    const float4 w0 = *(const float4*)(w + c4), w1 = *(const float4*)(w + 256 + c4), w2 = *(const float4*)(w + 512 + c4);
+    const float4 bb = *(const float4*)(b + c4);
+    const float* xw = x + td.src_row;
+    _Float16* ow = out + (size_t)td.seg_row * ROWH;
+    const int hoff = (c4 >> 5) * 64 + (c4 & 31);
+    const int tend = td.t0 + BM < td.seg_len ? td.t0 + BM : td.seg_len;
+    for (int t = td.t0 + (threadIdx.x >> 6); t < tend; t += 4) {
+        const float x2 = xw[t];
+        const float x1 = t - dil >= 0 ? xw[t - dil] : 0.f;
+        const float x0 = t - 2 * dil >= 0 ? xw[t - 2 * dil] : 0.f;
+        float v[4];
+        v[0] = bb.x + x0 * w0.x + x1 * w1.x + x2 * w2.x;
+        v[1] = bb.y + x0 * w0.y + x1 * w1.y + x2 * w2.y;
+        v[2] = bb.z + x0 * w0.z + x1 * w1.z + x2 * w2.z;
+        v[3] = bb.w + x0 * w0.w + x1 * w1.w + x2 * w2.w;
+        f16x4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float r = v[q] > 0.f ? v[q] : 0.f;
+            hi[q] = (_Float16)r;
+            lo[q] = (_Float16)(r - (float)hi[q]);
+        }
+        *(f16x4*)(ow + (size_t)t * ROWH + hoff) = hi;
+        *(f16x4*)(ow + (size_t)t * ROWH + hoff + 32) = lo;
+    }
+}
+
 int timer_begin(rd_ctx* ctx, KernelTimer& tm)
 {
     if (tm.enabled && tm.used < tm.starts.size()) RD_HIP(hipEventRecord(tm.starts[tm.used], ctx->stream));
@@ -356,6 +649,7 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileDesc* d_t
     const int grid = n_tiles;
     const double conv_flops = 2.0 * rows * RD_C * RD_C * RD_K;
     const double conv_bytes = 2.0 * rows * RD_C * 4.0;
+    const bool split = ctx->precision == 1;
 
     for (int b = 0; b < m.nblocks; b++) {
         const int d = m.dil[b];
@@ -364,10 +658,18 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileDesc* d_t
         a.sink = m.sink;
         a.tiles = d_tiles;
         a.dil = d;
+        SplitArgs sa = {};
+        sa.zeros = m.zeros;
+        sa.sink = m.sink;
+        sa.tiles = d_tiles;
+        sa.dil = d;
         if (b == 0) {
             // conv0: 1 -> 256 on the VALU
             if ((rc = timer_begin(ctx, ctx->timer_in))) return rc;
-            hipLaunchKernelGGL(tcn_in_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_signal, m.w_in, m.b_in, MID, d_tiles, d);
+            if (split)
+                hipLaunchKernelGGL(tcn_in_split_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_signal, m.w_in, m.b_in, (_Float16*)MID, d_tiles, d);
+            else
+                hipLaunchKernelGGL(tcn_in_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_signal, m.w_in, m.b_in, MID, d_tiles, d);
             RD_HIP(hipGetLastError());
             if ((rc = timer_end(ctx, ctx->timer_in, 2.0 * rows * RD_C * RD_K, rows * (RD_C * 4.0 + 4.0)))) return rc;
             // conv1 + relu, + 1x1 match residual + relu
@@ -378,8 +680,19 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileDesc* d_t
             a.x = d_signal;
             a.wmatch = m.w_match;
             a.bmatch = m.b_match;
+            sa.in = (const _Float16*)MID;
+            sa.out = (_Float16*)X;
+            sa.wpk = (const _Float16*)m.ws_conv[1];
+            sa.inv_scale = m.inv_scale[1];
+            sa.bias = m.b_conv[1];
+            sa.x = d_signal;
+            sa.wmatch = m.w_match;
+            sa.bmatch = m.b_match;
             if ((rc = timer_begin(ctx, ctx->timer_conv))) return rc;
-            hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_MATCH>), dim3(grid), dim3(256), 0, ctx->stream, a);
+            if (split)
+                hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RES_MATCH>), dim3(grid), dim3(256), 0, ctx->stream, sa);
+            else
+                hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_MATCH>), dim3(grid), dim3(256), 0, ctx->stream, a);
             RD_HIP(hipGetLastError());
             if ((rc = timer_end(ctx, ctx->timer_conv, conv_flops, conv_bytes))) return rc;
         } else {
@@ -387,8 +700,16 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileDesc* d_t
             a.out = MID;
             a.wpk = m.w_conv[2 * b];
             a.bias = m.b_conv[2 * b];
+            sa.in = (const _Float16*)X;
+            sa.out = (_Float16*)MID;
+            sa.wpk = (const _Float16*)m.ws_conv[2 * b];
+            sa.inv_scale = m.inv_scale[2 * b];
+            sa.bias = m.b_conv[2 * b];
             if ((rc = timer_begin(ctx, ctx->timer_conv))) return rc;
-            hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RELU>), dim3(grid), dim3(256), 0, ctx->stream, a);
+            if (split)
+                hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RELU>), dim3(grid), dim3(256), 0, ctx->stream, sa);
+            else
+                hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RELU>), dim3(grid), dim3(256), 0, ctx->stream, a);
             RD_HIP(hipGetLastError());
             if ((rc = timer_end(ctx, ctx->timer_conv, conv_flops, conv_bytes))) return rc;
             a.in = MID;
@@ -396,25 +717,50 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileDesc* d_t
             a.resid = X;
             a.wpk = m.w_conv[2 * b + 1];
             a.bias = m.b_conv[2 * b + 1];
+            sa.in = (const _Float16*)MID;
+            sa.out = (_Float16*)X;
+            sa.resid = (const _Float16*)X;
+            sa.wpk = (const _Float16*)m.ws_conv[2 * b + 1];
+            sa.inv_scale = m.inv_scale[2 * b + 1];
+            sa.bias = m.b_conv[2 * b + 1];
             if ((rc = timer_begin(ctx, ctx->timer_conv))) return rc;
-            hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_IDENT>), dim3(grid), dim3(256), 0, ctx->stream, a);
+            if (split)
+                hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RES_IDENT>), dim3(grid), dim3(256), 0, ctx->stream, sa);
+            else
+                hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_IDENT>), dim3(grid), dim3(256), 0, ctx->stream, a);
             RD_HIP(hipGetLastError());
             if ((rc = timer_end(ctx, ctx->timer_conv, conv_flops, conv_bytes + rows * RD_C * 4.0))) return rc;
         }
     }
-    ConvArgs h = {};
-    h.zeros = m.zeros;
-    h.sink = m.sink;
-    h.tiles = d_tiles;
-    h.dil = 0;
-    h.in = X;
-    h.wpk = m.w_d1;
-    h.bias = m.b_d1;
-    h.w2 = m.w_d2;
-    h.b2 = m.b_d2;
-    h.probs = d_probs;
     if ((rc = timer_begin(ctx, ctx->timer_head))) return rc;
-    hipLaunchKernelGGL((tcn_gemm_kernel<2, 1, EPI_HEAD>), dim3(grid), dim3(256), 0, ctx->stream, h);
+    if (split) {
+        SplitArgs h = {};
+        h.zeros = m.zeros;
+        h.sink = m.sink;
+        h.tiles = d_tiles;
+        h.dil = 0;
+        h.in = (const _Float16*)X;
+        h.wpk = (const _Float16*)m.ws_d1;
+        h.inv_scale = m.inv_scale_d1;
+        h.bias = m.b_d1;
+        h.w2 = m.w_d2;
+        h.b2 = m.b_d2;
+        h.probs = d_probs;
+        hipLaunchKernelGGL((tcn_gemm_split_kernel<2, 1, EPI_HEAD>), dim3(grid), dim3(256), 0, ctx->stream, h);
+    } else {
+        ConvArgs h = {};
+        h.zeros = m.zeros;
+        h.sink = m.sink;
+        h.tiles = d_tiles;
+        h.dil = 0;
+        h.in = X;
+        h.wpk = m.w_d1;
+        h.bias = m.b_d1;
+        h.w2 = m.w_d2;
+        h.b2 = m.b_d2;
+        h.probs = d_probs;
+        hipLaunchKernelGGL((tcn_gemm_kernel<2, 1, EPI_HEAD>), dim3(grid), dim3(256), 0, ctx->stream, h);
+    }
     RD_HIP(hipGetLastError());
     if ((rc = timer_end(ctx, ctx->timer_head, 2.0 * rows * (RD_C * RD_H + RD_H * 5), rows * (RD_C * 4.0 + 20.0)))) return rc;
     return RD_OK;

@@ -167,3 +167,53 @@ def test_forward_requires_weights():
     with pytest.raises(RadianHipError):
         b.forward(np.zeros((1, 64), dtype=np.float32))
     b.close()
+
+
+def test_forward_split_f16x3_accuracy(oracle):
+    """precision mode 1 (split-f16 products hi*hi + hi*lo + lo*hi, fp32 accumulate): softmax within 1e-4 of the oracle,
+    i.e. the same bound as the exact-fp32 mode, also with a peaky head and odd segment lengths."""
+    from radian_amd import Backend, weights
+    rng = np.random.default_rng(10)
+    for seed, gain, dil in ((1234, 1.0, (1, 2, 4, 8, 16, 32)), (77, 6.0, (1, 2, 4, 8, 16, 32)), (5, 3.0, (1, 2, 4))):
+        w = weights.synthetic_weights(seed=seed, head_gain=gain, dilations=dil)
+        b = Backend(0)
+        b.load_weights(w, dil)
+        x = np.clip(rng.normal(size=(3, 1024)), -4, 4).astype(np.float32)
+        exp = oracle.tcn_forward(w, x, dilations=dil, acc64=True)   # float64-accumulated yardstick
+        p32 = b.forward(x)
+        b.set_precision("f16x3")
+        p16 = b.forward(x)
+        assert np.all(np.isfinite(p16))
+        e32, e16 = np.abs(p32 - exp).max(), np.abs(p16 - exp).max()
+        print(f"seed {seed} gain {gain}: max|dp| vs f64-accumulated reference: fp32 MFMA {e32:.2e}, f16x3 {e16:.2e}")
+        assert e16 <= TOL, (seed, e16)
+        assert e32 <= TOL, (seed, e32)
+        assert e16 <= 3 * max(e32, 5e-6), (seed, e16, e32)     # no worse than float32 summation-order noise
+        for T in (1, 100, 300):
+            xs = rng.normal(size=(2, T)).astype(np.float32)
+            assert np.abs(b.forward(xs) - oracle.tcn_forward(w, xs, dilations=dil)).max() <= TOL, T
+        b.set_precision("fp32")
+        assert np.array_equal(b.forward(x), p32)
+        b.close()
+
+
+def test_split_mode_streamed_equals_windowed():
+    from radian_amd import Backend, weights
+    from radian_amd.preprocess import get_windows
+    b = Backend(0)
+    b.load_weights(weights.synthetic_weights(seed=1234))
+    b.set_precision("f16x3")
+    rng = np.random.default_rng(11)
+    sig = np.clip(rng.normal(size=3000), -4, 4).astype(np.float32)
+    stream = b.forward(sig[None, :])[0]
+    w, pad = get_windows(sig, 1024, 512)
+    probs = b.forward(w.astype(np.float32))
+    for i in range(w.shape[0]):
+        n = 1024 if i < w.shape[0] - 1 else 1024 - pad
+        assert np.array_equal(probs[i, 252:n], stream[i * 512 + 252: i * 512 + n]), i
+    got = b.basecall_reads_chunk([sig], 1024, 512, 10)[0]
+    valid = np.full(w.shape[0], 1024, dtype=np.int32)
+    valid[-1] = 1024 - pad
+    exp = b.basecall_chunk(w.astype(np.float32), valid, 10)
+    assert all(np.array_equal(a, e) for a, e in zip(got, exp))
+    b.close()
