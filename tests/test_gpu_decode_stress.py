@@ -1,0 +1,108 @@
+"""Randomised GPU-vs-oracle beam-search comparison at scale: thousands of sequences over distribution shapes that stress
+beam pruning and re-entry (a labeling leaves the top-W and is re-created later: the trie reload path), ties and zeros."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    from radian_amd import Backend
+    b = Backend(0)
+    yield b
+    b.close()
+
+
+def _mats(rng, n_seq, tmax, kind, dtype):
+    lens = rng.integers(1, tmax + 1, size=n_seq)
+    rows = []
+    for n in lens:
+        z = rng.normal(size=(n, 5))
+        if kind == "flat":
+            z *= 0.3
+        elif kind == "peaky":
+            z *= 4.0
+            z[:, 4] += 2.0
+        elif kind == "blocky":  # long runs of the same dominant class, then switches: many merges / re-entries
+            dom = np.repeat(rng.integers(0, 5, size=n // 7 + 1), 7)[:n]
+            z *= 0.8
+            z[np.arange(n), dom] += 2.5
+        elif kind == "quant":   # probabilities on a coarse grid: exact ties everywhere
+            p = rng.integers(0, 4, size=(n, 5)).astype(np.float64) + (rng.random((n, 1)) < 0.5)
+            p[:, 4] += 1
+            p /= p.sum(axis=1, keepdims=True)
+            rows.append(p.astype(dtype))
+            continue
+        z -= z.max(axis=1, keepdims=True)
+        e = np.exp(z)
+        rows.append((e / e.sum(axis=1, keepdims=True)).astype(dtype))
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    return np.concatenate(rows, axis=0), off, lens.astype(np.int32)
+
+
+@pytest.mark.parametrize("kind", ["flat", "peaky", "blocky", "quant"])
+def test_random_batches_match_oracle(be, oracle, kind):
+    rng = np.random.default_rng(hash(kind) % 1000)
+    for dtype in (np.float32, np.float64):
+        mats, off, lens = _mats(rng, 600, 300, kind, dtype)
+        for W in (1, 2, 3, 6, 10, 25):
+            got = be.decode_batch(mats, off, lens, W)
+            exp = oracle.beam_search_batch(mats, off, lens, W)
+            bad = [i for i in range(len(lens)) if not np.array_equal(got[i], exp[i])]
+            if kind != "quant":
+                assert not bad, (kind, dtype.__name__, W, bad[:5], len(bad))
+                continue
+            # Probabilities on a coarse rational grid make different labelings EXACTLY equiprobable; the reference then
+            # orders them by the last-ulp rounding of glibc's log/log1p/exp, which ROCm's device functions do not
+            # reproduce bit for bit.  Such a sequence may differ, but only from a step at which two of the oracle's
+            # leading beams are within a few ulp of each other -- anything else is a bug.
+            assert len(bad) <= 0.03 * len(lens), (W, len(bad))
+            for i in bad[:6]:
+                m = mats[off[i]:off[i] + lens[i]]
+                n = len(m)
+                pref = be.decode_batch(m, np.zeros(n, dtype=np.int64), np.arange(1, n + 1, dtype=np.int32), W)
+                first = next(t for t in range(n) if not np.array_equal(pref[t], oracle.beam_search_labels(m[:t + 1], W)[0]))
+                # the beam SETS may have parted earlier than the best labeling shows: look for a few-ulp tie among the
+                # entries around the pruning boundary (the first W+1 of the sorted list) at any step up to `first`
+                best_gap = np.inf
+                for t in range(first + 1):
+                    _, fin = oracle.beam_search_labels(m[:t + 1], W, max_final=W + 2)
+                    tots = [f[1] for f in fin if np.isfinite(f[1])]
+                    for j in range(len(tots) - 1):
+                        best_gap = min(best_gap, abs(tots[j] - tots[j + 1]) / max(1.0, abs(tots[j])))
+                assert best_gap <= 8 * np.finfo(np.float64).eps, (W, i, first, best_gap)
+
+
+def test_random_batches_with_lm_match_oracle(be, oracle):
+    rng = np.random.default_rng(77)
+    for k in (1, 2, 4):
+        table = rng.dirichlet([0.2] * 4, size=4 ** k)
+        be.load_lm(table, k)
+        for kind in ("flat", "blocky"):
+            mats, off, lens = _mats(rng, 300, 250, kind, np.float64)
+            for W, s_thr, r_thr in ((2, 0.5, 0.5), (6, 0.0, 2.0), (10, 0.8, 0.9)):
+                got = be.decode_batch(mats, off, lens, W, use_lm=True, s_threshold=s_thr, r_threshold=r_thr)
+                exp = oracle.beam_search_batch(mats, off, lens, W, table, s_thr, r_thr, k)
+                bad = [i for i in range(len(lens)) if not np.array_equal(got[i], exp[i])]
+                assert not bad, (k, kind, W, bad[:5], len(bad))
+    be.load_lm(None, 0)
+
+
+def test_long_global_sequences_match_oracle(be, oracle):
+    """read-length sequences (the 12.8k-sample read of data/reads.fast5 is the longest in the sample file)"""
+    rng = np.random.default_rng(5)
+    mats, off, lens = _mats(rng, 6, 13000, "peaky", np.float64)
+    lens[:] = [12833, 4863, 11388, 14799 % 13000 + 1, 9905, 13000]
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    tot = int(lens.sum())
+    z = rng.normal(size=(tot, 5)) * 3.0
+    z[:, 4] += 1.5
+    z -= z.max(axis=1, keepdims=True)
+    e = np.exp(z)
+    mats = e / e.sum(axis=1, keepdims=True)
+    for W in (6, 10):
+        got = be.decode_batch(mats, off, lens, W)
+        exp = oracle.beam_search_batch(mats, off, lens, W)
+        for i in range(len(lens)):
+            assert np.array_equal(got[i], exp[i]), (W, i)
