@@ -44,7 +44,8 @@ def build_parser():
     # extensions
     parser.add_argument("--device", default=0, type=int, help="GPU index (single-process run)")
     parser.add_argument("--gpus", default=1, type=int, help="shard reads over this many GPUs (one process each)")
-    parser.add_argument("--gpu-batch-windows", default=512, type=int, help="windows per device batch (across reads)")
+    parser.add_argument("--gpu-batch-windows", default=4096, type=int,
+                        help="device batch size across reads, in windows (chunk mode) or chunk_len-row units (global mode)")
     return parser
 
 
@@ -111,23 +112,32 @@ def report_skipped(read_id, status):
     print(f"{read_id} signal issue, skipping this read.")
 
 
-def basecall_batch(be, batch, args, use_lm):
-    """batch: list of (read_id, raw int16 signal).  Returns (sequences un-reversed, status per read).  Raw reads go to
-    the device: MAD normalisation, windowing, forward (every time step evaluated once), assembly and beam search run
-    there; only the chunk-mode string stitch (basecall.py:122-123) is host work."""
+def device_batch(be, batch, args, use_lm):
+    """batch: list of (read_id, raw int16 signal).  Raw reads go to the device: MAD normalisation, windowing, forward
+    (every time step evaluated once), assembly and beam search run there.  Returns (label arrays, status per read):
+    chunk mode -> per read the list of per-window fragments, global mode -> per read one labeling."""
     raws = [raw for _, raw in batch]
     if args.decode_type == "global":
-        labels, status = be.basecall_raw_global(raws, args.outlier_clip, args.chunk_len, args.step_size, args.beam_width, use_lm,
-                                                args.sig_threshold, args.rna_threshold)
-        return [labels_to_str(l) for l in labels], status
-    frags, status = be.basecall_raw_chunk(raws, args.outlier_clip, args.chunk_len, args.step_size, args.beam_width)
-    return [consensus_sequence([labels_to_str(f) for f in fr]) for fr in frags], status
+        return be.basecall_raw_global(raws, args.outlier_clip, args.chunk_len, args.step_size, args.beam_width, use_lm,
+                                      args.sig_threshold, args.rna_threshold)
+    return be.basecall_raw_chunk(raws, args.outlier_clip, args.chunk_len, args.step_size, args.beam_width)
+
+
+def host_finish(labels, args):
+    """labels of one read -> its (un-reversed) sequence; chunk mode stitches the fragments (basecall.py:122-123)."""
+    if args.decode_type == "global":
+        return labels_to_str(labels)
+    return consensus_sequence([labels_to_str(f) for f in labels])
 
 
 def run(args, be, reads=None, writer=None, shard=(0, 1)):
     """The driver loop (basecall.py:69-141) over `reads` (default: every read under args.fast5_dir).
     shard=(rank, world): this process handles reads whose index % world == rank and returns
-    [(read_index, read_id, sequence)] instead of writing when writer is None."""
+    [(read_index, read_id, sequence)] instead of writing when writer is None.
+    Three stages run concurrently, each on its own thread and all in input order: reading/batching reads (HDF5 through
+    ctypes), the device call of a batch, and the host work on its results (string stitch, FASTA write).  The two ctypes
+    stages release the GIL."""
+    from concurrent.futures import ThreadPoolExecutor
     if reads is None:
         reads = fast5.iter_directory(args.fast5_dir)
     if args.step_size <= 0:
@@ -138,39 +148,66 @@ def run(args, be, reads=None, writer=None, shard=(0, 1)):
     rank, world = shard
     results = []
     batch, batch_idx, n_win = [], [], 0
+    dev_pool = ThreadPoolExecutor(max_workers=1)    # one device call at a time (an rd_ctx is not thread-safe)
+    pool = ThreadPoolExecutor(max_workers=1)        # host post-processing, in order
+    pending = []
+
+    def finish(b, b_idx, labels, status, dur):
+        for (rid, _), idx, lab, st in zip(b, b_idx, labels, status):
+            if st != 0:
+                report_skipped(rid, st)
+                continue
+            seq = host_finish(lab, args)
+            if writer is not None:
+                writer.write(rid, seq)
+            results.append((idx, rid, seq))
+            print(f"Basecalled read {rid} in {dur:.2f} sec.")
 
     def flush():
         nonlocal batch, batch_idx, n_win
         if not batch:
             return
-        t0 = time()
-        seqs, status = basecall_batch(be, batch, args, use_lm)
-        dur = (time() - t0) / len(batch)
-        for (rid, _), idx, seq, st in zip(batch, batch_idx, seqs, status):
-            if st != 0:
-                report_skipped(rid, st)
-                continue
-            if writer is not None:
-                writer.write(rid, seq)
-            results.append((idx, rid, seq))
-            print(f"Basecalled read {rid} in {dur:.2f} sec.")
+        b, b_idx = batch, batch_idx
+
+        def on_device():
+            t0 = time()
+            labels, status = device_batch(be, b, args, use_lm)
+            dur = (time() - t0) / len(b)
+            return pool.submit(finish, b, b_idx, labels, status, dur)
+
+        pending.append(dev_pool.submit(on_device))
+        while len(pending) > 2:
+            pending.pop(0).result().result()     # bounded backlog; re-raises device- and host-side errors
         batch, batch_idx, n_win = [], [], 0
 
-    for idx, read in enumerate(reads):
-        if idx % world != rank:
-            continue
-        raw = np.asarray(read.get_raw_data())
-        n = raw.shape[0]
-        if n == 0:
-            report_skipped(read.read_id, 2)
-            continue
-        nw = (0 if n < args.chunk_len else (n - args.chunk_len) // args.step_size + 1) + 1
-        if batch and n_win + nw > args.gpu_batch_windows:
-            flush()
-        batch.append((read.read_id, raw))
-        batch_idx.append(idx)
-        n_win += nw
-    flush()
+    try:
+        for idx, read in enumerate(reads):
+            if idx % world != rank:
+                continue
+            raw = np.asarray(read.get_raw_data())
+            n = raw.shape[0]
+            if n == 0:
+                flush()                  # keep the reference's message order
+                for f in pending:
+                    f.result().result()
+                pending.clear()
+                report_skipped(read.read_id, 2)
+                continue
+            if args.decode_type == "chunk":
+                nw = (0 if n < args.chunk_len else (n - args.chunk_len) // args.step_size + 1) + 1   # windows decoded
+            else:
+                nw = -(-n // args.chunk_len)   # global: the device evaluates N rows and decodes one sequence per read
+            if batch and n_win + nw > args.gpu_batch_windows:
+                flush()
+            batch.append((read.read_id, raw))
+            batch_idx.append(idx)
+            n_win += nw
+        flush()
+        for f in pending:
+            f.result().result()
+    finally:
+        dev_pool.shutdown(wait=True)
+        pool.shutdown(wait=True)
     return results
 
 
