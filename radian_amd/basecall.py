@@ -44,6 +44,8 @@ def build_parser():
     # extensions
     parser.add_argument("--device", default=0, type=int, help="GPU index (single-process run)")
     parser.add_argument("--gpus", default=1, type=int, help="shard reads over this many GPUs (one process each)")
+    parser.add_argument("--device-contexts", default=2, type=int,
+                        help="independent device contexts (streams) per GPU: batch i+1's forward overlaps batch i's beam search")
     parser.add_argument("--gpu-batch-windows", default=4096, type=int,
                         help="device batch size across reads, in windows (chunk mode) or chunk_len-row units (global mode)")
     return parser
@@ -134,10 +136,12 @@ def run(args, be, reads=None, writer=None, shard=(0, 1)):
     """The driver loop (basecall.py:69-141) over `reads` (default: every read under args.fast5_dir).
     shard=(rank, world): this process handles reads whose index % world == rank and returns
     [(read_index, read_id, sequence)] instead of writing when writer is None.
-    Three stages run concurrently, each on its own thread and all in input order: reading/batching reads (HDF5 through
-    ctypes), the device call of a batch, and the host work on its results (string stitch, FASTA write).  The two ctypes
-    stages release the GIL."""
+    `be` is one Backend or a list of Backends on the same GPU (independent rd_ctx / HIP streams): batches go to them
+    round robin on one thread each, so the MFMA-bound forward of one batch overlaps the latency-bound beam search of
+    the previous one.  Reading/batching (HDF5 through ctypes), the device calls and the host work on the results
+    (string stitch, FASTA write) run concurrently; output order is the input order."""
     from concurrent.futures import ThreadPoolExecutor
+    backends = list(be) if isinstance(be, (list, tuple)) else [be]
     if reads is None:
         reads = fast5.iter_directory(args.fast5_dir)
     if args.step_size <= 0:
@@ -148,9 +152,10 @@ def run(args, be, reads=None, writer=None, shard=(0, 1)):
     rank, world = shard
     results = []
     batch, batch_idx, n_win = [], [], 0
-    dev_pool = ThreadPoolExecutor(max_workers=1)    # one device call at a time (an rd_ctx is not thread-safe)
-    pool = ThreadPoolExecutor(max_workers=1)        # host post-processing, in order
-    pending = []
+    dev_pools = [ThreadPoolExecutor(max_workers=1) for _ in backends]   # an rd_ctx is not thread-safe: one thread each
+    host_pool = ThreadPoolExecutor(max_workers=1)                        # host post-processing, strictly in order
+    in_flight, finishing = [], []
+    n_submitted = 0
 
     def finish(b, b_idx, labels, status, dur):
         for (rid, _), idx, lab, st in zip(b, b_idx, labels, status):
@@ -163,22 +168,35 @@ def run(args, be, reads=None, writer=None, shard=(0, 1)):
             results.append((idx, rid, seq))
             print(f"Basecalled read {rid} in {dur:.2f} sec.")
 
+    def on_device(backend, b):
+        t0 = time()
+        labels, status = device_batch(backend, b, args, use_lm)
+        return labels, status, (time() - t0) / len(b)
+
+    def retire(keep):
+        """hand the oldest device results to the host stage (in submission order) until `keep` batches are in flight"""
+        while len(in_flight) > keep:
+            fut, b, b_idx = in_flight.pop(0)
+            labels, status, dur = fut.result()          # re-raises device-side errors
+            finishing.append(host_pool.submit(finish, b, b_idx, labels, status, dur))
+            while len(finishing) > 2:
+                finishing.pop(0).result()               # re-raises host-side errors
+
     def flush():
-        nonlocal batch, batch_idx, n_win
+        nonlocal batch, batch_idx, n_win, n_submitted
         if not batch:
             return
-        b, b_idx = batch, batch_idx
-
-        def on_device():
-            t0 = time()
-            labels, status = device_batch(be, b, args, use_lm)
-            dur = (time() - t0) / len(b)
-            return pool.submit(finish, b, b_idx, labels, status, dur)
-
-        pending.append(dev_pool.submit(on_device))
-        while len(pending) > 2:
-            pending.pop(0).result().result()     # bounded backlog; re-raises device- and host-side errors
+        k = n_submitted % len(backends)
+        n_submitted += 1
+        in_flight.append((dev_pools[k].submit(on_device, backends[k], batch), batch, batch_idx))
+        retire(len(backends))
         batch, batch_idx, n_win = [], [], 0
+
+    def drain():
+        retire(0)
+        for f in finishing:
+            f.result()
+        finishing.clear()
 
     try:
         for idx, read in enumerate(reads):
@@ -188,9 +206,7 @@ def run(args, be, reads=None, writer=None, shard=(0, 1)):
             n = raw.shape[0]
             if n == 0:
                 flush()                  # keep the reference's message order
-                for f in pending:
-                    f.result().result()
-                pending.clear()
+                drain()
                 report_skipped(read.read_id, 2)
                 continue
             if args.decode_type == "chunk":
@@ -203,11 +219,11 @@ def run(args, be, reads=None, writer=None, shard=(0, 1)):
             batch_idx.append(idx)
             n_win += nw
         flush()
-        for f in pending:
-            f.result().result()
+        drain()
     finally:
-        dev_pool.shutdown(wait=True)
-        pool.shutdown(wait=True)
+        for p in dev_pools:
+            p.shutdown(wait=True)
+        host_pool.shutdown(wait=True)
     return results
 
 
@@ -235,14 +251,16 @@ def main(argv=None):
         from .launch import run_multi_gpu
         return run_multi_gpu(args, argv if argv is not None else sys.argv[1:])
     from .backend import Backend
-    be = Backend(args.device)
-    setup_backend(args, be)
+    bes = [Backend(args.device) for _ in range(max(1, args.device_contexts))]
+    for b in bes:
+        setup_backend(args, b)
     writer = FastaWriter(args.fasta_dir)
     try:
-        run(args, be, writer=writer)
+        run(args, bes, writer=writer)
     finally:
         writer.close()  # basecall.py:141
-        be.close()
+        for b in bes:
+            b.close()
 
 
 if __name__ == "__main__":
