@@ -43,10 +43,12 @@ def test_stream_rows_equal_window_rows_bitwise(be):
     assert not np.array_equal(probs[1, :halo], stream[512: 512 + halo])
 
 
-@pytest.mark.parametrize("chunk,step", [(1024, 512), (1024, 128), (1024, 1024), (1024, 900), (300, 100), (256, 256)])
+@pytest.mark.parametrize("chunk,step", [(1024, 512), (1024, 128), (1024, 1024), (1024, 900), (300, 100), (256, 256), (128, 64), (200, 7)])
 def test_reads_chunk_equals_windowed(be, chunk, step):
     rng = np.random.default_rng(chunk * 7 + step)
     lengths = [4096, 700, chunk, chunk + step, chunk + 3 * step + 17, 1, 2500, chunk - 1, chunk + 1]
+    if step < 50:
+        lengths = [1500, 700, chunk, chunk + step, 1, chunk + 1]   # keep the window count of tiny steps moderate
     sigs = _reads(rng, lengths)
     W = 10
     got = be.basecall_reads_chunk(sigs, chunk, step, W)
@@ -59,7 +61,7 @@ def test_reads_chunk_equals_windowed(be, chunk, step):
             assert np.array_equal(got[r][i], exp[i]), (r, i, lengths[r])
 
 
-@pytest.mark.parametrize("chunk,step", [(1024, 512), (1024, 128), (1024, 772), (1024, 773), (1024, 1024), (300, 40)])
+@pytest.mark.parametrize("chunk,step", [(1024, 512), (1024, 128), (1024, 772), (1024, 773), (1024, 1024), (300, 40), (128, 64), (4096, 2048)])
 def test_reads_global_equals_windowed(be, chunk, step):
     rng = np.random.default_rng(chunk + step)
     k = 3
@@ -177,3 +179,16 @@ def test_raw_paths_equal_normalised_paths(be):
     exp = be.basecall_reads_global([mad_normalise(reads[i], 4).astype(np.float32) for i in good], 1024, 128, 6, False)
     for j, i in enumerate(good):
         assert np.array_equal(labs[i], exp[j])
+
+
+def test_long_read_global_streamed(be, oracle):
+    """a 60k-sample read through the reads-level global path (469 windows at step 128 in the reference; one stream here)
+    against the oracle's assembly + decode of the windowed GPU probabilities"""
+    rng = np.random.default_rng(21)
+    sig = _reads(rng, [60000])[0]
+    got = be.basecall_reads_global([sig], 1024, 128, 6, False)[0]
+    w, valid, pad = _windows(sig, 1024, 128)
+    probs = be.forward(w)
+    mat = oracle.assemble_matrices(probs, pad, 128)
+    exp, _ = oracle.beam_search_labels(mat, 6)
+    assert mat.shape[0] == 60000 and np.array_equal(got, exp)
