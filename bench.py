@@ -180,9 +180,11 @@ def main():
     # reference as the fp32-MFMA mode (tests/test_gpu_forward.py::test_forward_split_f16x3_accuracy)
     secondary = None
     if args.precision == "fp32" and not args.no_secondary and not args.windowed:
-        be.set_precision("f16x3")
-        el2 = timed(submit)
-        be.set_precision("fp32")
+        try:
+            be.set_precision("f16x3")
+            el2 = timed(submit)
+        finally:
+            be.set_precision("fp32")
         secondary = {"precision": "f16x3 split products (3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate)",
                      "value": world * args.steps * samples_per_step / el2, "unit": "samples/s",
                      "ms_per_step": el2 / args.steps * 1e3,
@@ -234,7 +236,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             ncores = os.cpu_count() or 1
             nr = args.cpu_reads or max(2, min(reads_per_batch, ncores // 4))   # ~10-30 s of CPU work, all cores busy
-            cpu = cpu_baseline(batches[0][2][: nr * 8], batches[0][1][: nr * 8], nr)
+            try:
+                cpu = cpu_baseline(batches[0][2][: nr * 8], batches[0][1][: nr * 8], nr)
+            except Exception as e:   # the oracle is test infrastructure: its absence must not cost the GPU line
+                print(f"[bench] cpu_baseline unavailable: {e}", file=sys.stderr)
+                cpu = None
 
     if rank == 0:
         out = {
