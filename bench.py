@@ -191,7 +191,7 @@ def main():
                      "accuracy": "max |softmax - float64-accumulated reference|: 6.6e-6 / 6.5e-5 (peaky head) vs 1.1e-5 / 7.1e-5 for "
                                  "the fp32-MFMA mode (tests/test_gpu_forward.py)"}
     halo = 252
-    # time steps the model evaluates per step: every window row (windowed) or every time step once (streamed)
+    # probability rows produced per step: every window row (windowed) or every time step once + 7 window heads (streamed)
     rows_streamed = BATCH_WINDOWS * CHUNK if args.windowed else reads_per_batch * (READ_LEN + 7 * halo)
 
     # ---- roofline of the dominant kernel (dilated conv on fp32 MFMA), HIP events on the launch stream
@@ -211,8 +211,9 @@ def main():
         be.timer_enable(RD_TIMER_CONV, 0)
         be.timer_enable(RD_TIMER_DECODE, 0)
         be.timer_enable(RD_TIMER_HEAD, 0)
-        rows = rows_streamed
-        flop_per_launch = rows * FLOP_PER_CONV_ROW
+        # algorithmic FLOPs of the timed launches as accounted by the library: 393 216 per evaluated time step; the
+        # streamed forward evaluates fewer rows in the early layers (a head only holds the rows its layer changes)
+        flop_per_launch = tc["flops"] / max(1, tc["launches"])
         avg_s = tc["total_ms"] / max(1, tc["launches"]) * 1e-3
         achieved = flop_per_launch / avg_s / 1e12
         peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else F16_MFMA_PEAK_TFLOPS / 3.0

@@ -126,7 +126,7 @@ extern "C" int rd_destroy(rd_ctx* ctx)
     timer_free(ctx->timer_decode);
     timer_free(ctx->timer_head);
     timer_free(ctx->timer_in);
-    DevBuf* bufs[] = {&ctx->ws_tiles, &ctx->ws_raw, &ctx->ws_in, &ctx->ws_act0, &ctx->ws_act1, &ctx->ws_probs, &ctx->ws_mat, &ctx->ws_seq,
+    DevBuf* bufs[] = {&ctx->ws_tiles, &ctx->ws_raw, &ctx->ws_act2, &ctx->ws_in, &ctx->ws_act0, &ctx->ws_act1, &ctx->ws_probs, &ctx->ws_mat, &ctx->ws_seq,
                       &ctx->ws_nodes_child, &ctx->ws_nodes_back, &ctx->ws_labels, &ctx->ws_misc, &ctx->model.storage,
                       &ctx->lm.storage, &ctx->lm.gate_storage};
     for (DevBuf* b : bufs) b->release();
@@ -736,7 +736,10 @@ inline WindowGeom window_geom(int64_t N, int chunk, int step)
 }
 
 struct ReadsPlan {
-    std::vector<TileDesc> tiles;
+    int n_layers = 0;                       // 2 * nblocks + 1
+    bool per_layer = false;                 // false: tiles[0] serves every layer
+    std::vector<TileDesc> tiles[RD_MAX_LAYERS];
+    int64_t rows[RD_MAX_LAYERS] = {0};      // time steps evaluated per layer
     // per decoded sequence (chunk mode: window; global mode: read)
     std::vector<int64_t> off1, off2;
     std::vector<int32_t> split, valid;
@@ -746,30 +749,58 @@ struct ReadsPlan {
     int n_windows = 0;
 };
 
-void add_segment(ReadsPlan& P, int64_t seg_row, int64_t src_row, int len)
+void add_segment(std::vector<TileDesc>& list, int64_t& rows, int64_t seg_row, int64_t src_row, int len, int in_len,
+                 int64_t alt_row = 0, int alt_in = INT32_MAX, int alt_res = INT32_MAX)
 {
     for (int t0 = 0; t0 < len; t0 += 128) {
         TileDesc td;
         td.seg_row = seg_row;
         td.src_row = src_row;
+        td.alt_row = alt_row;
         td.t0 = t0;
         td.seg_len = len;
-        P.tiles.push_back(td);
+        td.in_len = in_len;
+        td.alt_in = alt_in;
+        td.alt_res = alt_res;
+        td.pad_ = 0;
+        list.push_back(td);
     }
+    rows += len;
 }
 
-// chunk mode: one stream per read + one head per window i >= 1
-int plan_reads_chunk(const int64_t* read_off, int n_reads, int chunk, int step, int halo, ReadsPlan& P)
+// Rows of a head that differ from the stream, per tensor: the signal has none; a k=3 conv of dilation d adds 2d.
+struct LayerHalo {
+    int h_in, h_res, h_out;
+};
+void layer_halos(const Model& m, LayerHalo* lh)
 {
+    int H = 0;  // halo of the block input
+    for (int b = 0; b < m.nblocks; b++) {
+        const int d = m.dil[b];
+        lh[2 * b] = {H, H, H + 2 * d};               // first conv (block 0: from the raw signal)
+        lh[2 * b + 1] = {H + 2 * d, H, H + 4 * d};   // second conv, residual = block input
+        H += 4 * d;
+    }
+    lh[2 * m.nblocks] = {H, H, H};                   // dense head
+}
+
+// chunk mode: one stream per read + one head per window i >= 1; per-layer head lengths
+int plan_reads_chunk(const Model& m, const int64_t* read_off, int n_reads, int chunk, int step, int halo, ReadsPlan& P)
+{
+    LayerHalo lh[RD_MAX_LAYERS];
+    layer_halos(m, lh);
+    P.n_layers = 2 * m.nblocks + 1;
+    P.per_layer = true;
     int64_t row = 0;
     P.read_win_off.assign(1, 0);
     for (int r = 0; r < n_reads; r++) {
         const int64_t N = read_off[r + 1] - read_off[r];
         RD_REQUIRE(N >= 1, "read %d is empty", r);
+        RD_REQUIRE(N < INT32_MAX, "read %d too long", r);
         const WindowGeom g = window_geom(N, chunk, step);
         const int64_t stream_row = row;
         P.read_row.push_back(stream_row);
-        add_segment(P, stream_row, read_off[r], (int)N);
+        for (int li = 0; li < P.n_layers; li++) add_segment(P.tiles[li], P.rows[li], stream_row, read_off[r], (int)N, (int)N);
         row += N;
         for (int i = 0; i < g.nW; i++) {
             const int valid = (i < g.nW - 1) ? chunk : chunk - g.pad;
@@ -777,7 +808,12 @@ int plan_reads_chunk(const int64_t* read_off, int n_reads, int chunk, int step, 
             int64_t o1 = stream_row + (int64_t)i * step;
             if (h > 0) {
                 o1 = row;
-                add_segment(P, row, read_off[r] + (int64_t)i * step, h);
+                const int64_t alt = stream_row + (int64_t)i * step;
+                for (int li = 0; li < P.n_layers; li++) {
+                    const int len = lh[li].h_out < valid ? lh[li].h_out : valid;   // rows of this head the layer must produce
+                    if (len > 0)
+                        add_segment(P.tiles[li], P.rows[li], row, read_off[r] + (int64_t)i * step, len, valid, alt, lh[li].h_in, lh[li].h_res);
+                }
                 row += h;
             }
             P.off1.push_back(o1);
@@ -793,11 +829,12 @@ int plan_reads_chunk(const int64_t* read_off, int n_reads, int chunk, int step, 
 }
 
 struct PlanCache {
-    int chunk = -1, step = -1, halo = -1, mode = -1;
+    int chunk = -1, step = -1, halo = -1, mode = -1, nblocks = -1;
     std::vector<int64_t> lens;
     ReadsPlan plan;
     bool streamed = false;
     DevBuf d_tiles;
+    TileLists lists;
 };
 
 // plan + device tile descriptors for a batch of reads, cached while consecutive batches have the same read lengths
@@ -1082,24 +1119,27 @@ extern "C" int rd_pipe_flush(rd_ctx* ctx)
 namespace {
 
 // global mode: one stream per read when the geometry allows it, else per-window segments in a uniform row layout
-int plan_reads_global(const int64_t* read_off, int n_reads, int chunk, int step, int halo, ReadsPlan& P, bool* streamed)
+int plan_reads_global(const Model& m, const int64_t* read_off, int n_reads, int chunk, int step, int halo, ReadsPlan& P, bool* streamed)
 {
     const bool st = step <= chunk - halo;
     *streamed = st;
+    P.n_layers = 2 * m.nblocks + 1;
+    P.per_layer = false;
     int64_t row = 0;
     P.read_win_off.assign(1, 0);
     for (int r = 0; r < n_reads; r++) {
         const int64_t N = read_off[r + 1] - read_off[r];
         RD_REQUIRE(N >= 1, "read %d is empty", r);
+        RD_REQUIRE(N < INT32_MAX, "read %d too long", r);
         const WindowGeom g = window_geom(N, chunk, step);
         P.read_row.push_back(row);
         if (st) {
-            add_segment(P, row, read_off[r], (int)N);
+            add_segment(P.tiles[0], P.rows[0], row, read_off[r], (int)N, (int)N);
             row += N;
         } else {
             for (int i = 0; i < g.nW; i++) {
                 const int valid = (i < g.nW - 1) ? chunk : chunk - g.pad;
-                if (valid > 0) add_segment(P, row + (int64_t)i * chunk, read_off[r] + (int64_t)i * step, valid);
+                if (valid > 0) add_segment(P.tiles[0], P.rows[0], row + (int64_t)i * chunk, read_off[r] + (int64_t)i * step, valid, valid);
             }
             row += (int64_t)g.nW * chunk;
         }
@@ -1112,7 +1152,7 @@ int plan_reads_global(const int64_t* read_off, int n_reads, int chunk, int step,
 }
 
 int get_plan(rd_ctx* ctx, const int64_t* read_off, int n_reads, int chunk, int step, int mode, const ReadsPlan** out,
-             const TileDesc** d_tiles, bool* streamed)
+             const TileLists** lists, bool* streamed)
 {
     PlanCache* pc = (PlanCache*)ctx->plan_cache[mode];
     if (!pc) {
@@ -1123,26 +1163,49 @@ int get_plan(rd_ctx* ctx, const int64_t* read_off, int n_reads, int chunk, int s
     std::vector<int64_t> lens(n_reads);
     for (int r = 0; r < n_reads; r++) lens[r] = read_off[r + 1] - read_off[r];
     bool hit = pc->chunk == chunk && pc->step == step && pc->halo == halo && pc->mode == mode && pc->lens == lens &&
-               read_off[0] == 0 && pc->d_tiles.p;
+               read_off[0] == 0 && pc->d_tiles.p && pc->nblocks == ctx->model.nblocks;
     if (!hit) {
         RD_REQUIRE(read_off[0] == 0, "read_off[0] must be 0");
         pc->plan = ReadsPlan();
-        int rc = mode == 0 ? plan_reads_chunk(read_off, n_reads, chunk, step, halo, pc->plan)
-                           : plan_reads_global(read_off, n_reads, chunk, step, halo, pc->plan, &pc->streamed);
+        int rc = mode == 0 ? plan_reads_chunk(ctx->model, read_off, n_reads, chunk, step, halo, pc->plan)
+                           : plan_reads_global(ctx->model, read_off, n_reads, chunk, step, halo, pc->plan, &pc->streamed);
         if (rc) return rc;
-        const size_t bytes = pc->plan.tiles.size() * sizeof(TileDesc);
-        if (pc->d_tiles.reserve(bytes ? bytes : 16)) return RD_ERR_NOMEM;
+        ReadsPlan& P = pc->plan;
+        size_t total = 0;
+        for (int li = 0; li < P.n_layers; li++) total += P.tiles[P.per_layer ? li : 0].size() * (P.per_layer || li == 0 ? 1 : 0);
+        if (pc->d_tiles.reserve(total * sizeof(TileDesc) + 16)) return RD_ERR_NOMEM;
         // make sure no forward still reads the previous descriptors
         RD_HIP(hipStreamSynchronize(ctx->stream));
-        if (bytes) RD_HIP(hipMemcpy(pc->d_tiles.p, pc->plan.tiles.data(), bytes, hipMemcpyHostToDevice));
+        size_t off = 0;
+        for (int li = 0; li < RD_MAX_LAYERS; li++) {
+            pc->lists.d[li] = nullptr;
+            pc->lists.n[li] = 0;
+            pc->lists.rows[li] = 0;
+        }
+        for (int li = 0; li < P.n_layers; li++) {
+            if (P.per_layer || li == 0) {
+                const std::vector<TileDesc>& v = P.tiles[li];
+                if (!v.empty())
+                    RD_HIP(hipMemcpy(pc->d_tiles.as<TileDesc>() + off, v.data(), v.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+                pc->lists.d[li] = pc->d_tiles.as<TileDesc>() + off;
+                pc->lists.n[li] = (int)v.size();
+                pc->lists.rows[li] = P.rows[li];
+                off += v.size();
+            } else {
+                pc->lists.d[li] = pc->lists.d[0];
+                pc->lists.n[li] = pc->lists.n[0];
+                pc->lists.rows[li] = pc->lists.rows[0];
+            }
+        }
         pc->chunk = chunk;
         pc->step = step;
         pc->halo = halo;
         pc->mode = mode;
         pc->lens = lens;
+        pc->nblocks = ctx->model.nblocks;
     }
     *out = &pc->plan;
-    *d_tiles = pc->d_tiles.as<TileDesc>();
+    *lists = &pc->lists;
     if (streamed) *streamed = pc->streamed;
     return RD_OK;
 }
@@ -1183,10 +1246,10 @@ extern "C" int rd_basecall_reads_chunk_resident(rd_ctx* ctx, const float* d_sign
     RD_REQUIRE(labels_out && label_len, "rd_basecall_reads_chunk: null output");
     RD_HIP(hipSetDevice(ctx->device));
     const ReadsPlan* P = nullptr;
-    const TileDesc* d_tiles = nullptr;
-    if ((rc = get_plan(ctx, read_off, n_reads, chunk_len, step, 0, &P, &d_tiles, nullptr))) return rc;
+    const TileLists* tl = nullptr;
+    if ((rc = get_plan(ctx, read_off, n_reads, chunk_len, step, 0, &P, &tl, nullptr))) return rc;
     if (ctx->ws_probs.reserve((size_t)P->total_rows * 20)) return RD_ERR_NOMEM;
-    rc = rd_forward_tiles_dev(ctx, d_signal, d_tiles, (int)P->tiles.size(), P->total_rows, ctx->ws_probs.as<float>());
+    rc = rd_forward_tiles_dev(ctx, d_signal, *tl, P->total_rows, ctx->ws_probs.as<float>());
     if (rc) return rc;
     std::vector<int64_t> lab_off(P->n_windows);
     for (int w = 0; w < P->n_windows; w++) lab_off[w] = (int64_t)w * chunk_len;
@@ -1270,11 +1333,11 @@ extern "C" int rd_basecall_reads_global_resident(rd_ctx* ctx, const float* d_sig
     RD_REQUIRE(labels_out && label_off && label_len, "rd_basecall_reads_global: null output");
     RD_HIP(hipSetDevice(ctx->device));
     const ReadsPlan* P = nullptr;
-    const TileDesc* d_tiles = nullptr;
+    const TileLists* tl = nullptr;
     bool streamed = false;
-    if ((rc = get_plan(ctx, read_off, n_reads, chunk_len, step, 1, &P, &d_tiles, &streamed))) return rc;
+    if ((rc = get_plan(ctx, read_off, n_reads, chunk_len, step, 1, &P, &tl, &streamed))) return rc;
     if (ctx->ws_probs.reserve((size_t)P->total_rows * 20)) return RD_ERR_NOMEM;
-    rc = rd_forward_tiles_dev(ctx, d_signal, d_tiles, (int)P->tiles.size(), P->total_rows, ctx->ws_probs.as<float>());
+    rc = rd_forward_tiles_dev(ctx, d_signal, *tl, P->total_rows, ctx->ws_probs.as<float>());
     if (rc) return rc;
     return global_finish(ctx, ctx->ws_probs.as<float>(), streamed, *P, read_off, n_reads, chunk_len, step, beam_width, use_lm, s_thr,
                          r_thr, labels_out, label_off, label_len);
@@ -1366,13 +1429,13 @@ extern "C" int rd_pipe_submit_reads(rd_ctx* ctx, const float* d_signal, const in
     RD_REQUIRE(labels_out && label_len, "rd_pipe_submit_reads: null output");
     RD_HIP(hipSetDevice(ctx->device));
     const ReadsPlan* P = nullptr;
-    const TileDesc* d_tiles = nullptr;
-    if ((rc = get_plan(ctx, read_off, n_reads, chunk_len, step, 0, &P, &d_tiles, nullptr))) return rc;
+    const TileLists* tl = nullptr;
+    if ((rc = get_plan(ctx, read_off, n_reads, chunk_len, step, 0, &P, &tl, nullptr))) return rc;
     Pipe* p = nullptr;
     if ((rc = pipe_get(ctx, &p))) return rc;
     PipeSlot* s = nullptr;
     if ((rc = pipe_open_slot(ctx, p, chunk_len, beam_width, P->total_rows, &s))) return rc;
-    rc = rd_forward_tiles_dev(ctx, d_signal, d_tiles, (int)P->tiles.size(), P->total_rows, s->probs.as<float>() + (size_t)s->rows * 5);
+    rc = rd_forward_tiles_dev(ctx, d_signal, *tl, P->total_rows, s->probs.as<float>() + (size_t)s->rows * 5);
     if (rc) return rc;
     PipeSub sb;
     sb.n = P->n_windows;

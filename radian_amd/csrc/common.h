@@ -84,12 +84,29 @@ struct LM {
     DevBuf storage, gate_storage;   // storage = table followed by d_entropy (one RCCL broadcast)
 };
 
-// One workgroup's tile of the forward: rows [t0, t0+128) of a segment that starts at global row seg_row.
+// One workgroup's tile of the forward: rows [t0, t0+128) of a segment whose time step 0 is global row seg_row.
+// A segment is a window, a whole read (the "stream"), or the first rows of a window (a "head").  Heads only hold the
+// rows that see their window's own zero left-padding; every later row equals the read's stream row, so a head's
+// reads of rows t >= alt_in (conv input) / alt_res (residual) are redirected to global row alt_row + t.
 struct TileDesc {
     int64_t seg_row;   // global row (activations / probabilities) of the segment's time step 0
     int64_t src_row;   // index of the segment's sample 0 in the signal buffer
+    int64_t alt_row;   // global row of the stream row that equals this segment's time step 0
     int32_t t0;        // first time step of this tile
-    int32_t seg_len;   // time steps in the segment
+    int32_t seg_len;   // time steps this layer computes and stores for the segment
+    int32_t in_len;    // time steps that exist as input (zero beyond)
+    int32_t alt_in;    // conv-input rows t >= alt_in come from alt_row + t   (INT32_MAX: never)
+    int32_t alt_res;   // residual rows  t >= alt_res come from alt_row + t
+    int32_t pad_;
+};
+
+// per-layer tile lists: index 0 = block-0 first conv (C_in = 1); 2b = first conv of block b >= 1; 2b+1 = second conv of
+// block b; 2*nblocks = dense head.  Uniform windows and streams use one list for every layer.
+constexpr int RD_MAX_LAYERS = 2 * 16 + 1;
+struct TileLists {
+    const TileDesc* d[RD_MAX_LAYERS];
+    int n[RD_MAX_LAYERS];
+    int64_t rows[RD_MAX_LAYERS];   // time steps the layer evaluates (for the FLOP / byte accounting of the timers)
 };
 
 struct KernelTimer {
@@ -110,6 +127,7 @@ struct rd_ctx {
     // workspaces
     DevBuf ws_tiles, ws_raw;
     int tiles_nW = -1, tiles_T = -1;   // shape the cached uniform tile descriptors were built for
+    DevBuf ws_act2;
     DevBuf ws_in, ws_act0, ws_act1, ws_probs, ws_mat, ws_seq, ws_nodes_child, ws_nodes_back, ws_labels, ws_misc;
     // pinned host staging
     void* h_stage = nullptr;
@@ -122,8 +140,7 @@ struct rd_ctx {
 
 // forward.hip
 int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_probs);
-int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileDesc* d_tiles, int n_tiles, int64_t total_rows,
-                         float* d_probs);
+int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tiles, int64_t total_rows, float* d_probs);
 int rd_model_halo(const rd_ctx* ctx);  // receptive field - 1 = (K-1) * 2 * sum(dilations)
 // decode.hip
 int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* d_seq_off, const int32_t* d_seq_len,

@@ -27,6 +27,7 @@
 // 128 -> 5 and applies softmax from LDS.
 #include "common.h"
 
+#include <stdint.h>
 #include <type_traits>
 
 namespace {
@@ -91,6 +92,9 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
     const int t0 = td.t0;
     const int T = td.seg_len;
     const float* __restrict__ inw = a.in + (size_t)seg_row * RD_C;
+    const float* __restrict__ inalt = a.in + (size_t)td.alt_row * RD_C;
+    // 32-row sub-tiles of this wave that hold rows to compute (a head's last tile is mostly empty)
+    const int mcount = (T - t0 - wm * 64 + 31) / 32 < 0 ? 0 : ((T - t0 - wm * 64 + 31) / 32 > 2 ? 2 : (T - t0 - wm * 64 + 31) / 32);
 
     // DMA roles: a wave-instruction moves 8 rows x 128 B; lane -> (row-in-piece, physical 16-B slot)
     const int dma_r = lane >> 3;
@@ -108,7 +112,8 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
             const int row = piece * 8 + dma_r;
             const int slot = dma_ps ^ ((row >> 1) & 7);
             const int t = t0 + row - shift;
-            const float* src = (t >= 0 && t < T) ? inw + (size_t)t * RD_C + ci0 + slot * 4 : a.zeros + dma_ps * 4;
+            const float* src = (t >= 0 && t < td.in_len) ? (t < td.alt_in ? inw : inalt) + (size_t)t * RD_C + ci0 + slot * 4
+                                                           : a.zeros + dma_ps * 4;
             glds16(src, As + piece * 256);
         }
         const float* wsrc = a.wpk + (size_t)chunk * BN * BK + lane * 4;   // pre-swizzled on the host: linear copy
@@ -141,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
         stage(chunk);
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's DMA pieces have landed
         __syncthreads();                     // ... and everyone else's
+        if (mcount > 0)
 #pragma unroll
         for (int g = 0; g < BK / 8; g++) {
             float4 af[2], bf[NT];
@@ -152,6 +158,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
             for (int kr = 0; kr < 4; kr++) {
 #pragma unroll
                 for (int m = 0; m < 2; m++) {
+                    if (m >= mcount) continue;
                     const float av = kr == 0 ? af[m].x : kr == 1 ? af[m].y : kr == 2 ? af[m].z : af[m].w;
 #pragma unroll
                     for (int n = 0; n < NT; n++) {
@@ -173,14 +180,16 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
         // instruction, 32 store (and 32 residual load) instructions per lane instead of 128.
         constexpr int TSTR = 68;                       // patch row stride in floats (64 + 4: conflict-free, 16-B aligned)
         float* ts = smem + wave * (32 * TSTR);
-        float* outw = a.out + (size_t)seg_row * RD_C;  // may alias a.resid: each element is read then written by one lane
-        const float* resw = a.resid + (size_t)seg_row * RD_C;
+        float* __restrict__ outw = a.out + (size_t)seg_row * RD_C;
+        const float* __restrict__ resw = a.resid + (size_t)seg_row * RD_C;      // block input (separate tensor)
+        const float* __restrict__ resalt = a.resid + (size_t)td.alt_row * RD_C;
         const bool interior = t0 + BM <= T;
         float4* sink4 = (float4*)a.sink + threadIdx.x;
         const int rrow = lane >> 4;                    // 0..3: row inside a 4-row store group
         const int c4 = (lane & 15) * 4;                // channel offset inside the 64-channel patch
 #pragma unroll
         for (int m = 0; m < 2; m++) {
+            if (m >= mcount) continue;
 #pragma unroll
             for (int np = 0; np < NT / 2; np++) {
                 // ---- accumulators (+ bias, ReLU) -> LDS patch
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
                     tt[i] = t;
                     if constexpr (EPI == EPI_RES_IDENT) {
                         const int tc = (interior || t < T) ? t : T - 1;
-                        rv[i] = *(const float4*)(resw + (size_t)tc * RD_C + ch);
+                        rv[i] = *(const float4*)((tc < td.alt_res ? resw : resalt) + (size_t)tc * RD_C + ch);
                     }
                 }
 #pragma unroll
@@ -377,6 +386,8 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
     const int t0 = td.t0;
     const int T = td.seg_len;
     const _Float16* __restrict__ inw = a.in + (size_t)seg_row * ROWH;
+    const _Float16* __restrict__ inalt = a.in + (size_t)td.alt_row * ROWH;
+    const int mcount = (T - t0 - wm * 64 + 31) / 32 < 0 ? 0 : ((T - t0 - wm * 64 + 31) / 32 > 2 ? 2 : (T - t0 - wm * 64 + 31) / 32);
 
     const int dma_r = lane >> 3;
     const int dma_ps = lane & 7;
@@ -391,7 +402,8 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
             const int row = piece * 8 + dma_r;
             const int slot = dma_ps ^ ((row >> 1) & 7);
             const int t = t0 + row - shift;
-            const float* src = (t >= 0 && t < T) ? (const float*)(inw + (size_t)t * ROWH + cc * 64 + slot * 8) : a.zeros + dma_ps * 4;
+            const float* src = (t >= 0 && t < td.in_len) ? (const float*)((t < td.alt_in ? inw : inalt) + (size_t)t * ROWH + cc * 64 + slot * 8)
+                                                           : a.zeros + dma_ps * 4;
             glds16(src, As + piece * 256);
         }
         const float* wsrc = (const float*)(a.wpk + (size_t)chunk * BN * 64) + lane * 4;
@@ -421,6 +433,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
         stage(chunk);
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
         __syncthreads();
+        if (mcount > 0)
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
             const int oh = ((2 * ks + fh) ^ swz) * 8;       // hi slot of this lane's k = 16 ks + 8 fh .. +7
@@ -440,6 +453,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int n = 0; n < NT; n++) {
+                    if (m >= mcount) continue;
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
@@ -451,14 +465,16 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
     if constexpr (EPI != EPI_HEAD) {
         constexpr int TSTR = 68;
         float* ts = smem + wave * (32 * TSTR);
-        _Float16* outw = a.out + (size_t)seg_row * ROWH;      // may alias a.resid (read-then-write by one lane)
-        const _Float16* resw = a.resid + (size_t)seg_row * ROWH;
+        _Float16* __restrict__ outw = a.out + (size_t)seg_row * ROWH;
+        const _Float16* __restrict__ resw = a.resid + (size_t)seg_row * ROWH;
+        const _Float16* __restrict__ resalt = a.resid + (size_t)td.alt_row * ROWH;
         const bool interior = t0 + BM <= T;
         f16x4* sinkh = (f16x4*)a.sink + 2 * threadIdx.x;
         const int rrow = lane >> 4;
         const int c4 = (lane & 15) * 4;
 #pragma unroll
         for (int m = 0; m < 2; m++) {
+            if (m >= mcount) continue;
 #pragma unroll
             for (int np = 0; np < NT / 2; np++) {
 #pragma unroll
@@ -489,8 +505,9 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
                     tt[i] = t;
                     if constexpr (EPI == EPI_RES_IDENT) {
                         const int tc = (interior || t < T) ? t : T - 1;
-                        rh[i] = *(const f16x4*)(resw + (size_t)tc * ROWH + hoff);
-                        rl4[i] = *(const f16x4*)(resw + (size_t)tc * ROWH + hoff + 32);
+                        const _Float16* rb = (tc < td.alt_res ? resw : resalt) + (size_t)tc * ROWH + hoff;
+                        rh[i] = *(const f16x4*)rb;
+                        rl4[i] = *(const f16x4*)(rb + 32);
                     }
                 }
 #pragma unroll
@@ -628,146 +645,157 @@ int timer_end(rd_ctx* ctx, KernelTimer& tm, double flops, double bytes)
 
 }  // namespace
 
-// Forward over a set of independent SEGMENTS packed in one row space: d_signal [total_rows] fp32 (already
-// MAD-normalised), d_tiles [n_tiles] (every segment cut into tiles of <= 128 rows) -> d_probs [total_rows][5].
-// A segment is causally zero-padded at its own start; nothing leaks between segments.
-int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileDesc* d_tiles, int n_tiles, int64_t total_rows,
-                         float* d_probs)
+// Forward over a set of independent SEGMENTS packed in one row space: d_signal [*] fp32 (already MAD-normalised),
+// per-layer tile lists (every segment cut into tiles of <= 128 rows) -> d_probs [total_rows][5].
+// A segment is causally zero-padded at its own start; nothing leaks between segments (heads read their later rows
+// from their read's stream, see TileDesc).  Three activation tensors: X_a / X_b (block input / output, ping-pong --
+// a head tile reads stream rows of the block input while stream tiles write the block output) and MID.
+int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl, int64_t total_rows, float* d_probs)
 {
     Model& m = ctx->model;
     if (!m.loaded) {
         rd_set_error("rd_forward: no weights loaded (rd_load_weights)");
         return RD_ERR_STATE;
     }
-    if (n_tiles == 0 || total_rows == 0) return RD_OK;
+    if (total_rows == 0) return RD_OK;
     int rc = RD_OK;
     const size_t act_bytes = (size_t)total_rows * RD_C * sizeof(float);
-    if (ctx->ws_act0.reserve(act_bytes) || ctx->ws_act1.reserve(act_bytes)) return RD_ERR_NOMEM;
-    float* X = ctx->ws_act0.as<float>();    // block input / output (residual added in place)
-    float* MID = ctx->ws_act1.as<float>();  // activation between the two convs of a block
-    const double rows = (double)total_rows;
-    const int grid = n_tiles;
-    const double conv_flops = 2.0 * rows * RD_C * RD_C * RD_K;
-    const double conv_bytes = 2.0 * rows * RD_C * 4.0;
+    if (ctx->ws_act0.reserve(act_bytes) || ctx->ws_act1.reserve(act_bytes) || ctx->ws_act2.reserve(act_bytes)) return RD_ERR_NOMEM;
+    float* Xin = ctx->ws_act0.as<float>();
+    float* Xout = ctx->ws_act1.as<float>();
+    float* MID = ctx->ws_act2.as<float>();
     const bool split = ctx->precision == 1;
+    auto rows_of = [&](int li) {   // time steps this layer evaluates (tiles * 128 is an upper bound; the lists know the truth)
+        return (double)tl.rows[li];
+    };
 
     for (int b = 0; b < m.nblocks; b++) {
         const int d = m.dil[b];
         ConvArgs a = {};
         a.zeros = m.zeros;
         a.sink = m.sink;
-        a.tiles = d_tiles;
         a.dil = d;
         SplitArgs sa = {};
         sa.zeros = m.zeros;
         sa.sink = m.sink;
-        sa.tiles = d_tiles;
         sa.dil = d;
         if (b == 0) {
             // conv0: 1 -> 256 on the VALU
-            if ((rc = timer_begin(ctx, ctx->timer_in))) return rc;
-            if (split)
-                hipLaunchKernelGGL(tcn_in_split_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_signal, m.w_in, m.b_in, (_Float16*)MID, d_tiles, d);
-            else
-                hipLaunchKernelGGL(tcn_in_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_signal, m.w_in, m.b_in, MID, d_tiles, d);
-            RD_HIP(hipGetLastError());
-            if ((rc = timer_end(ctx, ctx->timer_in, 2.0 * rows * RD_C * RD_K, rows * (RD_C * 4.0 + 4.0)))) return rc;
-            // conv1 + relu, + 1x1 match residual + relu
-            a.in = MID;
-            a.out = X;
-            a.wpk = m.w_conv[1];
-            a.bias = m.b_conv[1];
-            a.x = d_signal;
-            a.wmatch = m.w_match;
-            a.bmatch = m.b_match;
-            sa.in = (const _Float16*)MID;
-            sa.out = (_Float16*)X;
-            sa.wpk = (const _Float16*)m.ws_conv[1];
-            sa.inv_scale = m.inv_scale[1];
-            sa.bias = m.b_conv[1];
-            sa.x = d_signal;
-            sa.wmatch = m.w_match;
-            sa.bmatch = m.b_match;
-            if ((rc = timer_begin(ctx, ctx->timer_conv))) return rc;
-            if (split)
-                hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RES_MATCH>), dim3(grid), dim3(256), 0, ctx->stream, sa);
-            else
-                hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_MATCH>), dim3(grid), dim3(256), 0, ctx->stream, a);
-            RD_HIP(hipGetLastError());
-            if ((rc = timer_end(ctx, ctx->timer_conv, conv_flops, conv_bytes))) return rc;
+            const int li = 0;
+            if (tl.n[li]) {
+                if ((rc = timer_begin(ctx, ctx->timer_in))) return rc;
+                if (split)
+                    hipLaunchKernelGGL(tcn_in_split_kernel, dim3(tl.n[li]), dim3(256), 0, ctx->stream, d_signal, m.w_in, m.b_in, (_Float16*)MID, tl.d[li], d);
+                else
+                    hipLaunchKernelGGL(tcn_in_kernel, dim3(tl.n[li]), dim3(256), 0, ctx->stream, d_signal, m.w_in, m.b_in, MID, tl.d[li], d);
+                RD_HIP(hipGetLastError());
+                if ((rc = timer_end(ctx, ctx->timer_in, 2.0 * rows_of(li) * RD_C * RD_K, rows_of(li) * (RD_C * 4.0 + 4.0)))) return rc;
+            }
         } else {
-            a.in = X;
+            const int li = 2 * b;
+            a.in = Xin;
             a.out = MID;
             a.wpk = m.w_conv[2 * b];
             a.bias = m.b_conv[2 * b];
-            sa.in = (const _Float16*)X;
+            a.tiles = tl.d[li];
+            sa.in = (const _Float16*)Xin;
             sa.out = (_Float16*)MID;
             sa.wpk = (const _Float16*)m.ws_conv[2 * b];
             sa.inv_scale = m.inv_scale[2 * b];
             sa.bias = m.b_conv[2 * b];
-            if ((rc = timer_begin(ctx, ctx->timer_conv))) return rc;
-            if (split)
-                hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RELU>), dim3(grid), dim3(256), 0, ctx->stream, sa);
-            else
-                hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RELU>), dim3(grid), dim3(256), 0, ctx->stream, a);
-            RD_HIP(hipGetLastError());
-            if ((rc = timer_end(ctx, ctx->timer_conv, conv_flops, conv_bytes))) return rc;
-            a.in = MID;
-            a.out = X;
-            a.resid = X;
-            a.wpk = m.w_conv[2 * b + 1];
-            a.bias = m.b_conv[2 * b + 1];
-            sa.in = (const _Float16*)MID;
-            sa.out = (_Float16*)X;
-            sa.resid = (const _Float16*)X;
-            sa.wpk = (const _Float16*)m.ws_conv[2 * b + 1];
-            sa.inv_scale = m.inv_scale[2 * b + 1];
-            sa.bias = m.b_conv[2 * b + 1];
-            if ((rc = timer_begin(ctx, ctx->timer_conv))) return rc;
-            if (split)
-                hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RES_IDENT>), dim3(grid), dim3(256), 0, ctx->stream, sa);
-            else
-                hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_IDENT>), dim3(grid), dim3(256), 0, ctx->stream, a);
-            RD_HIP(hipGetLastError());
-            if ((rc = timer_end(ctx, ctx->timer_conv, conv_flops, conv_bytes + rows * RD_C * 4.0))) return rc;
+            sa.tiles = tl.d[li];
+            if (tl.n[li]) {
+                if ((rc = timer_begin(ctx, ctx->timer_conv))) return rc;
+                if (split)
+                    hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RELU>), dim3(tl.n[li]), dim3(256), 0, ctx->stream, sa);
+                else
+                    hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RELU>), dim3(tl.n[li]), dim3(256), 0, ctx->stream, a);
+                RD_HIP(hipGetLastError());
+                if ((rc = timer_end(ctx, ctx->timer_conv, 2.0 * rows_of(li) * RD_C * RD_C * RD_K, 2.0 * rows_of(li) * RD_C * 4.0))) return rc;
+            }
         }
+        // second conv + relu, + residual (block 0: 1x1 match from the raw sample; else the block input) + relu
+        const int li = 2 * b + 1;
+        a.in = MID;
+        a.out = Xout;
+        a.resid = Xin;
+        a.wpk = m.w_conv[2 * b + 1];
+        a.bias = m.b_conv[2 * b + 1];
+        a.x = d_signal;
+        a.wmatch = m.w_match;
+        a.bmatch = m.b_match;
+        a.tiles = tl.d[li];
+        sa.in = (const _Float16*)MID;
+        sa.out = (_Float16*)Xout;
+        sa.resid = (const _Float16*)Xin;
+        sa.wpk = (const _Float16*)m.ws_conv[2 * b + 1];
+        sa.inv_scale = m.inv_scale[2 * b + 1];
+        sa.bias = m.b_conv[2 * b + 1];
+        sa.x = d_signal;
+        sa.wmatch = m.w_match;
+        sa.bmatch = m.b_match;
+        sa.tiles = tl.d[li];
+        if (tl.n[li]) {
+            if ((rc = timer_begin(ctx, ctx->timer_conv))) return rc;
+            if (b == 0) {
+                if (split)
+                    hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RES_MATCH>), dim3(tl.n[li]), dim3(256), 0, ctx->stream, sa);
+                else
+                    hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_MATCH>), dim3(tl.n[li]), dim3(256), 0, ctx->stream, a);
+            } else {
+                if (split)
+                    hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RES_IDENT>), dim3(tl.n[li]), dim3(256), 0, ctx->stream, sa);
+                else
+                    hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_IDENT>), dim3(tl.n[li]), dim3(256), 0, ctx->stream, a);
+            }
+            RD_HIP(hipGetLastError());
+            if ((rc = timer_end(ctx, ctx->timer_conv, 2.0 * rows_of(li) * RD_C * RD_C * RD_K,
+                                (b == 0 ? 2.0 : 3.0) * rows_of(li) * RD_C * 4.0)))
+                return rc;
+        }
+        float* t = Xin;
+        Xin = Xout;
+        Xout = t;
     }
-    if ((rc = timer_begin(ctx, ctx->timer_head))) return rc;
-    if (split) {
-        SplitArgs h = {};
-        h.zeros = m.zeros;
-        h.sink = m.sink;
-        h.tiles = d_tiles;
-        h.dil = 0;
-        h.in = (const _Float16*)X;
-        h.wpk = (const _Float16*)m.ws_d1;
-        h.inv_scale = m.inv_scale_d1;
-        h.bias = m.b_d1;
-        h.w2 = m.w_d2;
-        h.b2 = m.b_d2;
-        h.probs = d_probs;
-        hipLaunchKernelGGL((tcn_gemm_split_kernel<2, 1, EPI_HEAD>), dim3(grid), dim3(256), 0, ctx->stream, h);
-    } else {
-        ConvArgs h = {};
-        h.zeros = m.zeros;
-        h.sink = m.sink;
-        h.tiles = d_tiles;
-        h.dil = 0;
-        h.in = X;
-        h.wpk = m.w_d1;
-        h.bias = m.b_d1;
-        h.w2 = m.w_d2;
-        h.b2 = m.b_d2;
-        h.probs = d_probs;
-        hipLaunchKernelGGL((tcn_gemm_kernel<2, 1, EPI_HEAD>), dim3(grid), dim3(256), 0, ctx->stream, h);
+    const int li = 2 * m.nblocks;
+    if (tl.n[li]) {
+        if ((rc = timer_begin(ctx, ctx->timer_head))) return rc;
+        if (split) {
+            SplitArgs h = {};
+            h.zeros = m.zeros;
+            h.sink = m.sink;
+            h.tiles = tl.d[li];
+            h.dil = 0;
+            h.in = (const _Float16*)Xin;
+            h.wpk = (const _Float16*)m.ws_d1;
+            h.inv_scale = m.inv_scale_d1;
+            h.bias = m.b_d1;
+            h.w2 = m.w_d2;
+            h.b2 = m.b_d2;
+            h.probs = d_probs;
+            hipLaunchKernelGGL((tcn_gemm_split_kernel<2, 1, EPI_HEAD>), dim3(tl.n[li]), dim3(256), 0, ctx->stream, h);
+        } else {
+            ConvArgs h = {};
+            h.zeros = m.zeros;
+            h.sink = m.sink;
+            h.tiles = tl.d[li];
+            h.dil = 0;
+            h.in = Xin;
+            h.wpk = m.w_d1;
+            h.bias = m.b_d1;
+            h.w2 = m.w_d2;
+            h.b2 = m.b_d2;
+            h.probs = d_probs;
+            hipLaunchKernelGGL((tcn_gemm_kernel<2, 1, EPI_HEAD>), dim3(tl.n[li]), dim3(256), 0, ctx->stream, h);
+        }
+        RD_HIP(hipGetLastError());
+        if ((rc = timer_end(ctx, ctx->timer_head, 2.0 * rows_of(li) * (RD_C * RD_H + RD_H * 5), rows_of(li) * (RD_C * 4.0 + 20.0)))) return rc;
     }
-    RD_HIP(hipGetLastError());
-    if ((rc = timer_end(ctx, ctx->timer_head, 2.0 * rows * (RD_C * RD_H + RD_H * 5), rows * (RD_C * 4.0 + 20.0)))) return rc;
     return RD_OK;
 }
 
-// Tile descriptors of nW uniform windows of T rows; cached on the device per (nW, T).
-int rd_uniform_tiles(rd_ctx* ctx, int nW, int T, const TileDesc** d_tiles, int* n_tiles)
+// Tile descriptors of nW uniform windows of T rows; cached on the device per (nW, T).  One list serves every layer.
+int rd_uniform_tiles(rd_ctx* ctx, int nW, int T, TileLists* out)
 {
     const int tiles = (T + BM - 1) / BM;
     const size_t n = (size_t)nW * tiles;
@@ -778,17 +806,26 @@ int rd_uniform_tiles(rd_ctx* ctx, int nW, int T, const TileDesc** d_tiles, int* 
                 TileDesc& td = h[(size_t)w * tiles + k];
                 td.seg_row = (int64_t)w * T;
                 td.src_row = (int64_t)w * T;
+                td.alt_row = (int64_t)w * T;
                 td.t0 = k * BM;
                 td.seg_len = T;
+                td.in_len = T;
+                td.alt_in = INT32_MAX;
+                td.alt_res = INT32_MAX;
+                td.pad_ = 0;
             }
         if (ctx->ws_tiles.reserve(n * sizeof(TileDesc))) return RD_ERR_NOMEM;
-        RD_HIP(hipMemcpyAsync(ctx->ws_tiles.p, h.data(), n * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream));
-        RD_HIP(hipStreamSynchronize(ctx->stream));  // h is a stack-owned vector
+        RD_HIP(hipStreamSynchronize(ctx->stream));   // no forward may still be reading the previous descriptors
+        RD_HIP(hipMemcpy(ctx->ws_tiles.p, h.data(), n * sizeof(TileDesc), hipMemcpyHostToDevice));
         ctx->tiles_nW = nW;
         ctx->tiles_T = T;
     }
-    *d_tiles = ctx->ws_tiles.as<TileDesc>();
-    *n_tiles = (int)n;
+    const int nl = 2 * ctx->model.nblocks + 1;
+    for (int li = 0; li < RD_MAX_LAYERS; li++) {
+        out->d[li] = li < nl ? ctx->ws_tiles.as<TileDesc>() : nullptr;
+        out->n[li] = li < nl ? (int)n : 0;
+        out->rows[li] = li < nl ? (int64_t)nW * T : 0;
+    }
     return RD_OK;
 }
 
@@ -797,9 +834,12 @@ int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_
 {
     RD_REQUIRE(nW >= 0 && T >= 1, "rd_forward: bad shape nW=%d T=%d", nW, T);
     if (nW == 0) return RD_OK;
-    const TileDesc* d_tiles = nullptr;
-    int n_tiles = 0;
-    int rc = rd_uniform_tiles(ctx, nW, T, &d_tiles, &n_tiles);
+    if (!ctx->model.loaded) {
+        rd_set_error("rd_forward: no weights loaded (rd_load_weights)");
+        return RD_ERR_STATE;
+    }
+    TileLists tl;
+    int rc = rd_uniform_tiles(ctx, nW, T, &tl);
     if (rc) return rc;
-    return rd_forward_tiles_dev(ctx, d_windows, d_tiles, n_tiles, (int64_t)nW * T, d_probs);
+    return rd_forward_tiles_dev(ctx, d_windows, tl, (int64_t)nW * T, d_probs);
 }
