@@ -124,9 +124,24 @@ def _b(s):
 
 
 class File:
+    """HDF5 file through libhdf5; for reading, falls back to the pure-Python reader of the classic layout
+    (radian_amd.h5pure) when no libhdf5 can be loaded or RADIAN_HDF5_PURE=1."""
+
     def __init__(self, path, mode="r"):
-        L = lib()
         self.path = str(path)
+        self._pure = None
+        if mode == "r":
+            force = os.environ.get("RADIAN_HDF5_PURE") == "1"
+            try:
+                if force:
+                    raise H5Error("forced")
+                lib()
+            except H5Error:
+                from .h5pure import PureFile
+                self._pure = PureFile(self.path)
+                self.id = None
+                return
+        L = lib()
         if mode == "r":
             self.id = L.H5Fopen(_b(self.path), H5F_ACC_RDONLY, H5P_DEFAULT)
         elif mode == "w":
@@ -137,6 +152,10 @@ class File:
             raise H5Error(f"cannot open HDF5 file {self.path!r} (mode {mode})")
 
     def close(self):
+        if self._pure is not None:
+            self._pure.close()
+            self._pure = None
+            return
         if self.id is not None and self.id >= 0:
             lib().H5Fclose(self.id)
         self.id = None
@@ -150,6 +169,8 @@ class File:
     # ------------------------------------------------------------------ reading
     def exists(self, path):
         """True if every component of the absolute path exists."""
+        if self._pure is not None:
+            return self._pure.exists(path)
         L = lib()
         cur = ""
         for part in [p for p in path.split("/") if p]:
@@ -160,6 +181,8 @@ class File:
 
     def keys(self, group="/"):
         """Member names of a group in increasing name order (what h5py / ont_fast5_api iterate in)."""
+        if self._pure is not None:
+            return self._pure.keys(group)
         L = lib()
         gid = L.H5Gopen2(self.id, _b(group), H5P_DEFAULT)
         if gid < 0:
@@ -180,6 +203,8 @@ class File:
 
     def read(self, path):
         """Whole numeric dataset -> numpy array (native dtype of matching class/size/sign)."""
+        if self._pure is not None:
+            return self._pure.read(path)
         L = lib()
         did = L.H5Dopen2(self.id, _b(path), H5P_DEFAULT)
         if did < 0:
@@ -212,6 +237,8 @@ class File:
 
     def attr(self, obj_path, name, default=None):
         """String / numeric attribute of an object; arrays of strings come back as a list."""
+        if self._pure is not None:
+            return self._pure.attr(obj_path, name, default)
         L = lib()
         oid = L.H5Oopen(self.id, _b(obj_path), H5P_DEFAULT)
         if oid < 0:

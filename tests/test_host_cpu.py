@@ -151,3 +151,34 @@ def test_driver_loop_with_test_double(mode, oracle, capsys):
     assert "('MAD is zero, issue with signal.',)" in text
     assert "('Signal must not be empty to normalise',)" in text
     assert text.count("Basecalled read ") == 10
+
+
+@pytest.mark.skipif(not _have_hdf5(), reason="libhdf5 needed to write the fixtures")
+def test_pure_python_hdf5_reader(tmp_path, golden_dir, monkeypatch):
+    """radian_amd.h5pure (no libhdf5) reads the same fast5 / Keras files: groups in name order, int16 chunked signals,
+    float32 2-D weights, fixed-string attributes; through fast5.iter_reads with RADIAN_HDF5_PURE=1 too."""
+    from radian_amd import fast5, h5pure, h5weights, weights
+    ids = json.load(open(os.path.join(golden_dir, "reads_fast5_ids.json")))["read_ids"]
+    sig = np.load(os.path.join(golden_dir, "reads_fast5_signals.npz"))
+    p = str(tmp_path / "x.fast5")
+    fast5.write_multi_fast5(p, {r: sig[r] for r in ids})
+    f = h5pure.PureFile(p)
+    assert f.keys("/") == sorted("read_" + r for r in ids)
+    for r in ids:
+        a = f.read(f"/read_{r}/Raw/Signal")
+        assert a.dtype == np.int16 and np.array_equal(a, sig[r])
+        assert f.attr(f"/read_{r}/Raw", "read_id") == r
+    assert f.exists(f"/read_{ids[0]}/Raw/Signal") and not f.exists("/nope/Raw")
+    monkeypatch.setenv("RADIAN_HDF5_PURE", "1")
+    got = [(r.read_id, r.get_raw_data()) for r in fast5.iter_reads(p)]
+    assert [g[0] for g in got] == ids and all(np.array_equal(a, sig[r]) for r, a in got)
+    w = weights.synthetic_weights(seed=3)
+    q = str(tmp_path / "sig2seq.h5")
+    monkeypatch.delenv("RADIAN_HDF5_PURE")
+    h5weights.write_keras_weights(q, w)
+    monkeypatch.setenv("RADIAN_HDF5_PURE", "1")
+    assert np.array_equal(h5weights.read_keras_weights(q), w)
+    ref = "/root/reference/radian/data/reads.fast5"   # build container only: compact link-message groups inside
+    if os.path.exists(ref):
+        got = [(r.read_id, r.get_raw_data()) for r in fast5.iter_reads(ref)]
+        assert [g[0] for g in got] == ids and all(np.array_equal(a, sig[r]) for r, a in got)
