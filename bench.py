@@ -86,6 +86,10 @@ def main():
     comm = None
     if world > 1:
         from radian_amd import dist
+        # RCCL prints a version banner on the C-level stdout; stdout must carry the one JSON line only
+        sys.stdout.flush()
+        saved_fd1 = os.dup(1)
+        os.dup2(2, 1)
         try:
             # the one collective of the job: rank 0 loads + repacks the weights, RCCL broadcasts the 8.8 MB device image
             # over xGMI; the 128-byte RCCL id goes through a file keyed by the launcher's pid (no PyTorch in this process)
@@ -97,6 +101,10 @@ def main():
             comm = dist.FileComm(rank, world, dist.uid_path() + ".fc")
             be.load_weights(weights.synthetic_weights(seed=1234))
             comm_kind = "file-fallback"
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd1, 1)
+            os.close(saved_fd1)
     else:
         be.load_weights(weights.synthetic_weights(seed=1234))
 
