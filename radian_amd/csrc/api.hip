@@ -752,7 +752,7 @@ struct ReadsPlan {
 void add_segment(std::vector<TileDesc>& list, int64_t& rows, int64_t seg_row, int64_t src_row, int len, int in_len,
                  int64_t alt_row = 0, int alt_in = INT32_MAX, int alt_res = INT32_MAX)
 {
-    for (int t0 = 0; t0 < len; t0 += 128) {
+    for (int t0 = 0; t0 < len; t0 += 32) {   // 32-row sub-tiles; four of them (of any segments) make a workgroup tile
         TileDesc td;
         td.seg_row = seg_row;
         td.src_row = src_row;
@@ -1171,8 +1171,20 @@ int get_plan(rd_ctx* ctx, const int64_t* read_off, int n_reads, int chunk, int s
                            : plan_reads_global(ctx->model, read_off, n_reads, chunk, step, halo, pc->plan, &pc->streamed);
         if (rc) return rc;
         ReadsPlan& P = pc->plan;
+        auto pad4 = [](std::vector<TileDesc>& v) {          // pad the last workgroup tile with empty sub-tiles
+            while (v.size() % 4) {
+                TileDesc e = {};
+                e.alt_in = e.alt_res = INT32_MAX;
+                v.push_back(e);
+            }
+        };
         size_t total = 0;
-        for (int li = 0; li < P.n_layers; li++) total += P.tiles[P.per_layer ? li : 0].size() * (P.per_layer || li == 0 ? 1 : 0);
+        for (int li = 0; li < P.n_layers; li++) {
+            if (P.per_layer || li == 0) {
+                pad4(P.tiles[li]);
+                total += P.tiles[li].size();
+            }
+        }
         if (pc->d_tiles.reserve(total * sizeof(TileDesc) + 16)) return RD_ERR_NOMEM;
         // make sure no forward still reads the previous descriptors
         RD_HIP(hipStreamSynchronize(ctx->stream));
@@ -1182,15 +1194,18 @@ int get_plan(rd_ctx* ctx, const int64_t* read_off, int n_reads, int chunk, int s
             pc->lists.n[li] = 0;
             pc->lists.rows[li] = 0;
         }
+        auto upload = [&](const std::vector<TileDesc>& v, const TileDesc** dptr, int* n) -> int {
+            if (!v.empty())
+                RD_HIP(hipMemcpy(pc->d_tiles.as<TileDesc>() + off, v.data(), v.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+            *dptr = pc->d_tiles.as<TileDesc>() + off;
+            *n = (int)(v.size() / 4);
+            off += v.size();
+            return RD_OK;
+        };
         for (int li = 0; li < P.n_layers; li++) {
             if (P.per_layer || li == 0) {
-                const std::vector<TileDesc>& v = P.tiles[li];
-                if (!v.empty())
-                    RD_HIP(hipMemcpy(pc->d_tiles.as<TileDesc>() + off, v.data(), v.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
-                pc->lists.d[li] = pc->d_tiles.as<TileDesc>() + off;
-                pc->lists.n[li] = (int)v.size();
+                if ((rc = upload(P.tiles[li], &pc->lists.d[li], &pc->lists.n[li]))) return rc;
                 pc->lists.rows[li] = P.rows[li];
-                off += v.size();
             } else {
                 pc->lists.d[li] = pc->lists.d[0];
                 pc->lists.n[li] = pc->lists.n[0];

@@ -84,7 +84,8 @@ struct LM {
     DevBuf storage, gate_storage;   // storage = table followed by d_entropy (one RCCL broadcast)
 };
 
-// One workgroup's tile of the forward: rows [t0, t0+128) of a segment whose time step 0 is global row seg_row.
+// One 32-row SUB-TILE of the forward: rows [t0, t0+32) of a segment whose time step 0 is global row seg_row; a
+// workgroup tile is four consecutive descriptors of a layer's list (any mix of segments; lists are padded with empty ones).
 // A segment is a window, a whole read (the "stream"), or the first rows of a window (a "head").  Heads only hold the
 // rows that see their window's own zero left-padding; every later row equals the read's stream row, so a head's
 // reads of rows t >= alt_in (conv input) / alt_res (residual) are redirected to global row alt_row + t.
@@ -92,7 +93,7 @@ struct TileDesc {
     int64_t seg_row;   // global row (activations / probabilities) of the segment's time step 0
     int64_t src_row;   // index of the segment's sample 0 in the signal buffer
     int64_t alt_row;   // global row of the stream row that equals this segment's time step 0
-    int32_t t0;        // first time step of this tile
+    int32_t t0;        // first time step of this sub-tile
     int32_t seg_len;   // time steps this layer computes and stores for the segment
     int32_t in_len;    // time steps that exist as input (zero beyond)
     int32_t alt_in;    // conv-input rows t >= alt_in come from alt_row + t   (INT32_MAX: never)
@@ -105,7 +106,7 @@ struct TileDesc {
 constexpr int RD_MAX_LAYERS = 2 * 16 + 1;
 struct TileLists {
     const TileDesc* d[RD_MAX_LAYERS];
-    int n[RD_MAX_LAYERS];
+    int n[RD_MAX_LAYERS];          // workgroup tiles = descriptors / 4
     int64_t rows[RD_MAX_LAYERS];   // time steps the layer evaluates (for the FLOP / byte accounting of the timers)
 };
 

@@ -87,18 +87,31 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
     const int wn = wave & 1;    // wave col (NT*32 channels)
     // tile descriptor (wave-uniform scalar loads): the segment's first global row, this tile's first local time
     // step, the segment length.  A segment is a window, a whole read, or the first rows of a window.
-    const TileDesc td = a.tiles[blockIdx.x];
-    const int64_t seg_row = td.seg_row;
-    const int t0 = td.t0;
-    const int T = td.seg_len;
-    const float* __restrict__ inw = a.in + (size_t)seg_row * RD_C;
-    const float* __restrict__ inalt = a.in + (size_t)td.alt_row * RD_C;
-    // 32-row sub-tiles of this wave that hold rows to compute (a head's last tile is mostly empty)
-    const int mcount = (T - t0 - wm * 64 + 31) / 32 < 0 ? 0 : ((T - t0 - wm * 64 + 31) / 32 > 2 ? 2 : (T - t0 - wm * 64 + 31) / 32);
+    // A workgroup tile is four independent 32-row sub-tiles (rows 32s .. 32s+31), each with its own descriptor: stream
+    // tiles use four consecutive sub-tiles of one segment, short head segments are packed four to a tile.
+    const TileDesc* __restrict__ tds = a.tiles + (size_t)blockIdx.x * 4;
+    const TileDesc sdm[2] = {tds[wm * 2], tds[wm * 2 + 1]};           // this wave's two sub-tiles
+    const bool mval[2] = {sdm[0].seg_len > sdm[0].t0, sdm[1].seg_len > sdm[1].t0};
 
     // DMA roles: a wave-instruction moves 8 rows x 128 B; lane -> (row-in-piece, physical 16-B slot)
     const int dma_r = lane >> 3;
     const int dma_ps = lane & 7;
+
+    // DMA roles, fixed for the whole tile: sub-tile r's rows 8*wave .. 8*wave+7 are this wave's piece of it.  The
+    // descriptor fields are wave-uniform (scalar registers); per lane there is only its row in the piece and its slot.
+    int64_t d_seg[BM / 32], d_alt[BM / 32];
+    int d_t0[BM / 32], d_len[BM / 32], d_ain[BM / 32];
+#pragma unroll
+    for (int r = 0; r < BM / 32; r++) {
+        const TileDesc sd = tds[r];
+        d_seg[r] = sd.seg_row;
+        d_alt[r] = sd.alt_row;
+        d_t0[r] = sd.t0;
+        d_len[r] = sd.seg_len > sd.t0 ? sd.in_len : 0;   // empty sub-tile: zero page only
+        d_ain[r] = sd.alt_in;
+    }
+    const int lane_t = wave * 8 + dma_r;                          // this lane's row inside every sub-tile
+    const int lane_slot = (dma_ps ^ ((wave * 4 + (dma_r >> 1)) & 7)) * 4;   // (tile row >> 1) & 7 does not depend on r
 
     auto stage = [&](int chunk) {
         // chunk order: input-channel chunk outer, tap inner -> the three shifted reads of the same rows are adjacent in time
@@ -108,12 +121,11 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
         const int shift = (TAPS - 1 - tap) * a.dil;
 #pragma unroll
         for (int r = 0; r < BM / 32; r++) {
-            const int piece = r * 4 + wave;            // 1 KiB piece = rows 8*piece .. 8*piece+7
-            const int row = piece * 8 + dma_r;
-            const int slot = dma_ps ^ ((row >> 1) & 7);
-            const int t = t0 + row - shift;
-            const float* src = (t >= 0 && t < td.in_len) ? (t < td.alt_in ? inw : inalt) + (size_t)t * RD_C + ci0 + slot * 4
-                                                           : a.zeros + dma_ps * 4;
+            const int piece = r * 4 + wave;            // 1 KiB piece = tile rows 8*piece .. 8*piece+7
+            const int t = d_t0[r] + lane_t - shift;
+            const float* src = (t >= 0 && t < d_len[r])
+                                   ? a.in + ((size_t)(t < d_ain[r] ? d_seg[r] : d_alt[r]) + t) * RD_C + ci0 + lane_slot
+                                   : a.zeros + dma_ps * 4;
             glds16(src, As + piece * 256);
         }
         const float* wsrc = a.wpk + (size_t)chunk * BN * BK + lane * 4;   // pre-swizzled on the host: linear copy
@@ -146,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
         stage(chunk);
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's DMA pieces have landed
         __syncthreads();                     // ... and everyone else's
-        if (mcount > 0)
+        if (mval[0] || mval[1])   // (tiles are packed, so a wave with work almost always has both sub-tiles)
 #pragma unroll
         for (int g = 0; g < BK / 8; g++) {
             float4 af[2], bf[NT];
@@ -158,7 +170,6 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
             for (int kr = 0; kr < 4; kr++) {
 #pragma unroll
                 for (int m = 0; m < 2; m++) {
-                    if (m >= mcount) continue;
                     const float av = kr == 0 ? af[m].x : kr == 1 ? af[m].y : kr == 2 ? af[m].z : af[m].w;
 #pragma unroll
                     for (int n = 0; n < NT; n++) {
@@ -180,16 +191,18 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
         // instruction, 32 store (and 32 residual load) instructions per lane instead of 128.
         constexpr int TSTR = 68;                       // patch row stride in floats (64 + 4: conflict-free, 16-B aligned)
         float* ts = smem + wave * (32 * TSTR);
-        float* __restrict__ outw = a.out + (size_t)seg_row * RD_C;
-        const float* __restrict__ resw = a.resid + (size_t)seg_row * RD_C;      // block input (separate tensor)
-        const float* __restrict__ resalt = a.resid + (size_t)td.alt_row * RD_C;
-        const bool interior = t0 + BM <= T;
         float4* sink4 = (float4*)a.sink + threadIdx.x;
         const int rrow = lane >> 4;                    // 0..3: row inside a 4-row store group
         const int c4 = (lane & 15) * 4;                // channel offset inside the 64-channel patch
 #pragma unroll
         for (int m = 0; m < 2; m++) {
-            if (m >= mcount) continue;
+            if (!mval[m]) continue;
+            const TileDesc sd = sdm[m];
+            const int T = sd.seg_len;
+            float* __restrict__ outw = a.out + (size_t)sd.seg_row * RD_C;
+            const float* __restrict__ resw = a.resid + (size_t)sd.seg_row * RD_C;      // block input (separate tensor)
+            const float* __restrict__ resalt = a.resid + (size_t)sd.alt_row * RD_C;
+            const bool interior = sd.t0 + 32 <= T;
 #pragma unroll
             for (int np = 0; np < NT / 2; np++) {
                 // ---- accumulators (+ bias, ReLU) -> LDS patch
@@ -217,11 +230,11 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
                 int tt[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    const int t = t0 + wm * 64 + m * 32 + i * 4 + rrow;
+                    const int t = sd.t0 + i * 4 + rrow;
                     tt[i] = t;
                     if constexpr (EPI == EPI_RES_IDENT) {
                         const int tc = (interior || t < T) ? t : T - 1;
-                        rv[i] = *(const float4*)((tc < td.alt_res ? resw : resalt) + (size_t)tc * RD_C + ch);
+                        rv[i] = *(const float4*)((tc < sd.alt_res ? resw : resalt) + (size_t)tc * RD_C + ch);
                     }
                 }
 #pragma unroll
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
                         v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
                         v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
                     } else if constexpr (EPI == EPI_RES_MATCH) {
-                        const float xv = a.x[(size_t)td.src_row + (inb ? t : T - 1)];
+                        const float xv = a.x[(size_t)sd.src_row + (inb ? t : T - 1)];
                         v.x = (bm4.x + xv * wm4.x) + v.x; v.y = (bm4.y + xv * wm4.y) + v.y;
                         v.z = (bm4.z + xv * wm4.z) + v.z; v.w = (bm4.w + xv * wm4.w) + v.w;
                         v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
@@ -269,8 +282,10 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
         if (tid < 5) w2s[RD_H * 5 + tid] = a.b2[tid];
         __syncthreads();
         if (tid < BM) {
-            const int t = t0 + tid;
-            if (t < T) {
+            const TileDesc sd = tds[tid >> 5];
+            const int t = sd.t0 + (tid & 31);
+            const int64_t seg_row = sd.seg_row;
+            if (t < sd.seg_len) {
                 float lg[5];
 #pragma unroll
                 for (int o = 0; o < 5; o++) lg[o] = w2s[RD_H * 5 + o];
@@ -302,14 +317,14 @@ __global__ __launch_bounds__(256) void tcn_in_kernel(const float* __restrict__ x
                                                       const float* __restrict__ b, float* __restrict__ out,
                                                       const TileDesc* __restrict__ tiles, int dil)
 {
-    const TileDesc td = tiles[blockIdx.x];
+    const TileDesc td = tiles[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];   // wave w owns sub-tile w: one row per pass
     const int c4 = (threadIdx.x & 63) * 4;
     const float4 w0 = *(const float4*)(w + c4), w1 = *(const float4*)(w + 256 + c4), w2 = *(const float4*)(w + 512 + c4);
     const float4 bb = *(const float4*)(b + c4);
     const float* xw = x + td.src_row;
     float* ow = out + (size_t)td.seg_row * RD_C;
-    const int tend = td.t0 + BM < td.seg_len ? td.t0 + BM : td.seg_len;
-    for (int t = td.t0 + (threadIdx.x >> 6); t < tend; t += 4) {
+    const int tend = td.t0 + 32 < td.seg_len ? td.t0 + 32 : td.seg_len;
+    for (int t = td.t0; t < tend; t++) {
         const float x2 = xw[t];
         const float x1 = t - dil >= 0 ? xw[t - dil] : 0.f;
         const float x0 = t - 2 * dil >= 0 ? xw[t - 2 * dil] : 0.f;
@@ -381,16 +396,26 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1;
     const int wn = wave & 1;
-    const TileDesc td = a.tiles[blockIdx.x];
-    const int64_t seg_row = td.seg_row;
-    const int t0 = td.t0;
-    const int T = td.seg_len;
-    const _Float16* __restrict__ inw = a.in + (size_t)seg_row * ROWH;
-    const _Float16* __restrict__ inalt = a.in + (size_t)td.alt_row * ROWH;
-    const int mcount = (T - t0 - wm * 64 + 31) / 32 < 0 ? 0 : ((T - t0 - wm * 64 + 31) / 32 > 2 ? 2 : (T - t0 - wm * 64 + 31) / 32);
+    const TileDesc* __restrict__ tds = a.tiles + (size_t)blockIdx.x * 4;   // four 32-row sub-tiles (see the fp32 kernel)
+    const TileDesc sdm[2] = {tds[wm * 2], tds[wm * 2 + 1]};
+    const bool mval[2] = {sdm[0].seg_len > sdm[0].t0, sdm[1].seg_len > sdm[1].t0};
 
     const int dma_r = lane >> 3;
     const int dma_ps = lane & 7;
+
+    int64_t d_seg[BM / 32], d_alt[BM / 32];
+    int d_t0[BM / 32], d_len[BM / 32], d_ain[BM / 32];
+#pragma unroll
+    for (int r = 0; r < BM / 32; r++) {
+        const TileDesc sd = tds[r];
+        d_seg[r] = sd.seg_row;
+        d_alt[r] = sd.alt_row;
+        d_t0[r] = sd.t0;
+        d_len[r] = sd.seg_len > sd.t0 ? sd.in_len : 0;
+        d_ain[r] = sd.alt_in;
+    }
+    const int lane_t = wave * 8 + dma_r;
+    const int lane_slot = (dma_ps ^ ((wave * 4 + (dma_r >> 1)) & 7)) * 8;
 
     auto stage = [&](int chunk) {
         const int cc = chunk / TAPS;
@@ -399,11 +424,10 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
 #pragma unroll
         for (int r = 0; r < BM / 32; r++) {
             const int piece = r * 4 + wave;
-            const int row = piece * 8 + dma_r;
-            const int slot = dma_ps ^ ((row >> 1) & 7);
-            const int t = t0 + row - shift;
-            const float* src = (t >= 0 && t < td.in_len) ? (const float*)((t < td.alt_in ? inw : inalt) + (size_t)t * ROWH + cc * 64 + slot * 8)
-                                                           : a.zeros + dma_ps * 4;
+            const int t = d_t0[r] + lane_t - shift;
+            const float* src = (t >= 0 && t < d_len[r])
+                                   ? (const float*)(a.in + ((size_t)(t < d_ain[r] ? d_seg[r] : d_alt[r]) + t) * ROWH + cc * 64 + lane_slot)
+                                   : a.zeros + dma_ps * 4;
             glds16(src, As + piece * 256);
         }
         const float* wsrc = (const float*)(a.wpk + (size_t)chunk * BN * 64) + lane * 4;
@@ -433,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
         stage(chunk);
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
         __syncthreads();
-        if (mcount > 0)
+        if (mval[0] || mval[1])
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
             const int oh = ((2 * ks + fh) ^ swz) * 8;       // hi slot of this lane's k = 16 ks + 8 fh .. +7
@@ -453,7 +477,6 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int n = 0; n < NT; n++) {
-                    if (m >= mcount) continue;
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
@@ -465,16 +488,18 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
     if constexpr (EPI != EPI_HEAD) {
         constexpr int TSTR = 68;
         float* ts = smem + wave * (32 * TSTR);
-        _Float16* __restrict__ outw = a.out + (size_t)seg_row * ROWH;
-        const _Float16* __restrict__ resw = a.resid + (size_t)seg_row * ROWH;
-        const _Float16* __restrict__ resalt = a.resid + (size_t)td.alt_row * ROWH;
-        const bool interior = t0 + BM <= T;
         f16x4* sinkh = (f16x4*)a.sink + 2 * threadIdx.x;
         const int rrow = lane >> 4;
         const int c4 = (lane & 15) * 4;
 #pragma unroll
         for (int m = 0; m < 2; m++) {
-            if (m >= mcount) continue;
+            if (!mval[m]) continue;
+            const TileDesc sd = sdm[m];
+            const int T = sd.seg_len;
+            _Float16* __restrict__ outw = a.out + (size_t)sd.seg_row * ROWH;
+            const _Float16* __restrict__ resw = a.resid + (size_t)sd.seg_row * ROWH;
+            const _Float16* __restrict__ resalt = a.resid + (size_t)sd.alt_row * ROWH;
+            const bool interior = sd.t0 + 32 <= T;
 #pragma unroll
             for (int np = 0; np < NT / 2; np++) {
 #pragma unroll
@@ -501,11 +526,11 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
                 int tt[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    const int t = t0 + wm * 64 + m * 32 + i * 4 + rrow;
+                    const int t = sd.t0 + i * 4 + rrow;
                     tt[i] = t;
                     if constexpr (EPI == EPI_RES_IDENT) {
                         const int tc = (interior || t < T) ? t : T - 1;
-                        const _Float16* rb = (tc < td.alt_res ? resw : resalt) + (size_t)tc * ROWH + hoff;
+                        const _Float16* rb = (tc < sd.alt_res ? resw : resalt) + (size_t)tc * ROWH + hoff;
                         rh[i] = *(const f16x4*)rb;
                         rl4[i] = *(const f16x4*)(rb + 32);
                     }
@@ -523,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
                             v[q] = v[q] > 0.f ? v[q] : 0.f;
                         }
                     } else if constexpr (EPI == EPI_RES_MATCH) {
-                        const float xv = a.x[(size_t)td.src_row + (inb ? t : T - 1)];
+                        const float xv = a.x[(size_t)sd.src_row + (inb ? t : T - 1)];
                         const float wq[4] = {wm4.x, wm4.y, wm4.z, wm4.w}, bq[4] = {bm4.x, bm4.y, bm4.z, bm4.w};
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
@@ -567,8 +592,10 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
         if (tid < 5) w2s[RD_H * 5 + tid] = a.b2[tid];
         __syncthreads();
         if (tid < BM) {
-            const int t = t0 + tid;
-            if (t < T) {
+            const TileDesc sd = tds[tid >> 5];
+            const int t = sd.t0 + (tid & 31);
+            const int64_t seg_row = sd.seg_row;
+            if (t < sd.seg_len) {
                 float lg[5];
 #pragma unroll
                 for (int o = 0; o < 5; o++) lg[o] = w2s[RD_H * 5 + o];
@@ -598,15 +625,15 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
 __global__ __launch_bounds__(256) void tcn_in_split_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                             _Float16* __restrict__ out, const TileDesc* __restrict__ tiles, int dil)
 {
-    const TileDesc td = tiles[blockIdx.x];
+    const TileDesc td = tiles[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];   // wave w owns sub-tile w
     const int c4 = (threadIdx.x & 63) * 4;
     const float4 w0 = *(const float4*)(w + c4), w1 = *(const float4*)(w + 256 + c4), w2 = *(const float4*)(w + 512 + c4);
     const float4 bb = *(const float4*)(b + c4);
     const float* xw = x + td.src_row;
     _Float16* ow = out + (size_t)td.seg_row * ROWH;
     const int hoff = (c4 >> 5) * 64 + (c4 & 31);
-    const int tend = td.t0 + BM < td.seg_len ? td.t0 + BM : td.seg_len;
-    for (int t = td.t0 + (threadIdx.x >> 6); t < tend; t += 4) {
+    const int tend = td.t0 + 32 < td.seg_len ? td.t0 + 32 : td.seg_len;
+    for (int t = td.t0; t < tend; t++) {
         const float x2 = xw[t];
         const float x1 = t - dil >= 0 ? xw[t - dil] : 0.f;
         const float x0 = t - 2 * dil >= 0 ? xw[t - 2 * dil] : 0.f;
@@ -627,15 +654,15 @@ __global__ __launch_bounds__(256) void tcn_in_split_kernel(const float* __restri
     }
 }
 
-int timer_begin(rd_ctx* ctx, KernelTimer& tm)
+int timer_begin(hipStream_t st, KernelTimer& tm)
 {
-    if (tm.enabled && tm.used < tm.starts.size()) RD_HIP(hipEventRecord(tm.starts[tm.used], ctx->stream));
+    if (tm.enabled && tm.used < tm.starts.size()) RD_HIP(hipEventRecord(tm.starts[tm.used], st));
     return RD_OK;
 }
-int timer_end(rd_ctx* ctx, KernelTimer& tm, double flops, double bytes)
+int timer_end(hipStream_t st, KernelTimer& tm, double flops, double bytes)
 {
     if (tm.enabled && tm.used < tm.starts.size()) {
-        RD_HIP(hipEventRecord(tm.stops[tm.used], ctx->stream));
+        RD_HIP(hipEventRecord(tm.stops[tm.used], st));
         tm.used++;
         tm.flops += flops;
         tm.bytes += bytes;
@@ -646,10 +673,111 @@ int timer_end(rd_ctx* ctx, KernelTimer& tm, double flops, double bytes)
 }  // namespace
 
 // Forward over a set of independent SEGMENTS packed in one row space: d_signal [*] fp32 (already MAD-normalised),
-// per-layer tile lists (every segment cut into tiles of <= 128 rows) -> d_probs [total_rows][5].
+// per-layer tile lists -> d_probs [total_rows][5].
 // A segment is causally zero-padded at its own start; nothing leaks between segments (heads read their later rows
-// from their read's stream, see TileDesc).  Three activation tensors: X_a / X_b (block input / output, ping-pong --
-// a head tile reads stream rows of the block input while stream tiles write the block output) and MID.
+// from their read's stream, see TileDesc).  Three activation tensors: X_a / X_b (block input / output, ping-pong) and
+// MID.
+namespace {
+
+int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2 conv1, 3 head*/, const TileDesc* tiles, int n,
+                double rows, const float* d_signal, float* Xin, float* Xout, float* MID, float* d_probs)
+{
+    if (n <= 0) return RD_OK;
+    Model& m = ctx->model;
+    const bool split = ctx->precision == 1;
+    int rc;
+    if (kind == 0) {
+        if ((rc = timer_begin(st, ctx->timer_in))) return rc;
+        if (split)
+            hipLaunchKernelGGL(tcn_in_split_kernel, dim3(n), dim3(256), 0, st, d_signal, m.w_in, m.b_in, (_Float16*)MID, tiles, m.dil[0]);
+        else
+            hipLaunchKernelGGL(tcn_in_kernel, dim3(n), dim3(256), 0, st, d_signal, m.w_in, m.b_in, MID, tiles, m.dil[0]);
+        RD_HIP(hipGetLastError());
+        return timer_end(st, ctx->timer_in, 2.0 * rows * RD_C * RD_K, rows * (RD_C * 4.0 + 4.0));
+    }
+    if (kind == 3) {
+        if ((rc = timer_begin(st, ctx->timer_head))) return rc;
+        if (split) {
+            SplitArgs h = {};
+            h.zeros = m.zeros;
+            h.sink = m.sink;
+            h.tiles = tiles;
+            h.in = (const _Float16*)Xin;
+            h.wpk = (const _Float16*)m.ws_d1;
+            h.inv_scale = m.inv_scale_d1;
+            h.bias = m.b_d1;
+            h.w2 = m.w_d2;
+            h.b2 = m.b_d2;
+            h.probs = d_probs;
+            hipLaunchKernelGGL((tcn_gemm_split_kernel<2, 1, EPI_HEAD>), dim3(n), dim3(256), 0, st, h);
+        } else {
+            ConvArgs h = {};
+            h.zeros = m.zeros;
+            h.sink = m.sink;
+            h.tiles = tiles;
+            h.in = Xin;
+            h.wpk = m.w_d1;
+            h.bias = m.b_d1;
+            h.w2 = m.w_d2;
+            h.b2 = m.b_d2;
+            h.probs = d_probs;
+            hipLaunchKernelGGL((tcn_gemm_kernel<2, 1, EPI_HEAD>), dim3(n), dim3(256), 0, st, h);
+        }
+        RD_HIP(hipGetLastError());
+        return timer_end(st, ctx->timer_head, 2.0 * rows * (RD_C * RD_H + RD_H * 5), rows * (RD_C * 4.0 + 20.0));
+    }
+    const int wi = 2 * b + (kind == 2 ? 1 : 0);
+    ConvArgs a = {};
+    a.zeros = m.zeros;
+    a.sink = m.sink;
+    a.dil = m.dil[b];
+    a.tiles = tiles;
+    a.wpk = m.w_conv[wi];
+    a.bias = m.b_conv[wi];
+    SplitArgs sa = {};
+    sa.zeros = m.zeros;
+    sa.sink = m.sink;
+    sa.dil = m.dil[b];
+    sa.tiles = tiles;
+    sa.wpk = (const _Float16*)m.ws_conv[wi];
+    sa.inv_scale = m.inv_scale[wi];
+    sa.bias = m.b_conv[wi];
+    if (kind == 1) {
+        a.in = Xin;
+        a.out = MID;
+        sa.in = (const _Float16*)Xin;
+        sa.out = (_Float16*)MID;
+    } else {
+        a.in = MID;
+        a.out = Xout;
+        a.resid = Xin;
+        a.x = d_signal;
+        a.wmatch = m.w_match;
+        a.bmatch = m.b_match;
+        sa.in = (const _Float16*)MID;
+        sa.out = (_Float16*)Xout;
+        sa.resid = (const _Float16*)Xin;
+        sa.x = d_signal;
+        sa.wmatch = m.w_match;
+        sa.bmatch = m.b_match;
+    }
+    if ((rc = timer_begin(st, ctx->timer_conv))) return rc;
+    if (kind == 1) {
+        if (split) hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RELU>), dim3(n), dim3(256), 0, st, sa);
+        else hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RELU>), dim3(n), dim3(256), 0, st, a);
+    } else if (b == 0) {
+        if (split) hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RES_MATCH>), dim3(n), dim3(256), 0, st, sa);
+        else hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_MATCH>), dim3(n), dim3(256), 0, st, a);
+    } else {
+        if (split) hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RES_IDENT>), dim3(n), dim3(256), 0, st, sa);
+        else hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_IDENT>), dim3(n), dim3(256), 0, st, a);
+    }
+    RD_HIP(hipGetLastError());
+    return timer_end(st, ctx->timer_conv, 2.0 * rows * RD_C * RD_C * RD_K, (kind == 2 && b > 0 ? 3.0 : 2.0) * rows * RD_C * 4.0);
+}
+
+}  // namespace
+
 int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl, int64_t total_rows, float* d_probs)
 {
     Model& m = ctx->model;
@@ -664,132 +792,16 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl
     float* Xin = ctx->ws_act0.as<float>();
     float* Xout = ctx->ws_act1.as<float>();
     float* MID = ctx->ws_act2.as<float>();
-    const bool split = ctx->precision == 1;
-    auto rows_of = [&](int li) {   // time steps this layer evaluates (tiles * 128 is an upper bound; the lists know the truth)
-        return (double)tl.rows[li];
-    };
-
-    for (int b = 0; b < m.nblocks; b++) {
-        const int d = m.dil[b];
-        ConvArgs a = {};
-        a.zeros = m.zeros;
-        a.sink = m.sink;
-        a.dil = d;
-        SplitArgs sa = {};
-        sa.zeros = m.zeros;
-        sa.sink = m.sink;
-        sa.dil = d;
-        if (b == 0) {
-            // conv0: 1 -> 256 on the VALU
-            const int li = 0;
-            if (tl.n[li]) {
-                if ((rc = timer_begin(ctx, ctx->timer_in))) return rc;
-                if (split)
-                    hipLaunchKernelGGL(tcn_in_split_kernel, dim3(tl.n[li]), dim3(256), 0, ctx->stream, d_signal, m.w_in, m.b_in, (_Float16*)MID, tl.d[li], d);
-                else
-                    hipLaunchKernelGGL(tcn_in_kernel, dim3(tl.n[li]), dim3(256), 0, ctx->stream, d_signal, m.w_in, m.b_in, MID, tl.d[li], d);
-                RD_HIP(hipGetLastError());
-                if ((rc = timer_end(ctx, ctx->timer_in, 2.0 * rows_of(li) * RD_C * RD_K, rows_of(li) * (RD_C * 4.0 + 4.0)))) return rc;
-            }
-        } else {
-            const int li = 2 * b;
-            a.in = Xin;
-            a.out = MID;
-            a.wpk = m.w_conv[2 * b];
-            a.bias = m.b_conv[2 * b];
-            a.tiles = tl.d[li];
-            sa.in = (const _Float16*)Xin;
-            sa.out = (_Float16*)MID;
-            sa.wpk = (const _Float16*)m.ws_conv[2 * b];
-            sa.inv_scale = m.inv_scale[2 * b];
-            sa.bias = m.b_conv[2 * b];
-            sa.tiles = tl.d[li];
-            if (tl.n[li]) {
-                if ((rc = timer_begin(ctx, ctx->timer_conv))) return rc;
-                if (split)
-                    hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RELU>), dim3(tl.n[li]), dim3(256), 0, ctx->stream, sa);
-                else
-                    hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RELU>), dim3(tl.n[li]), dim3(256), 0, ctx->stream, a);
-                RD_HIP(hipGetLastError());
-                if ((rc = timer_end(ctx, ctx->timer_conv, 2.0 * rows_of(li) * RD_C * RD_C * RD_K, 2.0 * rows_of(li) * RD_C * 4.0))) return rc;
-            }
+    const int nl = 2 * m.nblocks + 1;
+    for (int li = 0; li < nl; li++) {
+        const int b = li == nl - 1 ? m.nblocks : li / 2;
+        const int kind = li == nl - 1 ? 3 : (li == 0 ? 0 : (li & 1 ? 2 : 1));
+        if ((rc = launch_layer(ctx, ctx->stream, b, kind, tl.d[li], tl.n[li], (double)tl.rows[li], d_signal, Xin, Xout, MID, d_probs))) return rc;
+        if (kind == 2) {   // block finished: its output becomes the next block's input
+            float* t = Xin;
+            Xin = Xout;
+            Xout = t;
         }
-        // second conv + relu, + residual (block 0: 1x1 match from the raw sample; else the block input) + relu
-        const int li = 2 * b + 1;
-        a.in = MID;
-        a.out = Xout;
-        a.resid = Xin;
-        a.wpk = m.w_conv[2 * b + 1];
-        a.bias = m.b_conv[2 * b + 1];
-        a.x = d_signal;
-        a.wmatch = m.w_match;
-        a.bmatch = m.b_match;
-        a.tiles = tl.d[li];
-        sa.in = (const _Float16*)MID;
-        sa.out = (_Float16*)Xout;
-        sa.resid = (const _Float16*)Xin;
-        sa.wpk = (const _Float16*)m.ws_conv[2 * b + 1];
-        sa.inv_scale = m.inv_scale[2 * b + 1];
-        sa.bias = m.b_conv[2 * b + 1];
-        sa.x = d_signal;
-        sa.wmatch = m.w_match;
-        sa.bmatch = m.b_match;
-        sa.tiles = tl.d[li];
-        if (tl.n[li]) {
-            if ((rc = timer_begin(ctx, ctx->timer_conv))) return rc;
-            if (b == 0) {
-                if (split)
-                    hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RES_MATCH>), dim3(tl.n[li]), dim3(256), 0, ctx->stream, sa);
-                else
-                    hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_MATCH>), dim3(tl.n[li]), dim3(256), 0, ctx->stream, a);
-            } else {
-                if (split)
-                    hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RES_IDENT>), dim3(tl.n[li]), dim3(256), 0, ctx->stream, sa);
-                else
-                    hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_IDENT>), dim3(tl.n[li]), dim3(256), 0, ctx->stream, a);
-            }
-            RD_HIP(hipGetLastError());
-            if ((rc = timer_end(ctx, ctx->timer_conv, 2.0 * rows_of(li) * RD_C * RD_C * RD_K,
-                                (b == 0 ? 2.0 : 3.0) * rows_of(li) * RD_C * 4.0)))
-                return rc;
-        }
-        float* t = Xin;
-        Xin = Xout;
-        Xout = t;
-    }
-    const int li = 2 * m.nblocks;
-    if (tl.n[li]) {
-        if ((rc = timer_begin(ctx, ctx->timer_head))) return rc;
-        if (split) {
-            SplitArgs h = {};
-            h.zeros = m.zeros;
-            h.sink = m.sink;
-            h.tiles = tl.d[li];
-            h.dil = 0;
-            h.in = (const _Float16*)Xin;
-            h.wpk = (const _Float16*)m.ws_d1;
-            h.inv_scale = m.inv_scale_d1;
-            h.bias = m.b_d1;
-            h.w2 = m.w_d2;
-            h.b2 = m.b_d2;
-            h.probs = d_probs;
-            hipLaunchKernelGGL((tcn_gemm_split_kernel<2, 1, EPI_HEAD>), dim3(tl.n[li]), dim3(256), 0, ctx->stream, h);
-        } else {
-            ConvArgs h = {};
-            h.zeros = m.zeros;
-            h.sink = m.sink;
-            h.tiles = tl.d[li];
-            h.dil = 0;
-            h.in = Xin;
-            h.wpk = m.w_d1;
-            h.bias = m.b_d1;
-            h.w2 = m.w_d2;
-            h.b2 = m.b_d2;
-            h.probs = d_probs;
-            hipLaunchKernelGGL((tcn_gemm_kernel<2, 1, EPI_HEAD>), dim3(tl.n[li]), dim3(256), 0, ctx->stream, h);
-        }
-        RD_HIP(hipGetLastError());
-        if ((rc = timer_end(ctx, ctx->timer_head, 2.0 * rows_of(li) * (RD_C * RD_H + RD_H * 5), rows_of(li) * (RD_C * 4.0 + 20.0)))) return rc;
     }
     return RD_OK;
 }
@@ -797,26 +809,29 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl
 // Tile descriptors of nW uniform windows of T rows; cached on the device per (nW, T).  One list serves every layer.
 int rd_uniform_tiles(rd_ctx* ctx, int nW, int T, TileLists* out)
 {
-    const int tiles = (T + BM - 1) / BM;
-    const size_t n = (size_t)nW * tiles;
+    const int subs = (T + 31) / 32;                                  // 32-row sub-tiles per window
+    const size_t nsub = (size_t)nW * subs;
+    const size_t n = (nsub + 3) / 4;                                  // workgroup tiles (four sub-tiles each)
     if (ctx->tiles_nW != nW || ctx->tiles_T != T) {
-        std::vector<TileDesc> h(n);
-        for (int w = 0; w < nW; w++)
-            for (int k = 0; k < tiles; k++) {
-                TileDesc& td = h[(size_t)w * tiles + k];
-                td.seg_row = (int64_t)w * T;
-                td.src_row = (int64_t)w * T;
-                td.alt_row = (int64_t)w * T;
-                td.t0 = k * BM;
-                td.seg_len = T;
-                td.in_len = T;
-                td.alt_in = INT32_MAX;
-                td.alt_res = INT32_MAX;
-                td.pad_ = 0;
-            }
-        if (ctx->ws_tiles.reserve(n * sizeof(TileDesc))) return RD_ERR_NOMEM;
+        std::vector<TileDesc> h(n * 4);
+        for (size_t i = 0; i < n * 4; i++) {
+            TileDesc& td = h[i];
+            const size_t w = i / subs;
+            const int k = (int)(i % subs);
+            const bool real = i < nsub;
+            td.seg_row = real ? (int64_t)w * T : 0;
+            td.src_row = td.seg_row;
+            td.alt_row = td.seg_row;
+            td.t0 = real ? k * 32 : 0;
+            td.seg_len = real ? T : 0;                                // padding sub-tiles are empty
+            td.in_len = td.seg_len;
+            td.alt_in = INT32_MAX;
+            td.alt_res = INT32_MAX;
+            td.pad_ = 0;
+        }
+        if (ctx->ws_tiles.reserve(h.size() * sizeof(TileDesc))) return RD_ERR_NOMEM;
         RD_HIP(hipStreamSynchronize(ctx->stream));   // no forward may still be reading the previous descriptors
-        RD_HIP(hipMemcpy(ctx->ws_tiles.p, h.data(), n * sizeof(TileDesc), hipMemcpyHostToDevice));
+        RD_HIP(hipMemcpy(ctx->ws_tiles.p, h.data(), h.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
         ctx->tiles_nW = nW;
         ctx->tiles_T = T;
     }
