@@ -3,7 +3,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libradian_hip.so")
+LIB_PATH = os.environ.get("RADIAN_HIP_LIB") or os.path.join(HERE, "libradian_hip.so")   # override: kernel experiments only
 
 c_i = ctypes.c_int
 c_i32p = ctypes.POINTER(ctypes.c_int32)

@@ -17,17 +17,18 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+def build(force=False, verbose=False, defines=(), out=None):
+    """defines/out: build an experiment variant (-D...) into another file (tools_variants.sh); the product build uses neither."""
+    if not force and not _stale() and out is None:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in SOURCES:
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        obj = os.path.join(HERE, "build", src.replace(".hip", ".o") if out is None else os.path.basename(out) + "." + src.replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function",
-               "-I/opt/rocm/include", "-c", os.path.join(CSRC, src), "-o", obj]
+               "-I/opt/rocm/include", *[f"-D{d}" for d in defines], "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))
@@ -35,10 +36,12 @@ def build(force=False, verbose=False):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out or LIB] + objs + ["-ldl"]
     subprocess.check_call(cmd)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    outs = [a[2:] for a in sys.argv[1:] if a.startswith("-o")]
+    print(build(force="--force" in sys.argv, verbose=True, defines=defs, out=outs[0] if outs else None))

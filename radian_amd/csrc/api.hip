@@ -221,17 +221,18 @@ void model_bind(Model& m, const ModelLayout& L)
 }
 
 // LDS image order (forward.hip): rows of 32 floats whose 16-B slots are XOR-swizzled by (row >> 1) & 7.
-static inline int swz_k(int row, int k) { return ((((k >> 2) ^ ((row >> 1) & 7)) << 2) | (k & 3)); }
+// fp32 image: 64-B rows (16 floats), 16-B slot XOR (row >> 2) & 3 -- the LDS image of forward.hip's half-stages
+static inline int swz_k(int row, int k) { return ((((k >> 2) ^ ((row >> 2) & 3)) << 2) | (k & 3)); }
 
-// Keras conv kernel [j][ci][co] -> [chunk = (ci/32)*3 + j][co][swizzled ci%32]
+// Keras conv kernel [j][ci][co] -> [chunk = (ci/16)*3 + j][co][swizzled ci%16]
 void pack_conv(const float* k, float* dst)
 {
     for (int j = 0; j < RD_K; j++)
         for (int ci = 0; ci < RD_C; ci++) {
             const float* src = k + ((size_t)j * RD_C + ci) * RD_C;
-            const int chunk = (ci / 32) * RD_K + j;
-            float* d = dst + (size_t)chunk * RD_C * 32;
-            for (int co = 0; co < RD_C; co++) d[(size_t)co * 32 + swz_k(co, ci % 32)] = src[co];
+            const int chunk = (ci / 16) * RD_K + j;
+            float* d = dst + (size_t)chunk * RD_C * 16;
+            for (int co = 0; co < RD_C; co++) d[(size_t)co * 16 + swz_k(co, ci % 16)] = src[co];
         }
 }
 
@@ -240,8 +241,8 @@ void pack_dense(const float* k, float* dst)
 {
     for (int ci = 0; ci < RD_C; ci++) {
         const float* src = k + (size_t)ci * RD_H;
-        float* d = dst + (size_t)(ci / 32) * RD_H * 32;
-        for (int h = 0; h < RD_H; h++) d[(size_t)h * 32 + swz_k(h, ci % 32)] = src[h];
+        float* d = dst + (size_t)(ci / 16) * RD_H * 16;
+        for (int h = 0; h < RD_H; h++) d[(size_t)h * 16 + swz_k(h, ci % 16)] = src[h];
     }
 }
 

@@ -7,24 +7,25 @@
 // with match = 1x1 conv in block 0 (C_in 1 -> 256) and identity elsewhere; causal padding means
 //   out[t] = b + sum_j W[j] . x[t - (K-1-j) d]   with x[<0] = 0 inside each window.
 //
-// Layout in HBM: activations [window][t][256] fp32 (1 KiB per time step, channel-contiguous), two
-// ping-pong tensors (block input/output and the mid activation; the residual add is in place).
+// Layout in HBM: activations [row][256] fp32 (1 KiB per time step, channel-contiguous) in ONE row space shared by all
+// segments of a batch (windows, whole reads, window heads -- see TileDesc); three tensors: block input, block output
+// (ping-pong) and the mid activation.
 // Weights are repacked once at load into the exact LDS image of each K-chunk:
-//   conv  [chunk = tap*8 + ci/32][co 0..255][ci%32]     (32 KiB per chunk, 24 chunks per conv)
-//   dense [chunk = ci/32]        [h  0..127][ci%32]
+//   conv  [chunk = (ci/16)*3 + tap][co 0..255][ci%16]     (16 KiB per chunk, 48 chunks per conv)
+//   dense [chunk = ci/16]          [h  0..127][ci%16]
 //
-// The dilated conv is an implicit GEMM  M = windows*T (time), N = 256 (co), K = 768 (tap, ci)  on the
-// exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32 (gfx950 has no TF32; fp32 MFMA = 157 TFLOP/s
-// peak).  One 256-thread workgroup (4 waves, 2x2) owns a 128(t) x 256(co) output tile: all output
-// channels of a time tile, so each activation row is read once per tap.  Per K-chunk (one tap, 32
-// input channels) the A tile (128 shifted rows x 32) and the B tile (256 co x 32) go HBM/L2 -> LDS by
-// LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), 128-B rows with XOR-swizzled
-// 16-B slots (conflict-free ds_read_b128), double buffered with one barrier per chunk; each wave holds
-// a 64 x 128 accumulator (8 MFMA tiles = 128 VGPRs).  One ds_read_b128 feeds four MFMAs: lane (r, h) reads k = 8g+4h .. 8g+4h+3 of its
-// row, and MFMA number kr of the group consumes element kr of both operands, i.e. k-pair
-// (8g+kr, 8g+4+kr).  Bias, ReLU, the residual add (identity or block-0 1x1 match) and the second
-// ReLU are fused into the epilogue.  The head reuses the same core with N = 128, then reduces
-// 128 -> 5 and applies softmax from LDS.
+// The dilated conv is an implicit GEMM  M = rows (time), N = 256 (co), K = 768 (tap, ci)  on the exact-fp32 matrix
+// instruction v_mfma_f32_32x32x2_f32 (gfx950 has no TF32; fp32 MFMA = 157 TFLOP/s peak).  One 256-thread workgroup
+// (4 waves, 2x2) owns a 128(t) x 256(co) output tile: all output channels of a time tile, so each activation row is
+// read once per tap.  Per K-chunk (one tap, 16 input channels) the A tile (128 shifted rows x 16) and the B tile
+// (256 co x 16) go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write) into 64-B rows
+// with XOR-swizzled 16-B slots (conflict-free ds_read_b128).  Three 24-KiB stages, one barrier per chunk, the DMA of
+// chunk c+2 issued piecewise between the MFMAs of chunk c and counted by hand (uncounted inline-asm loads + an explicit
+// s_waitcnt vmcnt(N): with the builtin hipcc drains vmcnt(0) before the next ds_read).  Two workgroups per CU.
+// Each wave holds a 64 x 128 accumulator (8 MFMA tiles = 128 VGPRs).  One ds_read_b128 feeds four MFMAs: lane (r, h)
+// reads k = 8g+4h .. 8g+4h+3 of its row, and MFMA number kr of the group consumes element kr of both operands, i.e.
+// k-pair (8g+kr, 8g+4+kr).  Bias, ReLU, the residual add (identity or block-0 1x1 match) and the second ReLU are fused
+// into the epilogue.  The head reuses the same core with N = 128, then reduces 128 -> 5 and applies softmax from LDS.
 #include "common.h"
 
 #include <stdint.h>
@@ -35,7 +36,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;       // time steps per workgroup tile
-constexpr int BK = 32;        // K-chunk depth
+constexpr int BK = 16;        // K-chunk depth (64-B LDS rows)
 
 enum { EPI_RELU = 0, EPI_RES_IDENT = 1, EPI_RES_MATCH = 2, EPI_HEAD = 3 };
 
@@ -57,14 +58,36 @@ struct ConvArgs {
     int dil;
 };
 
-// LDS image of a K-chunk tile: [row][32 floats] (128-B rows, no padding -- LDS-DMA writes 1 KiB per
-// wave-instruction contiguously), with the 16-B slots of each row XOR-swizzled by (row >> 1) & 7 so that the
-// 16 lanes of a ds_read_b128 group (16 distinct rows, same logical slot) hit 16 different 16-B bank slots of
-// the 256-B bank row.  The swizzle is applied on the global SOURCE address of the DMA and again on the read.
+// LDS image of a K-chunk tile: [row][16 floats] (64-B rows, no padding -- LDS-DMA writes 1 KiB per wave-instruction
+// contiguously), with the four 16-B slots of each row XOR-swizzled by (row >> 2) & 3: the 16 lanes of a ds_read_b128
+// group hold four runs of 4 consecutive rows (row & 3 = 0..3 picks the 64-B quarter of the 256-B bank row) whose
+// row >> 2 differ mod 4, so the group hits 16 different 16-B bank slots.  The swizzle is applied on the global SOURCE
+// address of the DMA and again on the read.  (The split-f16 kernel below keeps 128-B rows and (row >> 1) & 7.)
 __device__ __forceinline__ void glds16(const float* src, float* lds_dst)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// The same instruction outside hipcc's s_waitcnt bookkeeping: with the builtin, hipcc drains vmcnt(0) before the first
+// ds_read that follows (it cannot tell the two LDS halves apart), which would serialise the prefetch of the next chunk
+// with the MFMAs of this one.  The kernel counts these loads by hand (wait_dma()).  M0 carries the wave-uniform LDS
+// byte address and is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void glds16_uncounted(const float* src, float* lds_dst)
+{
+    unsigned keep;
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(dst)
+                 : "memory");
+}
+// All but the newest LEAVE LDS-DMA instructions of this wave have landed (loads return in order); then the workgroup
+// barrier: everyone's pieces of that chunk are in LDS and every wave is past its reads of the stage overwritten next.
+template <int LEAVE>
+__device__ __forceinline__ void wait_dma_and_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LEAVE) : "memory");
 }
 
 template <int NT, int TAPS, int EPI>
@@ -72,13 +95,12 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
 {
     constexpr int BN = 2 * NT * 32;       // output channels per workgroup (2 waves along N)
     constexpr int NCHUNK = TAPS * (RD_C / BK);
-    constexpr int STAGE_FLOATS = (BM + BN) * BK;   // ONE stage: two workgroups per CU cover each other's DMA latency
+    constexpr int STAGE_FLOATS = (BM + BN) * BK;   // one K-chunk of A and B
     constexpr int HEAD_FLOATS = BM * (RD_H + 1) + RD_H * 5 + 8;
-    constexpr int SMEM_FLOATS = (EPI == EPI_HEAD && HEAD_FLOATS > STAGE_FLOATS) ? HEAD_FLOATS : STAGE_FLOATS;
+    constexpr int NSTAGE = 3;
+    constexpr int SMEM_FLOATS = (EPI == EPI_HEAD && HEAD_FLOATS > NSTAGE * STAGE_FLOATS) ? HEAD_FLOATS : NSTAGE * STAGE_FLOATS;
 
-    __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];  // 48 KiB (conv) / 67 KiB (head)
-    float* As = smem;                  // [BM][BK]
-    float* Bs = smem + BM * BK;        // [BN][BK]
+    __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];  // 2 x 24 KiB (conv) / 67 KiB (head)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -93,47 +115,37 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
     const TileDesc sdm[2] = {tds[wm * 2], tds[wm * 2 + 1]};           // this wave's two sub-tiles
     const bool mval[2] = {sdm[0].seg_len > sdm[0].t0, sdm[1].seg_len > sdm[1].t0};
 
-    // DMA roles: a wave-instruction moves 8 rows x 128 B; lane -> (row-in-piece, physical 16-B slot)
-    const int dma_r = lane >> 3;
-    const int dma_ps = lane & 7;
+    // DMA roles, fixed for the whole tile: a wave-instruction moves 16 rows x 64 B; lane -> (row-in-piece, physical
+    // 16-B slot).  Wave w stages sub-tile w (two pieces), so the descriptor fields it needs are wave-uniform scalars.
+    const int dma_r = lane >> 2;
+    const int dma_ps = lane & 3;
+    const TileDesc sst = tds[wave];
+    const int64_t d_seg = sst.seg_row, d_alt = sst.alt_row;
+    const int d_t0 = sst.t0, d_ain = sst.alt_in;
+    const int d_len = sst.seg_len > sst.t0 ? sst.in_len : 0;            // empty sub-tile: zero page only
+    const int lane_slot = (dma_ps ^ ((dma_r >> 2) & 3)) * 4;           // (tile row >> 2) & 3 = (dma_r >> 2) & 3
 
-    // DMA roles, fixed for the whole tile: sub-tile r's rows 8*wave .. 8*wave+7 are this wave's piece of it.  The
-    // descriptor fields are wave-uniform (scalar registers); per lane there is only its row in the piece and its slot.
-    int64_t d_seg[BM / 32], d_alt[BM / 32];
-    int d_t0[BM / 32], d_len[BM / 32], d_ain[BM / 32];
-#pragma unroll
-    for (int r = 0; r < BM / 32; r++) {
-        const TileDesc sd = tds[r];
-        d_seg[r] = sd.seg_row;
-        d_alt[r] = sd.alt_row;
-        d_t0[r] = sd.t0;
-        d_len[r] = sd.seg_len > sd.t0 ? sd.in_len : 0;   // empty sub-tile: zero page only
-        d_ain[r] = sd.alt_in;
-    }
-    const int lane_t = wave * 8 + dma_r;                          // this lane's row inside every sub-tile
-    const int lane_slot = (dma_ps ^ ((wave * 4 + (dma_r >> 1)) & 7)) * 4;   // (tile row >> 1) & 7 does not depend on r
-
-    auto stage = [&](int chunk) {
-        // chunk order: input-channel chunk outer, tap inner -> the three shifted reads of the same rows are adjacent in time
-        const int cc = chunk / TAPS;
-        const int tap = chunk - cc * TAPS;
-        const int ci0 = cc * BK;
-        const int shift = (TAPS - 1 - tap) * a.dil;
-#pragma unroll
-        for (int r = 0; r < BM / 32; r++) {
-            const int piece = r * 4 + wave;            // 1 KiB piece = tile rows 8*piece .. 8*piece+7
-            const int t = d_t0[r] + lane_t - shift;
-            const float* src = (t >= 0 && t < d_len[r])
-                                   ? a.in + ((size_t)(t < d_ain[r] ? d_seg[r] : d_alt[r]) + t) * RD_C + ci0 + lane_slot
-                                   : a.zeros + dma_ps * 4;
-            glds16(src, As + piece * 256);
+    // one piece (wave-instruction) of a chunk's staging: pieces 0,1 = this wave's two 16-row pieces of A, 2.. = its share of B
+    constexpr int NPIECE = 2 + BN / 64;
+    auto stage_piece = [&](int chunk, float* st, int pc) {
+        // chunk order: input-channel slice outer, tap inner -> the three shifted reads of the same rows are adjacent in time
+        if (pc < 2) {
+            const int cc = chunk / TAPS;
+            const int tap = chunk - cc * TAPS;
+            const int shift = (TAPS - 1 - tap) * a.dil;
+            const int t = d_t0 + pc * 16 + dma_r - shift;
+            const float* src = (t >= 0 && t < d_len) ? a.in + ((size_t)(t < d_ain ? d_seg : d_alt) + t) * RD_C + cc * BK + lane_slot
+                                                     : a.zeros + dma_ps * 4;
+            glds16_uncounted(src, st + (wave * 2 + pc) * 256);   // 1 KiB piece = tile rows 16*piece .. 16*piece+15
+        } else {
+            const int piece = (pc - 2) * 4 + wave;
+            const float* wsrc = a.wpk + (size_t)chunk * BN * BK + lane * 4;   // pre-swizzled on the host: linear copy
+            glds16_uncounted(wsrc + piece * 256, st + BM * BK + piece * 256);
         }
-        const float* wsrc = a.wpk + (size_t)chunk * BN * BK + lane * 4;   // pre-swizzled on the host: linear copy
+    };
+    auto stage = [&](int chunk, float* st) {
 #pragma unroll
-        for (int r = 0; r < BN / 32; r++) {
-            const int piece = r * 4 + wave;
-            glds16(wsrc + piece * 256, Bs + piece * 256);
-        }
+        for (int pc = 0; pc < NPIECE; pc++) stage_piece(chunk, st, pc);
     };
 
     f32x16 acc[2][NT];
@@ -146,39 +158,68 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
 
     const int fr = lane & 31;
     const int fh = lane >> 5;
-    const int swz = (fr >> 1) & 7;
+    const int swz = (fr >> 2) & 3;
     int koff[BK / 8];
 #pragma unroll
     for (int g = 0; g < BK / 8; g++) koff[g] = ((2 * g + fh) ^ swz) * 4;
-    const float* Ab = As + (wm * 64 + fr) * BK;
-    const float* Bb = Bs + (wn * NT * 32 + fr) * BK;
+    const int a_off = (wm * 64 + fr) * BK;
+    const int b_off = BM * BK + (wn * NT * 32 + fr) * BK;
 
-    for (int chunk = 0; chunk < NCHUNK; chunk++) {
-        if (chunk) __syncthreads();          // every wave has read the previous chunk out of LDS
-        stage(chunk);
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's DMA pieces have landed
-        __syncthreads();                     // ... and everyone else's
-        if (mval[0] || mval[1])   // (tiles are packed, so a wave with work almost always has both sub-tiles)
+    // One chunk: multiply the landed stage while the chunk after next is issued into the stage that was read last.  The
+    // DMA pieces go out one by one between groups of 2 x NT MFMAs, so their address arithmetic issues in the shadow of
+    // the matrix pipe instead of in front of it; the second k-group's fragments are requested after the first group of
+    // MFMAs (their LDS latency sits under the other 3 groups).  sched_barrier pins that order.
+    const bool work = mval[0] || mval[1];   // (tiles are packed, so a wave with work almost always has both sub-tiles)
+    auto chunk_step = [&](const float* st, int next, float* nst) {
+        const float* Ab = st + a_off;
+        const float* Bb = st + b_off;
+        float4 af[BK / 8][2], bf[BK / 8][NT];
+        auto rd = [&](int g) {
 #pragma unroll
-        for (int g = 0; g < BK / 8; g++) {
-            float4 af[2], bf[NT];
+            for (int m = 0; m < 2; m++) af[g][m] = *(const float4*)(Ab + m * 32 * BK + koff[g]);
 #pragma unroll
-            for (int m = 0; m < 2; m++) af[m] = *(const float4*)(Ab + m * 32 * BK + koff[g]);
+            for (int n = 0; n < NT; n++) bf[g][n] = *(const float4*)(Bb + n * 32 * BK + koff[g]);
+        };
+        auto mm = [&](int g, int kr) {
 #pragma unroll
-            for (int n = 0; n < NT; n++) bf[n] = *(const float4*)(Bb + n * 32 * BK + koff[g]);
+            for (int m = 0; m < 2; m++) {
+                const float av = kr == 0 ? af[g][m].x : kr == 1 ? af[g][m].y : kr == 2 ? af[g][m].z : af[g][m].w;
 #pragma unroll
-            for (int kr = 0; kr < 4; kr++) {
-#pragma unroll
-                for (int m = 0; m < 2; m++) {
-                    const float av = kr == 0 ? af[m].x : kr == 1 ? af[m].y : kr == 2 ? af[m].z : af[m].w;
-#pragma unroll
-                    for (int n = 0; n < NT; n++) {
-                        const float bv = kr == 0 ? bf[n].x : kr == 1 ? bf[n].y : kr == 2 ? bf[n].z : bf[n].w;
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0);
-                    }
+                for (int n = 0; n < NT; n++) {
+                    const float bv = kr == 0 ? bf[g][n].x : kr == 1 ? bf[g][n].y : kr == 2 ? bf[g][n].z : bf[g][n].w;
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0);
                 }
             }
+        };
+        const bool st_ok = next < NCHUNK;
+        if (work) rd(0);
+#pragma unroll
+        for (int i = 0; i < BK / 2; i++) {
+            if (work) mm(i >> 2, i & 3);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i == 0 && work) rd(1);
+            if (st_ok && i < NPIECE) stage_piece(next, nst, i);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+
+    // Three stages of one K-chunk each, one barrier per chunk: while chunk c is multiplied, chunk c+1 is landing and chunk
+    // c+2 is issued, so a row that comes from HBM has two chunk times; the wait at the top of a chunk leaves the newest
+    // chunk's NPIECE instructions in flight.  (Two workgroups per CU: 2 x 72 KiB of LDS, 2 waves per SIMD.)
+    static_assert(NPIECE <= BK / 2, "one DMA piece per MFMA group");
+    float* st0 = smem;
+    float* st1 = smem + STAGE_FLOATS;
+    float* st2 = smem + 2 * STAGE_FLOATS;
+    stage(0, st0);
+    stage(1, st1);
+    auto step = [&](int c, const float* st, float* nst) {
+        if (c + 1 < NCHUNK) wait_dma_and_barrier<NPIECE>(); else wait_dma_and_barrier<0>();
+        chunk_step(st, c + 2, nst);
+    };
+    for (int chunk = 0; chunk < NCHUNK; chunk += 3) {
+        step(chunk, st0, st2);
+        if (chunk + 1 < NCHUNK) step(chunk + 1, st1, st0);
+        if (chunk + 2 < NCHUNK) step(chunk + 2, st2, st1);
     }
     __syncthreads();   // every wave is done with the staging LDS: the epilogues reuse it
 
@@ -382,6 +423,7 @@ template <int NT, int TAPS, int EPI>
 __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
 {
     constexpr int BN = 2 * NT * 32;
+    constexpr int BK = 32;                // input channels per chunk: a row is [32 hi | 32 lo] f16 = 128 B
     constexpr int NCHUNK = TAPS * (RD_C / BK);
     constexpr int STAGE_FLOATS = (BM + BN) * BK;
     constexpr int HEAD_FLOATS = BM * (RD_H + 1) + RD_H * 5 + 8;
