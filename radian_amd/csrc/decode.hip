@@ -36,6 +36,17 @@ __device__ __forceinline__ double lae(double x, double y)
     return hi + log1p(exp(lo - hi));
 }
 
+// The workgroup IS one wave (launch bounds 64), so LDS hand-offs between lanes need no s_barrier and -- the point -- no
+// s_waitcnt vmcnt(0): __syncthreads() would also wait for the acknowledgement of the trie stores to HBM of every time
+// step (~1-2 us each on a loaded chip).  LDS operations of one wave execute in order; the fences keep the compiler from
+// moving LDS accesses across the hand-off.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // decode.py:16-17
 __device__ __forceinline__ double safe_log(double x) { return x == 0.0 ? -INFINITY : log(x); }
 
@@ -79,7 +90,6 @@ struct DecodeArgs {
 template <typename PT, int R, bool LM>
 __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
 {
-    constexpr int NC = Cfg<R>::NC;
     constexpr int WM = Cfg<R>::WM;
     const int lane = threadIdx.x;
     const int seq = blockIdx.x;
@@ -94,7 +104,6 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
     const unsigned ctx_mask = LM ? ((a.k >= 16) ? 0xffffffffu : ((1u << (2 * a.k)) - 1u)) : 0u;
 
     __shared__ BeamState<WM> st[2];
-    __shared__ double keys[NC];
     __shared__ double cpy_pnb[WM], cpy_tot[WM], cpy_pb[WM], mb_v[WM], mP[WM], mQ[WM];
     __shared__ int mb_q[WM];
     __shared__ int d_copy[WM], d_par[WM], d_c[WM];
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
     int nb = 1;        // beams currently kept (wave-uniform)
     int next_id = 1;   // next free trie node id (wave-uniform)
     int cur = 0;
-    __syncthreads();
+    wave_sync();
 
     for (int t0 = 0; t0 < T; t0 += 64) {
         // ---- per-tile prepass: one lane per time step computes the 5 log-probabilities (decode.py:165,168,193,195
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
 
         const int tend = (T - t0) < 64 ? (T - t0) : 64;
         for (int tt = 0; tt < tend; tt++) {
@@ -239,26 +248,23 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                     }
                 }
             }
-            __syncthreads();
+            wave_sync();
 
             // ---------------- Phase C: which extension equals which kept labeling? ----------------------
+            const int node_reg = lane < nb ? os.node[lane] : -1;   // beam j's trie id lives in lane j
 #pragma unroll
             for (int s = 0; s < R; s++) {
-                if (valid[s] && kk[s] > 0) {
-                    const int x = os.child[kk[s] - 1][bi[s]];
-                    if (x != 0) {
-                        int found = -1;
-                        for (int j = 0; j < nb; j++)
-                            if (os.node[j] == x) found = j;
-                        if (found >= 0) {
-                            pj[s] = found;
-                            mb_q[found] = s * 64 + lane;
-                            mb_v[found] = c_ptot[s];
-                        }
-                    }
+                const int x = (valid[s] && kk[s] > 0) ? os.child[kk[s] - 1][bi[s]] : 0;
+                int found = -1;
+                for (int j = 0; j < nb; j++)
+                    if (__builtin_amdgcn_readlane(node_reg, j) == x) found = j;
+                if (x != 0 && found >= 0) {
+                    pj[s] = found;
+                    mb_q[found] = s * 64 + lane;
+                    mb_v[found] = c_ptot[s];
                 }
             }
-            __syncthreads();
+            wave_sync();
             bool any_merge = false;
 #pragma unroll
             for (int s = 0; s < R; s++) {
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                         else mQ[pj[s]] = r;
                     }
                 }
-                __syncthreads();
+                wave_sync();
 #pragma unroll
                 for (int s = 0; s < R; s++) {
                     const int q = s * 64 + lane;
@@ -307,23 +313,31 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
             }
 
             // ---------------- Phase D: rank by (pr_total desc, insertion order asc)  decode.py:35-39,145 ------
+            // rank = number of candidates ahead.  Candidate qq's key is broadcast out of its lane's register with
+            // v_readlane (a scalar operand of the compares): no LDS round trip per candidate.
             int nvalid = 0;
+            double key[R];
 #pragma unroll
             for (int s = 0; s < R; s++) {
-                keys[s * 64 + lane] = valid[s] ? c_ptot[s] : __builtin_nan("");
+                key[s] = valid[s] ? c_ptot[s] : __builtin_nan("");
                 nvalid += __popcll(__ballot(valid[s]));
             }
-            __syncthreads();
             int rank[R];
 #pragma unroll
             for (int s = 0; s < R; s++) rank[s] = 0;
-            for (int qq = 0; qq < ncand; qq++) {
-                const double kv = keys[qq];
 #pragma unroll
-                for (int s = 0; s < R; s++) {
-                    const int q = s * 64 + lane;
-                    const bool ahead = (qq < q) ? (kv >= c_ptot[s]) : (kv > c_ptot[s]);
-                    rank[s] += ahead ? 1 : 0;
+            for (int s2 = 0; s2 < R; s2++) {
+                const int cnt = (ncand - s2 * 64) < 64 ? (ncand - s2 * 64) : 64;   // wave-uniform
+                const int klo = __double2loint(key[s2]), khi = __double2hiint(key[s2]);
+                for (int l = 0; l < cnt; l++) {
+                    const double kv = __hiloint2double(__builtin_amdgcn_readlane(khi, l), __builtin_amdgcn_readlane(klo, l));
+                    const int qq = s2 * 64 + l;
+#pragma unroll
+                    for (int s = 0; s < R; s++) {
+                        const int q = s * 64 + lane;
+                        const bool ahead = (kv > key[s]) || (kv == key[s] && qq < q);
+                        rank[s] += ahead ? 1 : 0;
+                    }
                 }
             }
             const int nb_new = nvalid < W ? nvalid : W;
@@ -341,7 +355,7 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                     d_c[r] = kk[s] - 1;
                 }
             }
-            __syncthreads();
+            wave_sync();
 
             // ---------------- Phase F: trie ids for the new beam set ------------------------------------------
             int my_node = 0, my_par = 0, my_c = 0;
@@ -377,7 +391,7 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                     ch.w = __hip_atomic_load(cp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            __syncthreads();
+            wave_sync();
             if (lane < nb_new) {
                 const int j = d_copy[lane];
                 if (j >= 0) {
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
             }
             nb = nb_new;
             cur ^= 1;
-            __syncthreads();
+            wave_sync();
         }
     }
 

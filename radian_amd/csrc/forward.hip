@@ -171,34 +171,47 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
     // MFMAs (their LDS latency sits under the other 3 groups).  sched_barrier pins that order.
     const bool work = mval[0] || mval[1];   // (tiles are packed, so a wave with work almost always has both sub-tiles)
     auto chunk_step = [&](const float* st, int next, float* nst) {
+        // MFMA order: k-group g, then N tile n, then (kr, m): 8 MFMAs per (g, n) step on two accumulators.  A step needs
+        // the A fragments of its k-group (8 registers) and ONE B fragment (4): the next step's B fragment and, during the
+        // last step of a group, the next group's A fragments are requested before the step's MFMAs, so 24 fragment
+        // registers are live instead of 48 -- that keeps the kernel at <= 208 VGPRs, which leaves room for a beam-search
+        // wave (96) beside two of these on a SIMD.
         const float* Ab = st + a_off;
         const float* Bb = st + b_off;
-        float4 af[BK / 8][2], bf[BK / 8][NT];
-        auto rd = [&](int g) {
+        constexpr int NSTEP = (BK / 8) * NT;
+        float4 af[2][2], bq[2];
+        auto rdA = [&](int g) {
 #pragma unroll
-            for (int m = 0; m < 2; m++) af[g][m] = *(const float4*)(Ab + m * 32 * BK + koff[g]);
-#pragma unroll
-            for (int n = 0; n < NT; n++) bf[g][n] = *(const float4*)(Bb + n * 32 * BK + koff[g]);
+            for (int m = 0; m < 2; m++) af[g & 1][m] = *(const float4*)(Ab + m * 32 * BK + koff[g]);
         };
-        auto mm = [&](int g, int kr) {
-#pragma unroll
-            for (int m = 0; m < 2; m++) {
-                const float av = kr == 0 ? af[g][m].x : kr == 1 ? af[g][m].y : kr == 2 ? af[g][m].z : af[g][m].w;
-#pragma unroll
-                for (int n = 0; n < NT; n++) {
-                    const float bv = kr == 0 ? bf[g][n].x : kr == 1 ? bf[g][n].y : kr == 2 ? bf[g][n].z : bf[g][n].w;
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0);
-                }
-            }
-        };
+        auto rdB = [&](int sidx) { bq[sidx & 1] = *(const float4*)(Bb + (sidx % NT) * 32 * BK + koff[sidx / NT]); };
         const bool st_ok = next < NCHUNK;
-        if (work) rd(0);
+        if (work) {
+            rdA(0);
+            rdB(0);
+        }
 #pragma unroll
-        for (int i = 0; i < BK / 2; i++) {
-            if (work) mm(i >> 2, i & 3);
+        for (int sidx = 0; sidx < NSTEP; sidx++) {
+            const int g = sidx / NT, n = sidx % NT;
+            if (work) {
+                if (sidx + 1 < NSTEP) rdB(sidx + 1);
+                if (n == NT - 1 && g + 1 < BK / 8) rdA(g + 1);
+#pragma unroll
+                for (int kr = 0; kr < 4; kr++) {
+                    const float bv = kr == 0 ? bq[sidx & 1].x : kr == 1 ? bq[sidx & 1].y : kr == 2 ? bq[sidx & 1].z : bq[sidx & 1].w;
+#pragma unroll
+                    for (int m = 0; m < 2; m++) {
+                        const float4 aq = af[g & 1][m];
+                        const float av = kr == 0 ? aq.x : kr == 1 ? aq.y : kr == 2 ? aq.z : aq.w;
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0);
+                    }
+                }
+                // the reads first, then the 8 MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            if (i == 0 && work) rd(1);
-            if (st_ok && i < NPIECE) stage_piece(next, nst, i);
+            if (st_ok && sidx < NPIECE) stage_piece(next, nst, sidx);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -206,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
     // Three stages of one K-chunk each, one barrier per chunk: while chunk c is multiplied, chunk c+1 is landing and chunk
     // c+2 is issued, so a row that comes from HBM has two chunk times; the wait at the top of a chunk leaves the newest
     // chunk's NPIECE instructions in flight.  (Two workgroups per CU: 2 x 72 KiB of LDS, 2 waves per SIMD.)
-    static_assert(NPIECE <= BK / 2, "one DMA piece per MFMA group");
+    static_assert(NPIECE <= (BK / 8) * NT, "one DMA piece per MFMA step");
     float* st0 = smem;
     float* st1 = smem + STAGE_FLOATS;
     float* st2 = smem + 2 * STAGE_FLOATS;
