@@ -257,25 +257,26 @@ float split_scale(const float* w, size_t n)
     return ldexpf(1.f, 10 - e);  // mx * scale in [512, 1024)
 }
 
+// one 64-B row of a 16-channel chunk: [16 hi | 16 lo] halves, 16-B slots (hi 0-7, hi 8-15, lo 0-7, lo 8-15) XOR (row >> 2) & 3
 inline void split_store(_Float16* row, int k, int rowidx, float v)
 {
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)(v - (float)hi);
-    const int sw = (rowidx >> 1) & 7;
-    row[(((k >> 3)) ^ sw) * 8 + (k & 7)] = hi;
-    row[((4 + (k >> 3)) ^ sw) * 8 + (k & 7)] = lo;
+    const int sw = (rowidx >> 2) & 3;
+    row[((k >> 3) ^ sw) * 8 + (k & 7)] = hi;
+    row[((2 + (k >> 3)) ^ sw) * 8 + (k & 7)] = lo;
 }
 
-// Keras conv kernel [j][ci][co] -> split image [chunk = (ci/32)*3 + j][co][hi 32 | lo 32] (16-B slots swizzled)
+// Keras conv kernel [j][ci][co] -> split image [chunk = (ci/16)*3 + j][co][hi 16 | lo 16] (16-B slots swizzled)
 float pack_conv_split(const float* k, _Float16* dst)
 {
     const float sc = split_scale(k, CONV_PK);
     for (int j = 0; j < RD_K; j++)
         for (int ci = 0; ci < RD_C; ci++) {
             const float* src = k + ((size_t)j * RD_C + ci) * RD_C;
-            const int chunk = (ci / 32) * RD_K + j;
-            _Float16* d = dst + (size_t)chunk * RD_C * 64;
-            for (int co = 0; co < RD_C; co++) split_store(d + (size_t)co * 64, ci % 32, co, src[co] * sc);
+            const int chunk = (ci / 16) * RD_K + j;
+            _Float16* d = dst + (size_t)chunk * RD_C * 32;
+            for (int co = 0; co < RD_C; co++) split_store(d + (size_t)co * 32, ci % 16, co, src[co] * sc);
         }
     return 1.f / sc;
 }
@@ -285,8 +286,8 @@ float pack_dense_split(const float* k, _Float16* dst)
     const float sc = split_scale(k, D1_PK);
     for (int ci = 0; ci < RD_C; ci++) {
         const float* src = k + (size_t)ci * RD_H;
-        _Float16* d = dst + (size_t)(ci / 32) * RD_H * 64;
-        for (int h = 0; h < RD_H; h++) split_store(d + (size_t)h * 64, ci % 32, h, src[h] * sc);
+        _Float16* d = dst + (size_t)(ci / 16) * RD_H * 32;
+        for (int h = 0; h < RD_H; h++) split_store(d + (size_t)h * 32, ci % 16, h, src[h] * sc);
     }
     return 1.f / sc;
 }

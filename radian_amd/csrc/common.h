@@ -59,7 +59,7 @@ struct Model {
     float* b_in = nullptr;      // [256]
     float* w_match = nullptr;   // [256]
     float* b_match = nullptr;   // [256]
-    float* w_conv[2 * RD_MAX_BLOCKS] = {nullptr};  // packed [24 chunks][256 co][32 k]; index 2*blk+which (blk0.conv0 unused)
+    float* w_conv[2 * RD_MAX_BLOCKS] = {nullptr};  // packed [48 chunks][256 co][16 k]; index 2*blk+which (blk0.conv0 unused)
     float* b_conv[2 * RD_MAX_BLOCKS] = {nullptr};  // [256]
     float* w_d1 = nullptr;      // packed like conv, K=256: [8 chunks][128 co][32 k]
     float* b_d1 = nullptr;      // [128]

@@ -435,16 +435,17 @@ struct SplitArgs {
 template <int NT, int TAPS, int EPI>
 __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
 {
+    // Same pipeline as tcn_gemm_kernel: 16-channel chunks (one MFMA k-step), 64-B LDS rows [16 hi | 16 lo], three stages,
+    // hand-counted LDS-DMA issued piecewise between the MFMA steps.
     constexpr int BN = 2 * NT * 32;
-    constexpr int BK = 32;                // input channels per chunk: a row is [32 hi | 32 lo] f16 = 128 B
-    constexpr int NCHUNK = TAPS * (RD_C / BK);
-    constexpr int STAGE_FLOATS = (BM + BN) * BK;
+    constexpr int BKC = 16;                       // input channels per chunk
+    constexpr int NCHUNK = TAPS * (RD_C / BKC);
+    constexpr int STAGE_FLOATS = (BM + BN) * 16;  // 64 B per row
+    constexpr int NSTAGE = 3;
     constexpr int HEAD_FLOATS = BM * (RD_H + 1) + RD_H * 5 + 8;
-    constexpr int SMEM_FLOATS = (EPI == EPI_HEAD && HEAD_FLOATS > STAGE_FLOATS) ? HEAD_FLOATS : STAGE_FLOATS;
+    constexpr int SMEM_FLOATS = (EPI == EPI_HEAD && HEAD_FLOATS > NSTAGE * STAGE_FLOATS) ? HEAD_FLOATS : NSTAGE * STAGE_FLOATS;
 
     __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
-    float* As = smem;                  // [BM][128 B]
-    float* Bs = smem + BM * BK;        // [BN][128 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -455,42 +456,39 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
     const TileDesc sdm[2] = {tds[wm * 2], tds[wm * 2 + 1]};
     const bool mval[2] = {sdm[0].seg_len > sdm[0].t0, sdm[1].seg_len > sdm[1].t0};
 
-    const int dma_r = lane >> 3;
-    const int dma_ps = lane & 7;
+    // DMA roles: a wave-instruction moves 16 rows x 64 B; wave w stages sub-tile w (two pieces) and its share of B.
+    // LDS slot s of a row: s = 0,1 hi halves of channels 0-7 / 8-15 of the chunk, s = 2,3 their lo halves; in HBM a
+    // 32-channel group is 128 B = [32 hi | 32 lo], so the slot's source is group base + (c16 & 1) * 32 B + (s & 1) * 16 B
+    // + (s >> 1) * 64 B.
+    const int dma_r = lane >> 2;
+    const int dma_ps = lane & 3;
+    const TileDesc sst = tds[wave];
+    const int64_t d_seg = sst.seg_row, d_alt = sst.alt_row;
+    const int d_t0 = sst.t0, d_ain = sst.alt_in;
+    const int d_len = sst.seg_len > sst.t0 ? sst.in_len : 0;
+    const int lslot = dma_ps ^ ((dma_r >> 2) & 3);
+    const int lane_half = (lslot & 1) * 8 + (lslot >> 1) * 32;   // offset in halves inside the 128-B group, before (c16 & 1) * 16
 
-    int64_t d_seg[BM / 32], d_alt[BM / 32];
-    int d_t0[BM / 32], d_len[BM / 32], d_ain[BM / 32];
-#pragma unroll
-    for (int r = 0; r < BM / 32; r++) {
-        const TileDesc sd = tds[r];
-        d_seg[r] = sd.seg_row;
-        d_alt[r] = sd.alt_row;
-        d_t0[r] = sd.t0;
-        d_len[r] = sd.seg_len > sd.t0 ? sd.in_len : 0;
-        d_ain[r] = sd.alt_in;
-    }
-    const int lane_t = wave * 8 + dma_r;
-    const int lane_slot = (dma_ps ^ ((wave * 4 + (dma_r >> 1)) & 7)) * 8;
-
-    auto stage = [&](int chunk) {
-        const int cc = chunk / TAPS;
-        const int tap = chunk - cc * TAPS;
-        const int shift = (TAPS - 1 - tap) * a.dil;
-#pragma unroll
-        for (int r = 0; r < BM / 32; r++) {
-            const int piece = r * 4 + wave;
-            const int t = d_t0[r] + lane_t - shift;
-            const float* src = (t >= 0 && t < d_len[r])
-                                   ? (const float*)(a.in + ((size_t)(t < d_ain[r] ? d_seg[r] : d_alt[r]) + t) * ROWH + cc * 64 + lane_slot)
+    constexpr int NPIECE = 2 + BN / 64;
+    auto stage_piece = [&](int chunk, float* st, int pc) {
+        if (pc < 2) {
+            const int cc = chunk / TAPS;
+            const int tap = chunk - cc * TAPS;
+            const int shift = (TAPS - 1 - tap) * a.dil;
+            const int t = d_t0 + pc * 16 + dma_r - shift;
+            const float* src = (t >= 0 && t < d_len)
+                                   ? (const float*)(a.in + ((size_t)(t < d_ain ? d_seg : d_alt) + t) * ROWH + (cc >> 1) * 64 + (cc & 1) * 16 + lane_half)
                                    : a.zeros + dma_ps * 4;
-            glds16(src, As + piece * 256);
+            glds16_uncounted(src, st + (wave * 2 + pc) * 256);
+        } else {
+            const int piece = (pc - 2) * 4 + wave;
+            const float* wsrc = (const float*)(a.wpk + (size_t)chunk * BN * 32) + lane * 4;
+            glds16_uncounted(wsrc + piece * 256, st + BM * 16 + piece * 256);
         }
-        const float* wsrc = (const float*)(a.wpk + (size_t)chunk * BN * 64) + lane * 4;
+    };
+    auto stage = [&](int chunk, float* st) {
 #pragma unroll
-        for (int r = 0; r < BN / 32; r++) {
-            const int piece = r * 4 + wave;
-            glds16(wsrc + piece * 256, Bs + piece * 256);
-        }
+        for (int pc = 0; pc < NPIECE; pc++) stage_piece(chunk, st, pc);
     };
 
     f32x16 acc[2][NT];
@@ -503,40 +501,66 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
 
     const int fr = lane & 31;
     const int fh = lane >> 5;
-    const int swz = (fr >> 1) & 7;
-    const _Float16* Ab = (const _Float16*)As + (wm * 64 + fr) * 64;
-    const _Float16* Bb = (const _Float16*)Bs + (wn * NT * 32 + fr) * 64;
+    const int swz = (fr >> 2) & 3;
+    const int oh = (fh ^ swz) * 8;         // halves: hi slot of this lane's k = 8 fh .. 8 fh + 7
+    const int ol = ((2 + fh) ^ swz) * 8;   // lo slot
+    const int a_off = (wm * 64 + fr) * 32;                       // halves
+    const int b_off = BM * 32 + (wn * NT * 32 + fr) * 32;
 
-    for (int chunk = 0; chunk < NCHUNK; chunk++) {
-        if (chunk) __syncthreads();
-        stage(chunk);
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-        __syncthreads();
-        if (mval[0] || mval[1])
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            const int oh = ((2 * ks + fh) ^ swz) * 8;       // hi slot of this lane's k = 16 ks + 8 fh .. +7
-            const int ol = ((4 + 2 * ks + fh) ^ swz) * 8;   // lo slot
-            f16x8 ah[2], al[2], bh[NT], bl[NT];
+    const bool work = mval[0] || mval[1];
+    auto chunk_step = [&](const float* stf, int next, float* nst) {
+        const _Float16* st = (const _Float16*)stf;
+        const _Float16* Ab = st + a_off;
+        const _Float16* Bb = st + b_off;
+        f16x8 ah[2], al[2], bh[2], bl[2];
+        const bool st_ok = next < NCHUNK;
+        if (work) {
 #pragma unroll
             for (int m = 0; m < 2; m++) {
-                ah[m] = *(const f16x8*)(Ab + m * 32 * 64 + oh);
-                al[m] = *(const f16x8*)(Ab + m * 32 * 64 + ol);
+                ah[m] = *(const f16x8*)(Ab + m * 32 * 32 + oh);
+                al[m] = *(const f16x8*)(Ab + m * 32 * 32 + ol);
             }
-#pragma unroll
-            for (int n = 0; n < NT; n++) {
-                bh[n] = *(const f16x8*)(Bb + n * 32 * 64 + oh);
-                bl[n] = *(const f16x8*)(Bb + n * 32 * 64 + ol);
-            }
-#pragma unroll
-            for (int m = 0; m < 2; m++)
-#pragma unroll
-                for (int n = 0; n < NT; n++) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
-                }
+            bh[0] = *(const f16x8*)(Bb + oh);
+            bl[0] = *(const f16x8*)(Bb + ol);
         }
+        constexpr int PPS = (NPIECE + NT - 1) / NT;   // DMA pieces issued after each N step
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            if (work) {
+                if (n + 1 < NT) {
+                    bh[(n + 1) & 1] = *(const f16x8*)(Bb + (n + 1) * 32 * 32 + oh);
+                    bl[(n + 1) & 1] = *(const f16x8*)(Bb + (n + 1) * 32 * 32 + ol);
+                }
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n & 1], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n & 1], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n & 1], acc[m][n], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < PPS; q++)
+                if (st_ok && n * PPS + q < NPIECE) stage_piece(next, nst, n * PPS + q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    float* st0 = smem;
+    float* st1 = smem + STAGE_FLOATS;
+    float* st2 = smem + 2 * STAGE_FLOATS;
+    stage(0, st0);
+    stage(1, st1);
+    auto step = [&](int c, const float* st, float* nst) {
+        if (c + 1 < NCHUNK) wait_dma_and_barrier<NPIECE>(); else wait_dma_and_barrier<0>();
+        chunk_step(st, c + 2, nst);
+    };
+    for (int chunk = 0; chunk < NCHUNK; chunk += 3) {
+        step(chunk, st0, st2);
+        if (chunk + 1 < NCHUNK) step(chunk + 1, st1, st0);
+        if (chunk + 2 < NCHUNK) step(chunk + 2, st2, st1);
     }
     __syncthreads();
 
