@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
     __shared__ BeamState<WM> st[2];
     __shared__ double cpy_pnb[WM], cpy_tot[WM], cpy_pb[WM], mb_v[WM], mP[WM], mQ[WM];
     __shared__ int mb_q[WM];
-    __shared__ int d_copy[WM], d_par[WM], d_c[WM];
+    __shared__ int d_copy[WM], d_par[WM], d_c[WM], rk_owner[WM];
     __shared__ double lp[64][5];
     __shared__ double praw[LM ? 64 : 1][5];
     __shared__ double sent[LM ? 64 : 1];
@@ -256,7 +256,8 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
             for (int s = 0; s < R; s++) {
                 const int x = (valid[s] && kk[s] > 0) ? os.child[kk[s] - 1][bi[s]] : 0;
                 int found = -1;
-                for (int j = 0; j < nb; j++)
+#pragma unroll
+                for (int j = 0; j < WM; j++)   // lanes >= nb hold -1: constant lane selects, no loop-carried scalar
                     if (__builtin_amdgcn_readlane(node_reg, j) == x) found = j;
                 if (x != 0 && found >= 0) {
                     pj[s] = found;
@@ -322,6 +323,10 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                 key[s] = valid[s] ? c_ptot[s] : __builtin_nan("");
                 nvalid += __popcll(__ballot(valid[s]));
             }
+            // Fast count: candidates with a strictly greater key, four broadcasts per trip (lanes past ncand hold NaN and
+            // count for nothing).  Two candidates get the same count iff their keys are equal, so a collision among the
+            // counts below W -- found by letting the lanes claim rk_owner[count] -- means a tie that matters; only then is
+            // the count redone with the insertion-order rule (exact 0 probabilities make such ties; softmax rows do not).
             int rank[R];
 #pragma unroll
             for (int s = 0; s < R; s++) rank[s] = 0;
@@ -329,14 +334,39 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
             for (int s2 = 0; s2 < R; s2++) {
                 const int cnt = (ncand - s2 * 64) < 64 ? (ncand - s2 * 64) : 64;   // wave-uniform
                 const int klo = __double2loint(key[s2]), khi = __double2hiint(key[s2]);
-                for (int l = 0; l < cnt; l++) {
-                    const double kv = __hiloint2double(__builtin_amdgcn_readlane(khi, l), __builtin_amdgcn_readlane(klo, l));
-                    const int qq = s2 * 64 + l;
+                for (int l = 0; l < cnt; l += 4) {
 #pragma unroll
-                    for (int s = 0; s < R; s++) {
-                        const int q = s * 64 + lane;
-                        const bool ahead = (kv > key[s]) || (kv == key[s] && qq < q);
-                        rank[s] += ahead ? 1 : 0;
+                    for (int u = 0; u < 4; u++) {
+                        const int ll = (l + u) & 63;
+                        const double kv = __hiloint2double(__builtin_amdgcn_readlane(khi, ll), __builtin_amdgcn_readlane(klo, ll));
+#pragma unroll
+                        for (int s = 0; s < R; s++) rank[s] += (kv > key[s]) ? 1 : 0;
+                    }
+                }
+            }
+            bool tie = false;
+#pragma unroll
+            for (int s = 0; s < R; s++)
+                if (valid[s] && rank[s] < W) rk_owner[rank[s]] = s * 64 + lane;
+            wave_sync();
+#pragma unroll
+            for (int s = 0; s < R; s++) tie |= valid[s] && rank[s] < W && rk_owner[rank[s]] != s * 64 + lane;
+            if (__any(tie)) {
+#pragma unroll
+                for (int s = 0; s < R; s++) rank[s] = 0;
+#pragma unroll
+                for (int s2 = 0; s2 < R; s2++) {
+                    const int cnt = (ncand - s2 * 64) < 64 ? (ncand - s2 * 64) : 64;
+                    const int klo = __double2loint(key[s2]), khi = __double2hiint(key[s2]);
+                    for (int l = 0; l < cnt; l++) {
+                        const double kv = __hiloint2double(__builtin_amdgcn_readlane(khi, l), __builtin_amdgcn_readlane(klo, l));
+                        const int qq = s2 * 64 + l;
+#pragma unroll
+                        for (int s = 0; s < R; s++) {
+                            const int q = s * 64 + lane;
+                            const bool ahead = (kv > key[s]) || (kv == key[s] && qq < q);
+                            rank[s] += ahead ? 1 : 0;
+                        }
                     }
                 }
             }
