@@ -52,7 +52,7 @@ struct ConvArgs {
     const float* w2;      // EPI_HEAD: [128][5]
     const float* b2;      // EPI_HEAD: [5]
     float* probs;         // EPI_HEAD: [nW][T][5]
-    const float* zeros;   // >= 32 zero floats (source of the causal left padding for the LDS-DMA)
+    int zero_row;         // a row of `in` that holds zeros and is never written: source of the causal left padding
     float* sink;          // 1024 floats nobody reads: target of the stores past a segment's end
     const TileDesc* tiles; // one per workgroup
     int dil;
@@ -80,6 +80,19 @@ __device__ __forceinline__ void glds16_uncounted(const float* src, float* lds_ds
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(src), "s"(dst)
+                 : "memory");
+}
+// Same, for a source that is one scalar base for the wave + 16 B per lane (the packed weights): scalar-base addressing,
+// and piece r of the wave's share through the instruction offset, which the hardware adds to the global AND the LDS
+// address (the wave's pieces are contiguous in both).
+template <int OFFSET>
+__device__ __forceinline__ void glds16_uncounted_saddr(unsigned lane_off, const void* sbase, float* lds_dst)
+{
+    unsigned keep;
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_off), "s"(sbase), "s"(dst), "n"(OFFSET)
                  : "memory");
 }
 // All but the newest LEAVE LDS-DMA instructions of this wave have landed (loads return in order); then the workgroup
@@ -124,28 +137,42 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
     const int d_t0 = sst.t0, d_ain = sst.alt_in;
     const int d_len = sst.seg_len > sst.t0 ? sst.in_len : 0;            // empty sub-tile: zero page only
     const int lane_slot = (dma_ps ^ ((dma_r >> 2) & 3)) * 4;           // (tile row >> 2) & 3 = (dma_r >> 2) & 3
+    // This lane's A source row for each tap and piece, fixed for the tile: a row of the input tensor, or the tensor's
+    // zero row where the time step lies before the segment (causal padding) or in an empty sub-tile.  Per chunk the
+    // address is then one multiply-add on a per-chunk base.
+    int arow[TAPS][2];
+#pragma unroll
+    for (int tap = 0; tap < TAPS; tap++)
+#pragma unroll
+        for (int pc = 0; pc < 2; pc++) {
+            const int t = d_t0 + pc * 16 + dma_r - (TAPS - 1 - tap) * a.dil;
+            arow[tap][pc] = (t >= 0 && t < d_len) ? (int)((t < d_ain ? d_seg : d_alt) + t) : a.zero_row;
+        }
+    const char* lanebase = (const char*)(a.in + lane_slot);
+    const unsigned lane_off = lane * 16;
 
-    // one piece (wave-instruction) of a chunk's staging: pieces 0,1 = this wave's two 16-row pieces of A, 2.. = its share of B
-    constexpr int NPIECE = 2 + BN / 64;
-    auto stage_piece = [&](int chunk, float* st, int pc) {
+    // one piece (wave-instruction) of a chunk's staging: pieces 0,1 = this wave's two 16-row pieces of A, 2.. = its
+    // BN/64 consecutive 1-KiB pieces of B.  `tap` is the chunk's tap (a literal at every call site).
+    constexpr int PB = BN / 64;
+    constexpr int NPIECE = 2 + PB;
+    auto stage_piece = [&](int chunk, int tap, float* st, int pc) {
         // chunk order: input-channel slice outer, tap inner -> the three shifted reads of the same rows are adjacent in time
         if (pc < 2) {
             const int cc = chunk / TAPS;
-            const int tap = chunk - cc * TAPS;
-            const int shift = (TAPS - 1 - tap) * a.dil;
-            const int t = d_t0 + pc * 16 + dma_r - shift;
-            const float* src = (t >= 0 && t < d_len) ? a.in + ((size_t)(t < d_ain ? d_seg : d_alt) + t) * RD_C + cc * BK + lane_slot
-                                                     : a.zeros + dma_ps * 4;
-            glds16_uncounted(src, st + (wave * 2 + pc) * 256);   // 1 KiB piece = tile rows 16*piece .. 16*piece+15
+            const char* src = lanebase + (size_t)cc * (BK * 4) + (uint64_t)(unsigned)arow[tap][pc] * (RD_C * 4);
+            glds16_uncounted((const float*)src, st + (wave * 2 + pc) * 256);   // 1 KiB piece = tile rows 16*piece .. 16*piece+15
         } else {
-            const int piece = (pc - 2) * 4 + wave;
-            const float* wsrc = a.wpk + (size_t)chunk * BN * BK + lane * 4;   // pre-swizzled on the host: linear copy
-            glds16_uncounted(wsrc + piece * 256, st + BM * BK + piece * 256);
+            const float* wb = a.wpk + (size_t)chunk * BN * BK + wave * PB * 256;   // pre-swizzled on the host: linear copy
+            float* dst = st + BM * BK + wave * PB * 256;
+            if (pc == 2) glds16_uncounted_saddr<0>(lane_off, wb, dst);
+            else if (pc == 3) glds16_uncounted_saddr<1024>(lane_off, wb, dst);
+            else if (pc == 4) glds16_uncounted_saddr<2048>(lane_off, wb, dst);
+            else glds16_uncounted_saddr<3072>(lane_off, wb, dst);
         }
     };
-    auto stage = [&](int chunk, float* st) {
+    auto stage = [&](int chunk, int tap, float* st) {
 #pragma unroll
-        for (int pc = 0; pc < NPIECE; pc++) stage_piece(chunk, st, pc);
+        for (int pc = 0; pc < NPIECE; pc++) stage_piece(chunk, tap, st, pc);
     };
 
     f32x16 acc[2][NT];
@@ -170,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
     // the matrix pipe instead of in front of it; the second k-group's fragments are requested after the first group of
     // MFMAs (their LDS latency sits under the other 3 groups).  sched_barrier pins that order.
     const bool work = mval[0] || mval[1];   // (tiles are packed, so a wave with work almost always has both sub-tiles)
-    auto chunk_step = [&](const float* st, int next, float* nst) {
+    auto chunk_step = [&](const float* st, int next, int next_tap, float* nst) {
         // MFMA order: k-group g, then N tile n, then (kr, m): 8 MFMAs per (g, n) step on two accumulators.  A step needs
         // the A fragments of its k-group (8 registers) and ONE B fragment (4): the next step's B fragment and, during the
         // last step of a group, the next group's A fragments are requested before the step's MFMAs, so 24 fragment
@@ -211,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (st_ok && sidx < NPIECE) stage_piece(next, nst, sidx);
+            if (st_ok && sidx < NPIECE) stage_piece(next, next_tap, nst, sidx);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -223,16 +250,18 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
     float* st0 = smem;
     float* st1 = smem + STAGE_FLOATS;
     float* st2 = smem + 2 * STAGE_FLOATS;
-    stage(0, st0);
-    stage(1, st1);
-    auto step = [&](int c, const float* st, float* nst) {
+    constexpr bool T3 = TAPS == 3;   // chunk % 3 is the tap; the loop below advances by the 3 stages
+    static_assert(TAPS == 3 || TAPS == 1, "tap of a chunk is a literal in the unrolled loop");
+    stage(0, 0, st0);
+    stage(1, T3 ? 1 : 0, st1);
+    auto step = [&](int c, const float* st, int tap2, float* nst) {
         if (c + 1 < NCHUNK) wait_dma_and_barrier<NPIECE>(); else wait_dma_and_barrier<0>();
-        chunk_step(st, c + 2, nst);
+        chunk_step(st, c + 2, tap2, nst);
     };
     for (int chunk = 0; chunk < NCHUNK; chunk += 3) {
-        step(chunk, st0, st2);
-        if (chunk + 1 < NCHUNK) step(chunk + 1, st1, st0);
-        if (chunk + 2 < NCHUNK) step(chunk + 2, st2, st1);
+        step(chunk, st0, T3 ? 2 : 0, st2);
+        if (chunk + 1 < NCHUNK) step(chunk + 1, st1, 0, st0);
+        if (chunk + 2 < NCHUNK) step(chunk + 2, st2, T3 ? 1 : 0, st1);
     }
     __syncthreads();   // every wave is done with the staging LDS: the epilogues reuse it
 
@@ -426,7 +455,7 @@ struct SplitArgs {
     const float* w2;
     const float* b2;
     float* probs;
-    const float* zeros;
+    int zero_row;
     float* sink;
     const TileDesc* tiles;
     int dil;
@@ -468,27 +497,36 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
     const int d_len = sst.seg_len > sst.t0 ? sst.in_len : 0;
     const int lslot = dma_ps ^ ((dma_r >> 2) & 3);
     const int lane_half = (lslot & 1) * 8 + (lslot >> 1) * 32;   // offset in halves inside the 128-B group, before (c16 & 1) * 16
+    int arow[TAPS][2];                                           // see the fp32 kernel
+#pragma unroll
+    for (int tap = 0; tap < TAPS; tap++)
+#pragma unroll
+        for (int pc = 0; pc < 2; pc++) {
+            const int t = d_t0 + pc * 16 + dma_r - (TAPS - 1 - tap) * a.dil;
+            arow[tap][pc] = (t >= 0 && t < d_len) ? (int)((t < d_ain ? d_seg : d_alt) + t) : a.zero_row;
+        }
+    const char* lanebase = (const char*)(a.in + lane_half);
+    const unsigned lane_off = lane * 16;
 
-    constexpr int NPIECE = 2 + BN / 64;
-    auto stage_piece = [&](int chunk, float* st, int pc) {
+    constexpr int PB = BN / 64;
+    constexpr int NPIECE = 2 + PB;
+    auto stage_piece = [&](int chunk, int tap, float* st, int pc) {
         if (pc < 2) {
             const int cc = chunk / TAPS;
-            const int tap = chunk - cc * TAPS;
-            const int shift = (TAPS - 1 - tap) * a.dil;
-            const int t = d_t0 + pc * 16 + dma_r - shift;
-            const float* src = (t >= 0 && t < d_len)
-                                   ? (const float*)(a.in + ((size_t)(t < d_ain ? d_seg : d_alt) + t) * ROWH + (cc >> 1) * 64 + (cc & 1) * 16 + lane_half)
-                                   : a.zeros + dma_ps * 4;
-            glds16_uncounted(src, st + (wave * 2 + pc) * 256);
+            const char* src = lanebase + (size_t)((cc >> 1) * 128 + (cc & 1) * 32) + (uint64_t)(unsigned)arow[tap][pc] * (ROWH * 2);
+            glds16_uncounted((const float*)src, st + (wave * 2 + pc) * 256);
         } else {
-            const int piece = (pc - 2) * 4 + wave;
-            const float* wsrc = (const float*)(a.wpk + (size_t)chunk * BN * 32) + lane * 4;
-            glds16_uncounted(wsrc + piece * 256, st + BM * 16 + piece * 256);
+            const float* wb = (const float*)(a.wpk + (size_t)chunk * BN * 32) + wave * PB * 256;
+            float* dst = st + BM * 16 + wave * PB * 256;
+            if (pc == 2) glds16_uncounted_saddr<0>(lane_off, wb, dst);
+            else if (pc == 3) glds16_uncounted_saddr<1024>(lane_off, wb, dst);
+            else if (pc == 4) glds16_uncounted_saddr<2048>(lane_off, wb, dst);
+            else glds16_uncounted_saddr<3072>(lane_off, wb, dst);
         }
     };
-    auto stage = [&](int chunk, float* st) {
+    auto stage = [&](int chunk, int tap, float* st) {
 #pragma unroll
-        for (int pc = 0; pc < NPIECE; pc++) stage_piece(chunk, st, pc);
+        for (int pc = 0; pc < NPIECE; pc++) stage_piece(chunk, tap, st, pc);
     };
 
     f32x16 acc[2][NT];
@@ -508,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
     const int b_off = BM * 32 + (wn * NT * 32 + fr) * 32;
 
     const bool work = mval[0] || mval[1];
-    auto chunk_step = [&](const float* stf, int next, float* nst) {
+    auto chunk_step = [&](const float* stf, int next, int next_tap, float* nst) {
         const _Float16* st = (const _Float16*)stf;
         const _Float16* Ab = st + a_off;
         const _Float16* Bb = st + b_off;
@@ -543,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < PPS; q++)
-                if (st_ok && n * PPS + q < NPIECE) stage_piece(next, nst, n * PPS + q);
+                if (st_ok && n * PPS + q < NPIECE) stage_piece(next, next_tap, nst, n * PPS + q);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -551,16 +589,18 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
     float* st0 = smem;
     float* st1 = smem + STAGE_FLOATS;
     float* st2 = smem + 2 * STAGE_FLOATS;
-    stage(0, st0);
-    stage(1, st1);
-    auto step = [&](int c, const float* st, float* nst) {
+    constexpr bool T3 = TAPS == 3;
+    static_assert(TAPS == 3 || TAPS == 1, "tap of a chunk is a literal in the unrolled loop");
+    stage(0, 0, st0);
+    stage(1, T3 ? 1 : 0, st1);
+    auto step = [&](int c, const float* st, int tap2, float* nst) {
         if (c + 1 < NCHUNK) wait_dma_and_barrier<NPIECE>(); else wait_dma_and_barrier<0>();
-        chunk_step(st, c + 2, nst);
+        chunk_step(st, c + 2, tap2, nst);
     };
     for (int chunk = 0; chunk < NCHUNK; chunk += 3) {
-        step(chunk, st0, st2);
-        if (chunk + 1 < NCHUNK) step(chunk + 1, st1, st0);
-        if (chunk + 2 < NCHUNK) step(chunk + 2, st2, st1);
+        step(chunk, st0, T3 ? 2 : 0, st2);
+        if (chunk + 1 < NCHUNK) step(chunk + 1, st1, 0, st0);
+        if (chunk + 2 < NCHUNK) step(chunk + 2, st2, T3 ? 1 : 0, st1);
     }
     __syncthreads();
 
@@ -759,7 +799,7 @@ int timer_end(hipStream_t st, KernelTimer& tm, double flops, double bytes)
 namespace {
 
 int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2 conv1, 3 head*/, const TileDesc* tiles, int n,
-                double rows, const float* d_signal, float* Xin, float* Xout, float* MID, float* d_probs)
+                double rows, int zero_row, const float* d_signal, float* Xin, float* Xout, float* MID, float* d_probs)
 {
     if (n <= 0) return RD_OK;
     Model& m = ctx->model;
@@ -778,7 +818,7 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
         if ((rc = timer_begin(st, ctx->timer_head))) return rc;
         if (split) {
             SplitArgs h = {};
-            h.zeros = m.zeros;
+            h.zero_row = zero_row;
             h.sink = m.sink;
             h.tiles = tiles;
             h.in = (const _Float16*)Xin;
@@ -791,7 +831,7 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
             hipLaunchKernelGGL((tcn_gemm_split_kernel<2, 1, EPI_HEAD>), dim3(n), dim3(256), 0, st, h);
         } else {
             ConvArgs h = {};
-            h.zeros = m.zeros;
+            h.zero_row = zero_row;
             h.sink = m.sink;
             h.tiles = tiles;
             h.in = Xin;
@@ -807,14 +847,14 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
     }
     const int wi = 2 * b + (kind == 2 ? 1 : 0);
     ConvArgs a = {};
-    a.zeros = m.zeros;
+    a.zero_row = zero_row;
     a.sink = m.sink;
     a.dil = m.dil[b];
     a.tiles = tiles;
     a.wpk = m.w_conv[wi];
     a.bias = m.b_conv[wi];
     SplitArgs sa = {};
-    sa.zeros = m.zeros;
+    sa.zero_row = zero_row;
     sa.sink = m.sink;
     sa.dil = m.dil[b];
     sa.tiles = tiles;
@@ -866,16 +906,26 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl
     }
     if (total_rows == 0) return RD_OK;
     int rc = RD_OK;
-    const size_t act_bytes = (size_t)total_rows * RD_C * sizeof(float);
+    if (total_rows >= INT32_MAX) {
+        rd_set_error("rd_forward: %lld rows in one batch (the kernels index rows with 32 bits)", (long long)total_rows);
+        return RD_ERR_ARG;
+    }
+    // each activation tensor carries one extra row of zeros behind its last row: the source of the causal left padding
+    const size_t row_bytes = (size_t)RD_C * sizeof(float);
+    const size_t act_bytes = (size_t)(total_rows + 1) * row_bytes;
     if (ctx->ws_act0.reserve(act_bytes) || ctx->ws_act1.reserve(act_bytes) || ctx->ws_act2.reserve(act_bytes)) return RD_ERR_NOMEM;
     float* Xin = ctx->ws_act0.as<float>();
     float* Xout = ctx->ws_act1.as<float>();
     float* MID = ctx->ws_act2.as<float>();
+    const int zero_row = (int)total_rows;
+    RD_HIP(hipMemsetAsync(Xin + (size_t)zero_row * RD_C, 0, row_bytes, ctx->stream));
+    RD_HIP(hipMemsetAsync(Xout + (size_t)zero_row * RD_C, 0, row_bytes, ctx->stream));
+    RD_HIP(hipMemsetAsync(MID + (size_t)zero_row * RD_C, 0, row_bytes, ctx->stream));
     const int nl = 2 * m.nblocks + 1;
     for (int li = 0; li < nl; li++) {
         const int b = li == nl - 1 ? m.nblocks : li / 2;
         const int kind = li == nl - 1 ? 3 : (li == 0 ? 0 : (li & 1 ? 2 : 1));
-        if ((rc = launch_layer(ctx, ctx->stream, b, kind, tl.d[li], tl.n[li], (double)tl.rows[li], d_signal, Xin, Xout, MID, d_probs))) return rc;
+        if ((rc = launch_layer(ctx, ctx->stream, b, kind, tl.d[li], tl.n[li], (double)tl.rows[li], zero_row, d_signal, Xin, Xout, MID, d_probs))) return rc;
         if (kind == 2) {   // block finished: its output becomes the next block's input
             float* t = Xin;
             Xin = Xout;

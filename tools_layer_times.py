@@ -9,6 +9,8 @@ from radian_amd.backend import RD_TIMER_CONV
 from radian_amd.preprocess import mad_normalise
 be = Backend(0)
 be.load_weights(weights.synthetic_weights(seed=1234))
+if len(sys.argv) > 1:
+    be.set_precision(sys.argv[1])
 reads = synthetic.synthetic_reads(64, 4096, seed=1)
 sigs = [mad_normalise(r, 4).astype(np.float32) for r in reads]
 for name, fn in (("chunk (streams + heads)", lambda: be.basecall_reads_chunk(sigs, 1024, 512, 1)),
