@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary timed run in the other precision mode")
     ap.add_argument("--check", action="store_true", help="untimed cross-check: streamed labels == windowed labels on one batch")
     ap.add_argument("--decode-group", type=int, default=8, help="batches per beam-search launch in the two-stream pipeline")
+    ap.add_argument("--lanes", type=int, default=2, help="forward streams the pipelined batches rotate over (1..4)")
     ap.add_argument("--cpu-reads", type=int, default=0, help="reads in the CPU-baseline sample (0: sized to the host core count)")
     args = ap.parse_args()
 
@@ -128,6 +129,7 @@ def main():
     lens = np.zeros(BATCH_WINDOWS, dtype=np.int32)
     # output buffers of the two-stream pipeline (a batch's labels land two submits later / at flush)
     be.pipe_config(args.decode_group)
+    be.pipe_set_lanes(args.lanes)
     out = [(np.zeros((BATCH_WINDOWS, CHUNK), dtype=np.uint8), np.full(BATCH_WINDOWS, -1, dtype=np.int32))
            for _ in range(2 * args.decode_group)]
 
@@ -269,7 +271,7 @@ def main():
                 "model_rows_per_step": rows_streamed,
                 "chunk_len": CHUNK, "step_size": STEP, "batch_windows": BATCH_WINDOWS, "beam_width": BEAM,
                 "decode_type": "chunk", "samples_per_step_per_gpu": samples_per_step, "sharding": "reads per rank, no data-path collective", "startup_comm": comm_kind,
-                "pipelining": f"2 HIP streams: forwards back to back; beam search + label copy-out of a group of {args.decode_group} batches overlaps the next group's forwards; all labels on host at stop",
+                "pipelining": f"{args.lanes} forward streams taking the steps' batches in turn (independent kernel chains fill each other's last, partial round of workgroups) + 1 decode stream: beam search + label copy-out of a group of {args.decode_group} batches overlaps the next group's forwards; all labels on host at stop",
             },
             "roofline": roof,
         }

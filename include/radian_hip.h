@@ -166,12 +166,16 @@ int rd_basecall_chunk_resident(rd_ctx* ctx, const float* d_windows, int n_window
 int rd_decode_resident(rd_ctx* ctx, const float* d_probs, int n_windows, int chunk_len, const int32_t* valid_len,
                        int beam_width, uint8_t* labels_out, int32_t* label_len);
 
-/* Two-stream software pipeline over chunk-mode batches: forwards run back to back on the compute stream; the beam
- * search + label copy-out of a GROUP of submitted batches (default 4, rd_pipe_config) runs on a second stream and
+/* Software pipeline over chunk-mode batches: the forwards of consecutive submitted batches rotate over a few
+ * independent streams ("lanes", default 2, rd_pipe_set_lanes; each lane has its own activation tensors) so that one
+ * batch's partially filled last round of workgroups overlaps the next batch's launches; the beam search + label
+ * copy-out of a GROUP of submitted batches (default 4, rd_pipe_config) runs on a further, high-priority stream and
  * overlaps the forwards of the next group.  Same contract as rd_basecall_chunk_resident, except that
  * labels_out/label_len of a submitted batch are only valid after rd_pipe_flush (or once a later submit had to
- * recycle its slot); the caller keeps them alive until then (labels of window i at labels_out + i*chunk_len). */
+ * recycle its slot); the caller keeps them alive until then (labels of window i at labels_out + i*chunk_len).
+ * The input buffers of a submitted batch must stay untouched until then as well. */
 int rd_pipe_config(rd_ctx* ctx, int group_batches);
+int rd_pipe_set_lanes(rd_ctx* ctx, int lanes); /* 1..4; only while the pipeline is empty */
 int rd_pipe_submit(rd_ctx* ctx, const float* d_windows, int n_windows, int chunk_len, const int32_t* valid_len,
                    int beam_width, uint8_t* labels_out, int32_t* label_len);
 int rd_pipe_flush(rd_ctx* ctx);

@@ -50,6 +50,7 @@ SIGNATURES = {
     "rd_basecall_chunk_resident": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_i, c_vp, c_vp]),
     "rd_decode_resident": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_i, c_vp, c_vp]),
     "rd_pipe_config": (c_i, [c_vp, c_i]),
+    "rd_pipe_set_lanes": (c_i, [c_vp, c_i]),
     "rd_pipe_submit": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_i, c_vp, c_vp]),
     "rd_pipe_flush": (c_i, [c_vp]),
     "rd_timer_enable": (c_i, [c_vp, c_i, c_i]),

@@ -300,6 +300,10 @@ class Backend:
     def pipe_config(self, group_batches):
         self._check(self._L.rd_pipe_config(self._h, int(group_batches)))
 
+    def pipe_set_lanes(self, lanes):
+        """forward streams the submitted batches rotate over (1..4, default 2)"""
+        self._check(self._L.rd_pipe_set_lanes(self._h, int(lanes)))
+
     def pipe_flush(self):
         self._check(self._L.rd_pipe_flush(self._h))
 

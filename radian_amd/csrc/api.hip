@@ -126,7 +126,16 @@ extern "C" int rd_destroy(rd_ctx* ctx)
     timer_free(ctx->timer_decode);
     timer_free(ctx->timer_head);
     timer_free(ctx->timer_in);
-    DevBuf* bufs[] = {&ctx->ws_tiles, &ctx->ws_raw, &ctx->ws_act2, &ctx->ws_in, &ctx->ws_act0, &ctx->ws_act1, &ctx->ws_probs, &ctx->ws_mat, &ctx->ws_seq,
+    for (int i = 0; i < RD_MAX_LANES; i++) {
+        FwdLane& L = ctx->lanes[i];
+        if (i > 0 && L.st) {
+            (void)hipStreamSynchronize(L.st);
+            (void)hipStreamDestroy(L.st);
+        }
+        if (L.done) (void)hipEventDestroy(L.done);
+        for (DevBuf& b : L.act) b.release();
+    }
+    DevBuf* bufs[] = {&ctx->ws_tiles, &ctx->ws_raw, &ctx->ws_in, &ctx->ws_probs, &ctx->ws_mat, &ctx->ws_seq,
                       &ctx->ws_nodes_child, &ctx->ws_nodes_back, &ctx->ws_labels, &ctx->ws_misc, &ctx->model.storage,
                       &ctx->lm.storage, &ctx->lm.gate_storage};
     for (DevBuf* b : bufs) b->release();
@@ -147,8 +156,7 @@ extern "C" int rd_set_precision(rd_ctx* ctx, int mode)
 extern "C" int rd_sync(rd_ctx* ctx)
 {
     RD_REQUIRE(ctx, "rd_sync: null context");
-    RD_HIP(hipStreamSynchronize(ctx->stream));
-    return RD_OK;
+    return rd_sync_lanes(ctx);
 }
 
 // --------------------------------------------------------------------------------------------- weights
@@ -869,13 +877,14 @@ struct PipeSlot {
     size_t h_meta_cap = 0;
     void* h_out = nullptr;
     size_t h_out_cap = 0;
-    hipEvent_t fwd_done = nullptr, dec_done = nullptr;
+    hipEvent_t dec_done = nullptr;
     bool busy = false;      // decode launched, labels not yet delivered
     int T = 0, W = 0, nwin = 0;
     int64_t rows = 0;       // probability rows produced into this slot so far
     std::vector<PipeSub> subs;
     std::vector<int64_t> off1, off2;   // per window: source rows (see DecodeArgs)
     std::vector<int32_t> split, valid;
+    unsigned lane_mask = 0; // forward lanes that produced rows of the open group
 };
 
 struct Pipe {
@@ -883,6 +892,8 @@ struct Pipe {
     PipeSlot slot[2];
     int cur = 0;
     int group = 4;          // batches per decode launch
+    int lanes = 2;          // forward lanes the submitted batches rotate over
+    int next_lane = 0;
 };
 
 int pinned_reserve(void** p, size_t* cap, size_t bytes)
@@ -905,7 +916,6 @@ int pipe_get(rd_ctx* ctx, Pipe** out)
         RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         RD_HIP(hipStreamCreateWithPriority(&p->s_dec, hipStreamNonBlocking, hi));
         for (int i = 0; i < 2; i++) {
-            RD_HIP(hipEventCreateWithFlags(&p->slot[i].fwd_done, hipEventDisableTiming));
             RD_HIP(hipEventCreateWithFlags(&p->slot[i].dec_done, hipEventDisableTiming));
         }
         ctx->pipe = p;
@@ -923,6 +933,7 @@ void pipe_reset(PipeSlot& s)
     s.valid.clear();
     s.nwin = 0;
     s.rows = 0;
+    s.lane_mask = 0;
 }
 
 int pipe_collect(PipeSlot& s)
@@ -955,7 +966,6 @@ int pipe_launch_decode(rd_ctx* ctx, Pipe* p, PipeSlot& s)
     if (s.nwin == 0 || s.busy) return RD_OK;
     int rc;
     const size_t n = (size_t)s.nwin, nT = n * s.T;
-    RD_HIP(hipEventRecord(s.fwd_done, ctx->stream));
     // metadata: [off1 | off2 | node_off | label_off] int64, then [seq_len | split] int32, then label_len int32 (device only)
     const size_t a8 = align_up(n * 8, 256), a4 = align_up(n * 4, 256);
     const size_t o_off2 = a8, o_node = 2 * a8, o_lab = 3 * a8, o_len = 4 * a8, o_split = o_len + a4, o_llen = o_split + a4;
@@ -977,7 +987,8 @@ int pipe_launch_decode(rd_ctx* ctx, Pipe* p, PipeSlot& s)
     }
     if (s.labels.reserve(nT + 16)) return RD_ERR_NOMEM;
     if ((rc = pinned_reserve(&s.h_out, &s.h_out_cap, align_up(nT, 256) + n * 4))) return rc;
-    RD_HIP(hipStreamWaitEvent(p->s_dec, s.fwd_done, 0));
+    for (int l = 0; l < RD_MAX_LANES; l++)   // every forward that wrote into this slot has finished (a lane's event is its latest forward)
+        if (s.lane_mask & (1u << l)) RD_HIP(hipStreamWaitEvent(p->s_dec, ctx->lanes[l].done, 0));
     RD_HIP(hipMemcpyAsync(s.meta.p, s.h_meta, o_llen, hipMemcpyHostToDevice, p->s_dec));
     char* dm = (char*)s.meta.p;
     rc = rd_decode_dev(ctx, s.probs.p, 0, (const int64_t*)dm, (const int32_t*)(dm + o_len), (const int64_t*)(dm + o_node),
@@ -1042,7 +1053,6 @@ void pipe_destroy(rd_ctx* ctx)
         s.labels.release();
         if (s.h_meta) (void)hipHostFree(s.h_meta);
         if (s.h_out) (void)hipHostFree(s.h_out);
-        if (s.fwd_done) (void)hipEventDestroy(s.fwd_done);
         if (s.dec_done) (void)hipEventDestroy(s.dec_done);
     }
     if (p->s_dec) (void)hipStreamDestroy(p->s_dec);
@@ -1068,6 +1078,20 @@ extern "C" int rd_pipe_config(rd_ctx* ctx, int group_batches)
     return RD_OK;
 }
 
+extern "C" int rd_pipe_set_lanes(rd_ctx* ctx, int lanes)
+{
+    RD_REQUIRE(ctx, "rd_pipe_set_lanes: null context");
+    RD_REQUIRE(lanes >= 1 && lanes <= RD_MAX_LANES, "rd_pipe_set_lanes: %d out of range [1,%d]", lanes, RD_MAX_LANES);
+    Pipe* p = nullptr;
+    int rc = pipe_get(ctx, &p);
+    if (rc) return rc;
+    RD_REQUIRE(p->slot[0].nwin == 0 && p->slot[1].nwin == 0 && !p->slot[0].busy && !p->slot[1].busy,
+               "rd_pipe_set_lanes: pipeline not empty (call rd_pipe_flush first)");
+    p->lanes = lanes;
+    p->next_lane = 0;
+    return RD_OK;
+}
+
 extern "C" int rd_pipe_submit(rd_ctx* ctx, const float* d_windows, int n_windows, int chunk_len, const int32_t* valid_len,
                               int beam_width, uint8_t* labels_out, int32_t* label_len)
 {
@@ -1083,8 +1107,11 @@ extern "C" int rd_pipe_submit(rd_ctx* ctx, const float* d_windows, int n_windows
     PipeSlot* s = nullptr;
     const int64_t rows = (int64_t)n_windows * chunk_len;
     if ((rc = pipe_open_slot(ctx, p, chunk_len, beam_width, rows, &s))) return rc;
-    rc = rd_forward_dev(ctx, d_windows, n_windows, chunk_len, s->probs.as<float>() + (size_t)s->rows * 5);
+    const int lane = p->next_lane;
+    p->next_lane = (p->next_lane + 1) % p->lanes;
+    rc = rd_forward_dev(ctx, d_windows, n_windows, chunk_len, s->probs.as<float>() + (size_t)s->rows * 5, lane);
     if (rc) return rc;
+    s->lane_mask |= 1u << lane;
     PipeSub sb;
     sb.n = n_windows;
     sb.win0 = s->nwin;
@@ -1189,7 +1216,7 @@ int get_plan(rd_ctx* ctx, const int64_t* read_off, int n_reads, int chunk, int s
         }
         if (pc->d_tiles.reserve(total * sizeof(TileDesc) + 16)) return RD_ERR_NOMEM;
         // make sure no forward still reads the previous descriptors
-        RD_HIP(hipStreamSynchronize(ctx->stream));
+        if ((rc = rd_sync_lanes(ctx))) return rc;
         size_t off = 0;
         for (int li = 0; li < RD_MAX_LAYERS; li++) {
             pc->lists.d[li] = nullptr;
@@ -1452,8 +1479,11 @@ extern "C" int rd_pipe_submit_reads(rd_ctx* ctx, const float* d_signal, const in
     if ((rc = pipe_get(ctx, &p))) return rc;
     PipeSlot* s = nullptr;
     if ((rc = pipe_open_slot(ctx, p, chunk_len, beam_width, P->total_rows, &s))) return rc;
-    rc = rd_forward_tiles_dev(ctx, d_signal, *tl, P->total_rows, s->probs.as<float>() + (size_t)s->rows * 5);
+    const int lane = p->next_lane;
+    p->next_lane = (p->next_lane + 1) % p->lanes;
+    rc = rd_forward_tiles_dev(ctx, d_signal, *tl, P->total_rows, s->probs.as<float>() + (size_t)s->rows * 5, lane);
     if (rc) return rc;
+    s->lane_mask |= 1u << lane;
     PipeSub sb;
     sb.n = P->n_windows;
     sb.win0 = s->nwin;

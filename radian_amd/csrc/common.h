@@ -119,6 +119,16 @@ struct KernelTimer {
     double bytes = 0.0;
 };
 
+// One forward "lane": a stream with its own three activation tensors.  Lane 0 is the context's main stream; the
+// pipelined entry points spread consecutive batches over several lanes so that independent kernel chains overlap (the
+// partially filled last round of one chain's launch is filled by the other chain's workgroups).
+constexpr int RD_MAX_LANES = 4;
+struct FwdLane {
+    hipStream_t st = nullptr;
+    DevBuf act[3];
+    hipEvent_t done = nullptr;   // recorded after the lane's latest forward
+};
+
 struct rd_ctx {
     int device = 0;
     int precision = 0;   // 0: exact fp32 MFMA (default); 1: split-f16 (f16x3) matrix products
@@ -128,8 +138,8 @@ struct rd_ctx {
     // workspaces
     DevBuf ws_tiles, ws_raw;
     int tiles_nW = -1, tiles_T = -1;   // shape the cached uniform tile descriptors were built for
-    DevBuf ws_act2;
-    DevBuf ws_in, ws_act0, ws_act1, ws_probs, ws_mat, ws_seq, ws_nodes_child, ws_nodes_back, ws_labels, ws_misc;
+    FwdLane lanes[RD_MAX_LANES];   // lanes[0].st == stream; lanes >= 1 are created on first use
+    DevBuf ws_in, ws_probs, ws_mat, ws_seq, ws_nodes_child, ws_nodes_back, ws_labels, ws_misc;
     // pinned host staging
     void* h_stage = nullptr;
     size_t h_stage_cap = 0;
@@ -140,8 +150,10 @@ struct rd_ctx {
 };
 
 // forward.hip
-int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_probs);
-int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tiles, int64_t total_rows, float* d_probs);
+int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_probs, int lane = 0);
+int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tiles, int64_t total_rows, float* d_probs, int lane = 0);
+int rd_lane_get(rd_ctx* ctx, int lane, FwdLane** out);   // creates the lane's stream on first use
+int rd_sync_lanes(rd_ctx* ctx);                          // every forward stream idle
 int rd_model_halo(const rd_ctx* ctx);  // receptive field - 1 = (K-1) * 2 * sum(dilations)
 // decode.hip
 int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* d_seq_off, const int32_t* d_seq_len,

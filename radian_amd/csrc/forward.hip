@@ -897,7 +897,31 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
 
 }  // namespace
 
-int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl, int64_t total_rows, float* d_probs)
+int rd_lane_get(rd_ctx* ctx, int lane, FwdLane** out)
+{
+    if (lane < 0 || lane >= RD_MAX_LANES) {
+        rd_set_error("forward lane %d out of range", lane);
+        return RD_ERR_ARG;
+    }
+    FwdLane& L = ctx->lanes[lane];
+    if (!L.st) {
+        if (lane == 0) L.st = ctx->stream;
+        else RD_HIP(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
+    }
+    if (!L.done) RD_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+    *out = &L;
+    return RD_OK;
+}
+
+int rd_sync_lanes(rd_ctx* ctx)
+{
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 1; i < RD_MAX_LANES; i++)
+        if (ctx->lanes[i].st) RD_HIP(hipStreamSynchronize(ctx->lanes[i].st));
+    return RD_OK;
+}
+
+int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl, int64_t total_rows, float* d_probs, int lane)
 {
     Model& m = ctx->model;
     if (!m.loaded) {
@@ -906,6 +930,8 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl
     }
     if (total_rows == 0) return RD_OK;
     int rc = RD_OK;
+    FwdLane* L = nullptr;
+    if ((rc = rd_lane_get(ctx, lane, &L))) return rc;
     if (total_rows >= INT32_MAX) {
         rd_set_error("rd_forward: %lld rows in one batch (the kernels index rows with 32 bits)", (long long)total_rows);
         return RD_ERR_ARG;
@@ -913,25 +939,26 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl
     // each activation tensor carries one extra row of zeros behind its last row: the source of the causal left padding
     const size_t row_bytes = (size_t)RD_C * sizeof(float);
     const size_t act_bytes = (size_t)(total_rows + 1) * row_bytes;
-    if (ctx->ws_act0.reserve(act_bytes) || ctx->ws_act1.reserve(act_bytes) || ctx->ws_act2.reserve(act_bytes)) return RD_ERR_NOMEM;
-    float* Xin = ctx->ws_act0.as<float>();
-    float* Xout = ctx->ws_act1.as<float>();
-    float* MID = ctx->ws_act2.as<float>();
+    if (L->act[0].reserve(act_bytes) || L->act[1].reserve(act_bytes) || L->act[2].reserve(act_bytes)) return RD_ERR_NOMEM;
+    float* Xin = L->act[0].as<float>();
+    float* Xout = L->act[1].as<float>();
+    float* MID = L->act[2].as<float>();
     const int zero_row = (int)total_rows;
-    RD_HIP(hipMemsetAsync(Xin + (size_t)zero_row * RD_C, 0, row_bytes, ctx->stream));
-    RD_HIP(hipMemsetAsync(Xout + (size_t)zero_row * RD_C, 0, row_bytes, ctx->stream));
-    RD_HIP(hipMemsetAsync(MID + (size_t)zero_row * RD_C, 0, row_bytes, ctx->stream));
+    RD_HIP(hipMemsetAsync(Xin + (size_t)zero_row * RD_C, 0, row_bytes, L->st));
+    RD_HIP(hipMemsetAsync(Xout + (size_t)zero_row * RD_C, 0, row_bytes, L->st));
+    RD_HIP(hipMemsetAsync(MID + (size_t)zero_row * RD_C, 0, row_bytes, L->st));
     const int nl = 2 * m.nblocks + 1;
     for (int li = 0; li < nl; li++) {
         const int b = li == nl - 1 ? m.nblocks : li / 2;
         const int kind = li == nl - 1 ? 3 : (li == 0 ? 0 : (li & 1 ? 2 : 1));
-        if ((rc = launch_layer(ctx, ctx->stream, b, kind, tl.d[li], tl.n[li], (double)tl.rows[li], zero_row, d_signal, Xin, Xout, MID, d_probs))) return rc;
+        if ((rc = launch_layer(ctx, L->st, b, kind, tl.d[li], tl.n[li], (double)tl.rows[li], zero_row, d_signal, Xin, Xout, MID, d_probs))) return rc;
         if (kind == 2) {   // block finished: its output becomes the next block's input
             float* t = Xin;
             Xin = Xout;
             Xout = t;
         }
     }
+    RD_HIP(hipEventRecord(L->done, L->st));
     return RD_OK;
 }
 
@@ -959,7 +986,7 @@ int rd_uniform_tiles(rd_ctx* ctx, int nW, int T, TileLists* out)
             td.pad_ = 0;
         }
         if (ctx->ws_tiles.reserve(h.size() * sizeof(TileDesc))) return RD_ERR_NOMEM;
-        RD_HIP(hipStreamSynchronize(ctx->stream));   // no forward may still be reading the previous descriptors
+        if (int rcs = rd_sync_lanes(ctx)) return rcs;   // no forward may still be reading the previous descriptors
         RD_HIP(hipMemcpy(ctx->ws_tiles.p, h.data(), h.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
         ctx->tiles_nW = nW;
         ctx->tiles_T = T;
@@ -974,7 +1001,7 @@ int rd_uniform_tiles(rd_ctx* ctx, int nW, int T, TileLists* out)
 }
 
 // d_windows [nW][T] fp32 (already MAD-normalised) -> d_probs [nW][T][5] fp32; all on ctx->stream.
-int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_probs)
+int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_probs, int lane)
 {
     RD_REQUIRE(nW >= 0 && T >= 1, "rd_forward: bad shape nW=%d T=%d", nW, T);
     if (nW == 0) return RD_OK;
@@ -985,5 +1012,5 @@ int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_
     TileLists tl;
     int rc = rd_uniform_tiles(ctx, nW, T, &tl);
     if (rc) return rc;
-    return rd_forward_tiles_dev(ctx, d_windows, tl, (int64_t)nW * T, d_probs);
+    return rd_forward_tiles_dev(ctx, d_windows, tl, (int64_t)nW * T, d_probs, lane);
 }
