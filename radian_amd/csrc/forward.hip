@@ -175,16 +175,20 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
         for (int pc = 0; pc < NPIECE; pc++) stage_piece(chunk, tap, st, pc);
     };
 
-    f32x16 acc[2][NT];
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int n = 0; n < NT; n++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[m][n][e] = 0.f;
-
     const int fr = lane & 31;
     const int fh = lane >> 5;
+    // the accumulators start at the bias of their output channel (a lane holds ONE channel of each N tile): the epilogue
+    // then has no add to do before the ReLU
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+        const float bias = a.bias[wn * NT * 32 + n * 32 + fr];
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[m][n][e] = bias;
+    }
+
     const int swz = (fr >> 2) & 3;
     int koff[BK / 8];
 #pragma unroll
@@ -288,15 +292,14 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
             const bool interior = sd.t0 + 32 <= T;
 #pragma unroll
             for (int np = 0; np < NT / 2; np++) {
-                // ---- accumulators (+ bias, ReLU) -> LDS patch
+                // ---- accumulators (ReLU) -> LDS patch
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     const int n = 2 * np + j;
-                    const float bias = a.bias[wn * NT * 32 + n * 32 + fr];
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
                         const int rl = (e & 3) + 8 * (e >> 2) + 4 * fh;
-                        float v = acc[m][n][e] + bias;
+                        const float v = acc[m][n][e];   // bias included since the start
                         ts[rl * TSTR + j * 32 + fr] = v > 0.f ? v : 0.f;
                     }
                 }
@@ -350,13 +353,12 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
 #pragma unroll
         for (int n = 0; n < NT; n++) {
             const int hcol = wn * NT * 32 + n * 32 + fr;
-            const float bias = a.bias[hcol];
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const int row = wm * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                    float v = acc[m][n][e] + bias;
+                    const float v = acc[m][n][e];
                     hs[row * LDH + hcol] = v > 0.f ? v : 0.f;
                 }
         }
@@ -529,16 +531,19 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
         for (int pc = 0; pc < NPIECE; pc++) stage_piece(chunk, tap, st, pc);
     };
 
-    f32x16 acc[2][NT];
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int n = 0; n < NT; n++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[m][n][e] = 0.f;
-
     const int fr = lane & 31;
     const int fh = lane >> 5;
+    // accumulators start at bias / inv_scale (inv_scale is a power of two: exact), see the fp32 kernel
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+        const float bias = a.bias[wn * NT * 32 + n * 32 + fr] / a.inv_scale;
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[m][n][e] = bias;
+    }
+
     const int swz = (fr >> 2) & 3;
     const int oh = (fh ^ swz) * 8;         // halves: hi slot of this lane's k = 8 fh .. 8 fh + 7
     const int ol = ((2 + fh) ^ swz) * 8;   // lo slot
@@ -624,11 +629,10 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     const int n = 2 * np + j;
-                    const float bias = a.bias[wn * NT * 32 + n * 32 + fr];
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
                         const int rl = (e & 3) + 8 * (e >> 2) + 4 * fh;
-                        float v = acc[m][n][e] * a.inv_scale + bias;
+                        const float v = acc[m][n][e] * a.inv_scale;
                         ts[rl * TSTR + j * 32 + fr] = v > 0.f ? v : 0.f;
                     }
                 }
@@ -696,13 +700,12 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
 #pragma unroll
         for (int n = 0; n < NT; n++) {
             const int hcol = wn * NT * 32 + n * 32 + fr;
-            const float bias = a.bias[hcol];
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const int row = wm * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                    float v = acc[m][n][e] * a.inv_scale + bias;
+                    const float v = acc[m][n][e] * a.inv_scale;
                     hs[row * LDH + hcol] = v > 0.f ? v : 0.f;
                 }
         }
