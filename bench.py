@@ -242,6 +242,10 @@ def main():
             "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_s * 1e3, "launches_timed": tc["launches"],
             "conv_ms_per_step": tc["total_ms"] / n_prof, "decode_ms_per_step": td["total_ms"] / n_prof,
             "head_ms_per_step": th["total_ms"] / n_prof,
+            "timing": "HIP events around every launch of a forward + beam search run on ONE stream after the timed region "
+                      "(launches back to back: the kernel's own duration; = profiles/*_kernel_stats.csv, taken with --lanes 1). "
+                      "In the timed region the launches of consecutive batches overlap on two lanes, so a launch's bracketed "
+                      "duration there also counts the time it shares the chip (profiles/*_kernel_stats_default_2lanes.csv)",
             "decode_timesteps_per_s": float(sum(b[1].sum() for b in batches[:n_prof])) / max(1e-9, td["total_ms"] * 1e-3),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -28,7 +28,10 @@ for f in ["pmc_sq", "pmc_fetch", "pmc_write", "pmc_lds"]:
         for c, x in v.items():
             out.setdefault(k, {})[c] = {"mean_per_dispatch": sum(x) / len(x), "dispatches": len(x)}
 stats = glob.glob(base + "trace/*/*_kernel_stats.csv")[0]
-shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
+shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")   # one forward lane: launches back to back
+two = glob.glob(base + "trace2/*/*_kernel_stats.csv")
+if two:
+    shutil.copy(two[0], f"profiles/{tag}_kernel_stats_default_2lanes.csv")   # default command: launches of two batches overlap
 dur = {}
 for r in csv.DictReader(open(stats)):
     k = short(r["Name"])
@@ -42,7 +45,7 @@ for k in ["conv_relu", "conv_res_ident", "conv_res_match"]:
     derived[k] = {"avg_ns_trace": dur.get(k), "cycles_per_xcd": cyc, "mfma_busy_cycles_per_simd": mf, "mfma_util": mf / cyc,
                   "eff_clock_ghz": cyc / dur[k] if k in dur else None,
                   "hbm_bytes": (2 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024}
-json.dump({"round": tag, "command": "tools_prof.sh (rocprofv3 --pmc <group>, one pass per counter group; python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline)",
+json.dump({"round": tag, "command": "tools_prof.sh (rocprofv3 --pmc <group>, one pass per counter group; python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --lanes 1; durations from the --kernel-trace pass of the same command)",
            "units": {"FETCH_SIZE": "KiB; gfx950 tallies 16-B-per-lane loads (incl. LDS-DMA) at half their bytes -> doubled in hbm_bytes",
                      "WRITE_SIZE": "KiB", "SQ_*": "quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES (cycles summed over SIMDs)",
                      "GRBM_GUI_ACTIVE": "cycles summed over 8 XCDs"},
