@@ -46,6 +46,8 @@ def build_parser():
     parser.add_argument("--gpus", default=1, type=int, help="shard reads over this many GPUs (one process each)")
     parser.add_argument("--device-contexts", default=2, type=int,
                         help="independent device contexts (streams) per GPU: batch i+1's forward overlaps batch i's beam search")
+    parser.add_argument("--stitch-workers", default=min(4, max(1, (os.cpu_count() or 2) // 4)), type=int,
+                        help="worker processes for the chunk-mode fragment stitch (0: stitch on the driver's host thread)")
     parser.add_argument("--gpu-batch-windows", default=4096, type=int,
                         help="device batch size across reads, in windows (chunk mode) or chunk_len-row units (global mode)")
     return parser
@@ -125,6 +127,30 @@ def device_batch(be, batch, args, use_lm):
     return be.basecall_raw_chunk(raws, args.outlier_clip, args.chunk_len, args.step_size, args.beam_width)
 
 
+def _stitch_reads(frag_lists):
+    """worker-process task: fragments (label arrays) of a few reads -> their consensus strings"""
+    return [consensus_sequence([labels_to_str(f) for f in frags]) for frags in frag_lists]
+
+
+def make_stitch_pool(n_workers):
+    """Process pool for the chunk-mode string stitch (pure Python difflib, the reference's own algorithm; one interpreter
+    cannot keep up with one GPU).  Must be created BEFORE the process touches the GPU: the workers are spawned fresh
+    interpreters that never load the HIP library."""
+    if n_workers <= 0:
+        return None
+    import multiprocessing
+    from concurrent.futures import ProcessPoolExecutor
+    pool = ProcessPoolExecutor(max_workers=n_workers, mp_context=multiprocessing.get_context("spawn"))
+    try:
+        for f in [pool.submit(_stitch_reads, []) for _ in range(n_workers)]:   # start every worker now
+            f.result()
+    except Exception as e:   # e.g. a __main__ that cannot be re-imported by the workers: stitch on the host thread instead
+        print(f"stitch workers unavailable ({type(e).__name__}: {e}); stitching on the driver thread", file=sys.stderr)
+        pool.shutdown(wait=False, cancel_futures=True)
+        return None
+    return pool
+
+
 def host_finish(labels, args):
     """labels of one read -> its (un-reversed) sequence; chunk mode stitches the fragments (basecall.py:122-123)."""
     if args.decode_type == "global":
@@ -132,7 +158,7 @@ def host_finish(labels, args):
     return consensus_sequence([labels_to_str(f) for f in labels])
 
 
-def run(args, be, reads=None, writer=None, shard=(0, 1)):
+def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None):
     """The driver loop (basecall.py:69-141) over `reads` (default: every read under args.fast5_dir).
     shard=(rank, world): this process handles reads whose index % world == rank and returns
     [(read_index, read_id, sequence)] instead of writing when writer is None.
@@ -158,11 +184,18 @@ def run(args, be, reads=None, writer=None, shard=(0, 1)):
     n_submitted = 0
 
     def finish(b, b_idx, labels, status, dur):
+        seqs = None
+        if stitch_pool is not None and args.decode_type == "chunk":
+            # the reads of the batch in slices, one task each; results come back in order
+            ok = [lab for lab, st in zip(labels, status) if st == 0]
+            per = max(1, -(-len(ok) // (4 * stitch_pool._max_workers)))
+            futs = [stitch_pool.submit(_stitch_reads, ok[i:i + per]) for i in range(0, len(ok), per)]
+            seqs = iter([sq for f in futs for sq in f.result()])
         for (rid, _), idx, lab, st in zip(b, b_idx, labels, status):
             if st != 0:
                 report_skipped(rid, st)
                 continue
-            seq = host_finish(lab, args)
+            seq = next(seqs) if seqs is not None else host_finish(lab, args)
             if writer is not None:
                 writer.write(rid, seq)
             results.append((idx, rid, seq))
@@ -250,17 +283,20 @@ def main(argv=None):
     if args.gpus > 1:
         from .launch import run_multi_gpu
         return run_multi_gpu(args, argv if argv is not None else sys.argv[1:])
+    pool = make_stitch_pool(args.stitch_workers) if args.decode_type == "chunk" else None   # before the GPU is touched
     from .backend import Backend
     bes = [Backend(args.device) for _ in range(max(1, args.device_contexts))]
     for b in bes:
         setup_backend(args, b)
     writer = FastaWriter(args.fasta_dir)
     try:
-        run(args, bes, writer=writer)
+        run(args, bes, writer=writer, stitch_pool=pool)
     finally:
         writer.close()  # basecall.py:141
         for b in bes:
             b.close()
+        if pool is not None:
+            pool.shutdown()
 
 
 if __name__ == "__main__":

@@ -36,10 +36,11 @@ def run_multi_gpu(args, argv):
 
 def worker(scratch, tag, argv):
     from .backend import Backend
-    from .basecall import build_parser, run, setup_backend
+    from .basecall import build_parser, make_stitch_pool, run, setup_backend
     from .dist import RcclComm, env_rank_world, uid_path
     args = build_parser().parse_args(argv)
     rank, local_rank, world = env_rank_world()
+    pool = make_stitch_pool(args.stitch_workers) if args.decode_type == "chunk" else None   # before the GPU is touched
     be = Backend(local_rank)
     comm = RcclComm(be, rank, world, uid_path(tag))
     # rank 0 parses / repacks the artefacts; everyone gets the device images by one broadcast
@@ -53,13 +54,15 @@ def worker(scratch, tag, argv):
     # the flag `_lm_loaded` is host state: recompute it on the other ranks without touching the files' contents
     if rank != 0:
         args._lm_loaded = (args.rna_model != "None" and args.decode_type == "global")
-    results = run(args, be, writer=None, shard=(rank, world))
+    results = run(args, be, writer=None, shard=(rank, world), stitch_pool=pool)
     with open(os.path.join(scratch, f"rank{rank}.jsonl"), "w") as f:
         for r in results:
             f.write(json.dumps(list(r)) + "\n")
     comm.barrier()
     comm.close()
     be.close()
+    if pool is not None:
+        pool.shutdown()
 
 
 if __name__ == "__main__":
