@@ -166,7 +166,7 @@ constexpr size_t CONV_PK = (size_t)RD_K * RD_C * RD_C;  // 196608 floats
 constexpr size_t D1_PK = (size_t)RD_C * RD_H;
 
 struct ModelLayout {
-    size_t zeros, sink, w_in, b_in, w_match, b_match, w_conv[2 * RD_MAX_BLOCKS], b_conv[2 * RD_MAX_BLOCKS], w_d1, b_d1, w_d2, b_d2;
+    size_t sink, w_in, b_in, w_match, b_match, w_conv[2 * RD_MAX_BLOCKS], b_conv[2 * RD_MAX_BLOCKS], w_d1, b_d1, w_d2, b_d2;
     size_t ws_conv[2 * RD_MAX_BLOCKS], ws_d1, total;
 };
 
@@ -179,7 +179,6 @@ ModelLayout model_layout(int nblocks)
         off += align_up(n, 64);
         return o;
     };
-    L.zeros = take(64);
     L.sink = take(1024);
     L.w_in = take(RD_K * RD_C);
     L.b_in = take(RD_C);
@@ -208,7 +207,6 @@ ModelLayout model_layout(int nblocks)
 void model_bind(Model& m, const ModelLayout& L)
 {
     float* base = m.storage.as<float>();
-    m.zeros = base + L.zeros;
     m.sink = base + L.sink;
     m.w_in = base + L.w_in;
     m.b_in = base + L.b_in;

@@ -53,7 +53,6 @@ struct Model {
     int nblocks = 0;
     int dil[RD_MAX_BLOCKS] = {0};
     // device tensors (packed layouts, see forward.hip)
-    float* zeros = nullptr;     // 64 zero floats
     float* sink = nullptr;      // 1024 floats, write-only scratch
     float* w_in = nullptr;      // block0.conv0 kernel [3][256]
     float* b_in = nullptr;      // [256]

@@ -62,17 +62,13 @@ struct ConvArgs {
 // contiguously), with the four 16-B slots of each row XOR-swizzled by (row >> 2) & 3: the 16 lanes of a ds_read_b128
 // group hold four runs of 4 consecutive rows (row & 3 = 0..3 picks the 64-B quarter of the 256-B bank row) whose
 // row >> 2 differ mod 4, so the group hits 16 different 16-B bank slots.  The swizzle is applied on the global SOURCE
-// address of the DMA and again on the read.  (The split-f16 kernel below keeps 128-B rows and (row >> 1) & 7.)
-__device__ __forceinline__ void glds16(const float* src, float* lds_dst)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
-// The same instruction outside hipcc's s_waitcnt bookkeeping: with the builtin, hipcc drains vmcnt(0) before the first
-// ds_read that follows (it cannot tell the two LDS halves apart), which would serialise the prefetch of the next chunk
-// with the MFMAs of this one.  The kernel counts these loads by hand (wait_dma()).  M0 carries the wave-uniform LDS
-// byte address and is compiler-reserved: saved and restored inside the statement.
+// address of the DMA and again on the read.  (The split-f16 kernel uses the same image with [16 hi | 16 lo] halves.)
+//
+// The LDS-DMA instruction is issued by inline asm, outside hipcc's s_waitcnt bookkeeping: with the builtin
+// (__builtin_amdgcn_global_load_lds) hipcc drains vmcnt(0) before the first ds_read that follows (it cannot tell the
+// LDS stages apart), which would serialise the prefetch of the next chunks with the MFMAs of this one.  The kernels
+// count these loads by hand (wait_dma_and_barrier<N>).  M0 carries the wave-uniform LDS byte address and is
+// compiler-reserved: saved and restored inside the statement.
 __device__ __forceinline__ void glds16_uncounted(const float* src, float* lds_dst)
 {
     unsigned keep;

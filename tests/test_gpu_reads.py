@@ -110,20 +110,23 @@ def test_pipe_submit_reads_equals_unpipelined(be):
         be.h2d(d, b)
         dptr.append(d)
     be.pipe_config(2)
-    outs = [(np.zeros((nwin, chunk), dtype=np.uint8), np.full(nwin, -1, dtype=np.int32)) for _ in batches]
-    for b in range(len(batches)):
-        be.pipe_submit_reads(dptr[b], read_off, n_reads, chunk, step, W, outs[b][0], outs[b][1])
-    be.pipe_flush()
-    for b in range(len(batches)):
-        lab, ln = outs[b]
-        w = 0
-        for r in range(n_reads):
-            for frag in ref[b][r]:
-                assert ln[w] == len(frag) and np.array_equal(lab[w, : ln[w]], frag), (b, r, w)
-                w += 1
+    for lanes in (1, 2, 4):   # forwards of consecutive batches on 1 / 2 / 4 independent streams: same labels
+        be.pipe_set_lanes(lanes)
+        outs = [(np.zeros((nwin, chunk), dtype=np.uint8), np.full(nwin, -1, dtype=np.int32)) for _ in batches]
+        for b in range(len(batches)):
+            be.pipe_submit_reads(dptr[b], read_off, n_reads, chunk, step, W, outs[b][0], outs[b][1])
+        be.pipe_flush()
+        for b in range(len(batches)):
+            lab, ln = outs[b]
+            w = 0
+            for r in range(n_reads):
+                for frag in ref[b][r]:
+                    assert ln[w] == len(frag) and np.array_equal(lab[w, : ln[w]], frag), (lanes, b, r, w)
+                    w += 1
     for d in dptr:
         be.dev_free(d)
     be.pipe_config(4)
+    be.pipe_set_lanes(2)
 
 
 def test_normalise_on_device_matches_golden_and_numpy(be, golden_dir):
