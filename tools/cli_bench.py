@@ -2,7 +2,7 @@
 """End-to-end CLI timing on a synthetic multi-read fast5 (GPU box): fast5 in -> FASTA out, both decode types."""
 import os, sys, tempfile, time
 import numpy as np
-R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.abspath(__file__)))
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 from radian_amd import fast5, basecall, synthetic
 

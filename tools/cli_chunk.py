@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Chunk-mode CLI end to end on N synthetic reads with different numbers of stitch workers."""
 import os, sys, tempfile, time
-R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.abspath(__file__)))
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 import os, sys, tempfile, cProfile, pstats, io
 import numpy as np
-R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.abspath(__file__)))
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 from radian_amd import fast5, basecall, synthetic
 n_reads = 4096

@@ -2,7 +2,7 @@
 """Beam search alone (no concurrent forward): n windows x T time steps resident in HBM, W = 10; HIP-event time per launch."""
 import os, sys, time
 import numpy as np
-R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.abspath(__file__)))
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 from radian_amd import Backend, weights, synthetic
 from radian_amd.backend import RD_TIMER_DECODE

@@ -3,7 +3,7 @@
 W=25 stress of configs[4] (chunk decode), unpipelined reads-level calls; for DESIGN.md."""
 import os, sys, time
 import numpy as np
-R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.abspath(__file__)))
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 from radian_amd import Backend, weights, synthetic
 from radian_amd.preprocess import mad_normalise

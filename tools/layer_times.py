@@ -2,7 +2,7 @@
 """Per-launch conv times (HIP events) for the chunk plan (streams + heads) vs streams only, 64 reads x 4096."""
 import os, sys
 import numpy as np
-R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.abspath(__file__)))
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 from radian_amd import Backend, weights, synthetic
 from radian_amd.backend import RD_TIMER_CONV

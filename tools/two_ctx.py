@@ -3,7 +3,7 @@
 alternately (two independent kernel chains, so one chain's partially filled last round overlaps the other's launches)."""
 import os, sys, time
 import numpy as np
-R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.abspath(__file__)))
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 from radian_amd import Backend, weights, synthetic
 from radian_amd.preprocess import mad_normalise
