@@ -18,7 +18,7 @@ def _stale():
 
 
 def build(force=False, verbose=False, defines=(), out=None):
-    """defines/out: build an experiment variant (-D...) into another file (tools_variants.sh); the product build uses neither."""
+    """defines/out: build an experiment variant (-D...) into another file (tools/variants.sh); the product build uses neither."""
     if not force and not _stale() and out is None:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

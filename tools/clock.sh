@@ -6,7 +6,7 @@ cd $R
 for so in radian_amd/variants/lib_*.so; do
   tag=$(basename $so .so)
   export RADIAN_HIP_LIB=$R/$so
-  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d gpurun_out/clock_$tag -- python3 tools_layer_times.py > gpurun_out/clock_$tag.log 2>&1 || exit 1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d gpurun_out/clock_$tag -- python3 tools/layer_times.py > gpurun_out/clock_$tag.log 2>&1 || exit 1
   python3 - $tag <<'PY'
 import csv, glob, sys, collections
 tag = sys.argv[1]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes for the bench (run on the GPU box via gpurun): kernel trace + PMC passes (separate runs).
-# usage: tools_prof.sh <tag>
+# usage: tools/prof.sh <tag>
 set -u
 TAG=${1:-r01}
 export TMPDIR=/tmp
