@@ -854,12 +854,14 @@ extern "C" int rd_count_windows(int64_t n_samples, int chunk_len, int step)
     return count_windows(n_samples, chunk_len, step);
 }
 
-// --------------------------------------------------------------------------------------------- two-stream pipeline
-// Chunk-mode batches flow through two HIP streams: forwards (MFMA-bound) run back to back on ctx->stream; the beam
-// search (one wave per window, latency-bound) of a GROUP of batches runs on a second, high-priority stream together
-// with its label copy-out, overlapped with the forwards of the next group.  Grouping matters because the decoder's
-// throughput comes from waves per SIMD: 4 x 512 windows decode in about the time of 512.  Two slots of probability /
-// metadata / pinned output buffers; a slot is recycled only after its labels were handed to the caller.
+// --------------------------------------------------------------------------------------------- software pipeline
+// Chunk-mode batches flow through several HIP streams.  Forwards (MFMA-bound): consecutive batches rotate over a few
+// forward lanes (FwdLane: a stream + its own activation tensors), so two independent kernel chains are in flight and the
+// partially filled last round of one chain's launch is filled by the other's workgroups.  Beam search (one wave per
+// window, latency-bound): the windows of a GROUP of batches are decoded by one launch on a further, high-priority
+// stream together with their label copy-out, overlapped with the forwards of the next group.  Grouping matters because
+// the decoder's throughput comes from waves per SIMD: 4 x 512 windows decode in about the time of 512.  Two slots of
+// probability / metadata / pinned output buffers; a slot is recycled only after its labels were handed to the caller.
 namespace {
 
 struct PipeSub {
