@@ -48,6 +48,8 @@ def build_parser():
                         help="independent device contexts (streams) per GPU: batch i+1's forward overlaps batch i's beam search")
     parser.add_argument("--stitch-workers", default=min(4, max(1, (os.cpu_count() or 2) // 4)), type=int,
                         help="worker processes for the chunk-mode fragment stitch (0: stitch on the driver's host thread)")
+    parser.add_argument("--queue-block", default=256, type=int,
+                        help="--gpus N: reads per claim of the per-node work queue (0: static round-robin by read index)")
     parser.add_argument("--gpu-batch-windows", default=4096, type=int,
                         help="device batch size across reads, in windows (chunk mode) or chunk_len-row units (global mode)")
     return parser
@@ -158,9 +160,10 @@ def host_finish(labels, args):
     return consensus_sequence([labels_to_str(f) for f in labels])
 
 
-def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None):
+def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue=None):
     """The driver loop (basecall.py:69-141) over `reads` (default: every read under args.fast5_dir).
-    shard=(rank, world): this process handles reads whose index % world == rank and returns
+    shard=(rank, world): this process handles reads whose index % world == rank -- or, with queue (a dist.WorkQueue
+    shared by the ranks of the node), the blocks of consecutive reads it claims from that queue -- and returns
     [(read_index, read_id, sequence)] instead of writing when writer is None.
     `be` is one Backend or a list of Backends on the same GPU (independent rd_ctx / HIP streams): batches go to them
     round robin on one thread each, so the MFMA-bound forward of one batch overlaps the latency-bound beam search of
@@ -233,7 +236,7 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None):
 
     try:
         for idx, read in enumerate(reads):
-            if idx % world != rank:
+            if (not queue.owns(idx)) if queue is not None else (idx % world != rank):
                 continue
             raw = np.asarray(read.get_raw_data())
             n = raw.shape[0]

@@ -184,6 +184,48 @@ class _Recorder:
         self.calls.append(("load_lm", a, kw))
 
 
+class WorkQueue:
+    """Per-node work queue over read indices ("per-rank work queue over fast5 files/reads for real input").
+    The ranks of one node share a counter file; a rank claims the next block of `block` consecutive read indices by
+    advancing the counter under an fcntl lock, so a rank with long reads simply claims fewer blocks.  Every rank walks
+    the same read sequence and asks owns(idx) in increasing idx order; results are merged by index (merge_results)."""
+
+    def __init__(self, path, block=256):
+        import fcntl
+        self._fcntl = fcntl
+        self.path, self.block = path, int(block)
+        if self.block < 1:
+            raise ValueError("work-queue block must be >= 1")
+        self._fd = os.open(path, os.O_RDWR | os.O_CREAT, 0o600)
+        self._start = self._stop = 0
+        self.claimed = []
+
+    def _claim(self):
+        f = self._fcntl
+        f.flock(self._fd, f.LOCK_EX)
+        try:
+            os.lseek(self._fd, 0, os.SEEK_SET)
+            raw = os.read(self._fd, 32)
+            k = int(raw) if raw.strip() else 0
+            os.lseek(self._fd, 0, os.SEEK_SET)
+            os.write(self._fd, b"%-31d\n" % (k + 1))
+        finally:
+            f.flock(self._fd, f.LOCK_UN)
+        self._start, self._stop = k * self.block, (k + 1) * self.block
+        self.claimed.append(k)
+
+    def owns(self, idx):
+        """True iff this rank basecalls read `idx`; idx must not decrease between calls."""
+        while idx >= self._stop:
+            self._claim()
+        return idx >= self._start
+
+    def close(self):
+        if self._fd is not None:
+            os.close(self._fd)
+            self._fd = None
+
+
 def shard_indices(n, rank, world):
     """Round-robin shard of read indices (what basecall.run uses: index % world == rank)."""
     return list(range(rank, n, world))

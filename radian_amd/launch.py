@@ -1,5 +1,5 @@
 """Multi-GPU driver: `python -m radian_amd.basecall ... --gpus N` forks one worker process per GPU
-(this module with --worker), each basecalls the reads whose index % N == rank on its own device and
+(this module with --worker), each basecalls the blocks of reads it claims from a per-node work queue on its own device and
 writes its results to a scratch file; the parent (which never touches a GPU) merges them in input order into
 the reference's FASTA layout.  The only inter-GPU traffic is the start-up RCCL broadcast of the artefacts."""
 import json
@@ -37,7 +37,7 @@ def run_multi_gpu(args, argv):
 def worker(scratch, tag, argv):
     from .backend import Backend
     from .basecall import build_parser, make_stitch_pool, run, setup_backend
-    from .dist import RcclComm, env_rank_world, uid_path
+    from .dist import RcclComm, WorkQueue, env_rank_world, uid_path
     args = build_parser().parse_args(argv)
     rank, local_rank, world = env_rank_world()
     pool = make_stitch_pool(args.stitch_workers) if args.decode_type == "chunk" else None   # before the GPU is touched
@@ -54,7 +54,11 @@ def worker(scratch, tag, argv):
     # the flag `_lm_loaded` is host state: recompute it on the other ranks without touching the files' contents
     if rank != 0:
         args._lm_loaded = (args.rna_model != "None" and args.decode_type == "global")
-    results = run(args, be, writer=None, shard=(rank, world), stitch_pool=pool)
+    # reads go to the ranks through a work queue (a counter file in the launcher's scratch directory): dynamic balance
+    queue = WorkQueue(os.path.join(scratch, "queue"), args.queue_block) if args.queue_block > 0 else None
+    results = run(args, be, writer=None, shard=(rank, world), stitch_pool=pool, queue=queue)
+    if queue is not None:
+        queue.close()
     with open(os.path.join(scratch, f"rank{rank}.jsonl"), "w") as f:
         for r in results:
             f.write(json.dumps(list(r)) + "\n")

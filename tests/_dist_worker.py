@@ -13,6 +13,7 @@ import numpy as np  # noqa: E402
 
 def main():
     out_dir, mode = sys.argv[1], sys.argv[2]
+    queue_block = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     from radian_amd import basecall, dist, weights
     from _oracle_backend import OracleBackend
     from _reads import golden_reads
@@ -31,7 +32,8 @@ def main():
     comm.bcast_artifacts(be, load)
     assert be.w is not None and be.dil == (1, 2, 4)
     args._lm_loaded = mode == "global"
-    res = basecall.run(args, be, reads=golden_reads(1500), writer=None, shard=(rank, world))
+    queue = dist.WorkQueue(os.path.join(out_dir, "queue"), queue_block) if queue_block else None
+    res = basecall.run(args, be, reads=golden_reads(1500), writer=None, shard=(rank, world), queue=queue)
     t = comm.allreduce_max([float(rank)])
     assert t[0] == world - 1
     comm.barrier()

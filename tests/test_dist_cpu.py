@@ -20,15 +20,16 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("mode", ["chunk", "global"])
-def test_two_rank_gloo_equals_single(tmp_path, mode, oracle):
+@pytest.mark.parametrize("mode,queue_block", [("chunk", 0), ("global", 0), ("chunk", 2)])
+def test_two_rank_gloo_equals_single(tmp_path, mode, queue_block, oracle):
+    """queue_block 0: static round-robin shard; > 0: the ranks claim blocks of reads from the per-node work queue"""
     world = 2
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="3")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(tmp_path), mode], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(tmp_path), mode, str(queue_block)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
@@ -40,8 +41,15 @@ def test_two_rank_gloo_equals_single(tmp_path, mode, oracle):
     for rank in range(world):
         with open(tmp_path / f"rank{rank}.jsonl") as f:
             per_rank.append([tuple(json.loads(l)) for l in f])
-    assert sorted(i for i, _, _ in per_rank[0]) == dist.shard_indices(5, 0, 2)
-    assert sorted(i for i, _, _ in per_rank[1]) == dist.shard_indices(5, 1, 2)
+    if queue_block == 0:
+        assert sorted(i for i, _, _ in per_rank[0]) == dist.shard_indices(5, 0, 2)
+        assert sorted(i for i, _, _ in per_rank[1]) == dist.shard_indices(5, 1, 2)
+    else:   # whoever claimed what: every read exactly once, in blocks of queue_block consecutive indices per claim
+        owned = sorted(i for rr in per_rank for i, _, _ in rr)
+        assert owned == [0, 1, 2, 3, 4]
+        for rr in per_rank:
+            blocks = {i // queue_block for i, _, _ in rr}
+            assert all(b not in {j // queue_block for j, _, _ in other} for other in per_rank if other is not rr for b in blocks)
     merged = dist.merge_results(per_rank)
     # single process reference run of the same driver
     args = basecall.build_parser().parse_args(
@@ -81,3 +89,26 @@ def test_uid_rendezvous_and_filecomm_under_torchrun(tmp_path):
     assert r.returncode == 0, r.stdout.decode()[-2000:]
     uids = {open(tmp_path / f"uid{i}").read() for i in range(3)}
     assert len(uids) == 1
+
+
+def test_work_queue_many_claimers(tmp_path):
+    """WorkQueue under contention: 4 processes walk 0..N-1 at different speeds; every index is owned exactly once."""
+    script = tmp_path / "q.py"
+    script.write_text(
+        "import os, sys, time, json\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from radian_amd.dist import WorkQueue\n"
+        "me, n = int(sys.argv[1]), int(sys.argv[2])\n"
+        f"q = WorkQueue(os.path.join({str(tmp_path)!r}, 'queue'), 7)\n"
+        "mine = []\n"
+        "for i in range(n):\n"
+        "    if q.owns(i):\n"
+        "        mine.append(i)\n"
+        "        if me % 2: time.sleep(0.0003)\n"
+        "q.close()\n"
+        f"json.dump(mine, open(os.path.join({str(tmp_path)!r}, f'own{{me}}.json'), 'w'))\n")
+    n = 1000
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(n)]) for r in range(4)]
+    assert all(p.wait(timeout=120) == 0 for p in procs)
+    owned = [json.load(open(tmp_path / f"own{r}.json")) for r in range(4)]
+    assert sorted(i for o in owned for i in o) == list(range(n))   # (a late starter may find nothing left: fine)
