@@ -153,6 +153,26 @@ def test_driver_loop_with_test_double(mode, oracle, capsys):
     assert text.count("Basecalled read ") == 10
 
 
+def test_driver_loop_stitch_workers(oracle):
+    """chunk mode with the fragment stitch in spawned worker processes == stitch on the driver thread, same order"""
+    from radian_amd import basecall, weights
+    from _oracle_backend import OracleBackend
+    from _reads import golden_reads
+    be = OracleBackend()
+    be.load_weights(weights.synthetic_weights(seed=5, dilations=(1, 2)), (1, 2))
+    args = basecall.build_parser().parse_args(["a", "b", "--chunk-len", "128", "--step-size", "64", "--beam-width", "3",
+                                                "--decode-type", "chunk", "--gpu-batch-windows", "40"])
+    args._lm_loaded = False
+    base = basecall.run(args, be, reads=golden_reads(700, extra_bad=True), writer=None)
+    pool = basecall.make_stitch_pool(2)
+    assert pool is not None
+    try:
+        got = basecall.run(args, be, reads=golden_reads(700, extra_bad=True), writer=None, stitch_pool=pool)
+    finally:
+        pool.shutdown()
+    assert got == base and len(got) == 5
+
+
 @pytest.mark.skipif(not _have_hdf5(), reason="libhdf5 needed to write the fixtures")
 def test_pure_python_hdf5_reader(tmp_path, golden_dir, monkeypatch):
     """radian_amd.h5pure (no libhdf5) reads the same fast5 / Keras files: groups in name order, int16 chunked signals,
