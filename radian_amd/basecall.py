@@ -46,6 +46,9 @@ def build_parser():
     parser.add_argument("--gpus", default=1, type=int, help="shard reads over this many GPUs (one process each)")
     parser.add_argument("--device-contexts", default=2, type=int,
                         help="independent device contexts (streams) per GPU: batch i+1's forward overlaps batch i's beam search")
+    parser.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"],
+                        help="matrix products of the signal model: exact fp32 MFMA (default) or split-f16 products with fp32 "
+                             "accumulation (about 2x faster, same softmax error against a float64 reference; DESIGN.md 4.7)")
     parser.add_argument("--stitch-workers", default=min(4, max(1, (os.cpu_count() or 2) // 4)), type=int,
                         help="worker processes for the chunk-mode fragment stitch (0: stitch on the driver's host thread)")
     parser.add_argument("--queue-block", default=256, type=int,
@@ -267,6 +270,7 @@ def setup_backend(args, be):
     """Load weights and (when given) the RNA model into a Backend; mirrors basecall.py:47-62."""
     dil = load_dilations(args.sig_config)
     be.load_weights(load_sig_model(args.sig_model, dil), dil)
+    be.set_precision(getattr(args, "precision", "fp32"))
     args._lm_loaded = False
     if args.rna_model != "None":
         if os.path.exists(args.rna_model):

@@ -51,6 +51,7 @@ def worker(scratch, tag, argv):
         holder["lm"] = args._lm_loaded
 
     comm.bcast_artifacts(be, load)
+    be.set_precision(args.precision)   # context state, not part of the broadcast images
     # the flag `_lm_loaded` is host state: recompute it on the other ranks without touching the files' contents
     if rank != 0:
         args._lm_loaded = (args.rna_model != "None" and args.decode_type == "global")
