@@ -37,12 +37,16 @@ def run_multi_gpu(args, argv):
 def worker(scratch, tag, argv):
     from .backend import Backend
     from .basecall import build_parser, make_stitch_pool, run, setup_backend
-    from .dist import RcclComm, WorkQueue, env_rank_world, uid_path
+    from .dist import FileComm, RcclComm, WorkQueue, env_rank_world, uid_path
     args = build_parser().parse_args(argv)
     rank, local_rank, world = env_rank_world()
     pool = make_stitch_pool(args.stitch_workers) if args.decode_type == "chunk" else None   # before the GPU is touched
-    be = Backend(local_rank)
-    comm = RcclComm(be, rank, world, uid_path(tag))
+    be = Backend(int(os.environ.get("RD_CLI_DEVICE", local_rank)))   # override only for rehearsals on a 1-GPU box
+    try:
+        comm = RcclComm(be, rank, world, uid_path(tag))
+    except Exception as e:   # no usable RCCL communicator: every rank loads the artefacts itself, file-based barrier
+        print(f"[rank {rank}] RCCL start-up failed ({e}); loading the model per rank", file=sys.stderr)
+        comm = FileComm(rank, world, os.path.join(scratch, "fc"))
     # rank 0 parses / repacks the artefacts; everyone gets the device images by one broadcast
     holder = {}
 
