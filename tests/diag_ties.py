@@ -3,7 +3,7 @@
 starts at a time step where two of the oracle's beams around the pruning boundary have pr_total within a few ulp."""
 import os, sys
 import numpy as np
-R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, R + "/tests")
 from radian_amd import Backend
 from oracle import oracle as orc
