@@ -31,27 +31,155 @@ FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2
 F16_MFMA_PEAK_TFLOPS = 16 * 157.3      # dense f16 MFMA = 16x the fp32 MFMA rate (~2.5 PFLOP/s)
 
 
-def cpu_baseline(windows, valid, n_reads):
-    """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload, all host cores."""
+def effective_cores():
+    """CPU cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (a GPU box hands
+    a job a share of the host -- os.cpu_count() reports every hardware thread of the machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            if parse is not None:
+                quota, period = parse(open(path).read())
+            else:
+                quota, period = open(path).read().strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(int(quota) / int(period) + 0.5)))
+                break
+        except Exception:
+            continue
+    return n
+
+
+def cpu_baseline(windows, valid, n_reads, cores, n_reads_single):
+    """The oracle (CPU restatement, kind 'port') on bounded samples of the same workload: (ii) one OpenMP thread per
+    usable host core over disjoint windows and (i) a single thread, as the reference runs (basecall.py:70-72)."""
     from oracle import oracle as orc
     from radian_amd import weights
     orc.build()
     w = weights.synthetic_weights(seed=1234)
-    cores = orc.num_threads()
-    t0 = time.perf_counter()
-    probs = orc.tcn_forward(w, windows, nthreads=cores)
-    t1 = time.perf_counter()
-    n, T = windows.shape
-    off = np.arange(n, dtype=np.int64) * T
-    orc.beam_search_batch(probs.reshape(-1, 5), off, valid, BEAM, nthreads=cores)
-    t2 = time.perf_counter()
-    samples = n_reads * READ_LEN
-    return {
-        "value": samples / (t2 - t0), "unit": "samples/s", "cores": int(cores), "kind": "port",
+
+    def leg(nr, threads):
+        win, val = windows[: nr * 8], valid[: nr * 8]
+        t0 = time.perf_counter()
+        probs = orc.tcn_forward(w, win, nthreads=threads)
+        t1 = time.perf_counter()
+        n, T = win.shape
+        off = np.arange(n, dtype=np.int64) * T
+        orc.beam_search_batch(probs.reshape(-1, 5), off, val, BEAM, nthreads=threads)
+        t2 = time.perf_counter()
+        return nr * READ_LEN / (t2 - t0), t1 - t0, t2 - t1, n
+
+    v, fs, ds, n = leg(n_reads, cores)
+    out = {
+        "value": v, "unit": "samples/s", "cores": int(cores), "kind": "port",
         "sample": f"{n_reads} reads x {READ_LEN} samples ({n} windows) of the same workload; oracle forward "
-                  f"{t1 - t0:.2f}s + beam search {t2 - t1:.2f}s, OpenMP over {cores} threads",
-        "forward_s": t1 - t0, "decode_s": t2 - t1,
+                  f"{fs:.2f}s + beam search {ds:.2f}s, OpenMP over {cores} threads (= the cores this job may use; the host "
+                  f"reports {os.cpu_count()} hardware threads)",
+        "forward_s": fs, "decode_s": ds,
     }
+    if n_reads_single > 0:
+        v1, fs1, ds1, n1 = leg(n_reads_single, 1)
+        out["single_thread"] = {"value": v1, "unit": "samples/s", "cores": 1,
+                                "sample": f"{n_reads_single} reads ({n1} windows); forward {fs1:.2f}s + beam search {ds1:.2f}s on one thread "
+                                          "(the reference is single-threaded, basecall.py:70-72)"}
+    return out
+
+
+def check_against_oracle(be, batch, labels_fn):
+    """--check: batch 0 of this rank through the timed entry point, every window's labels against the oracle's beam search
+    of the GPU's probabilities, and the probabilities against the oracle forward (the oracle is the checker here, never
+    the thing measured; the same comparison runs in tests/test_gpu_baseline_configs.py)."""
+    from oracle import oracle as orc
+    from radian_amd import weights
+    orc.build()
+    win, valid = batch[2], batch[1]
+    probs = be.forward(win)
+    ref = orc.tcn_forward(weights.synthetic_weights(seed=1234), win, nthreads=effective_cores())
+    err = float(np.abs(probs - ref).max())
+    assert err <= 1e-4, f"forward differs from the oracle by {err}"
+    lab, ln = labels_fn()
+    off = np.arange(win.shape[0], dtype=np.int64) * CHUNK
+    exp = orc.beam_search_batch(probs.reshape(-1, 5), off, valid, BEAM, nthreads=effective_cores())
+    bad = [w for w in range(win.shape[0]) if ln[w] != len(exp[w]) or not np.array_equal(lab[w, : ln[w]], exp[w])]
+    assert not bad, f"{len(bad)} windows differ from the oracle, first {bad[:5]}"
+    print(f"[bench --check] {win.shape[0]} windows: labels identical to the oracle, max |d softmax| = {err:.2e}", file=sys.stderr)
+
+
+class _MemRead:
+    """a read as the fast5 reader hands it to the driver loop (read_id + get_raw_data)"""
+
+    def __init__(self, rid, sig):
+        self.read_id, self._sig = rid, sig
+
+    def get_raw_data(self):
+        return self._sig
+
+
+def e2e_raw_leg(device, pool, n_reads, precision):
+    """BASELINE configs[2] end to end through the product's driver loop (radian_amd.basecall.run = basecall.py:69-141):
+    host int16 reads -> H2D -> MAD normalisation on the device -> forward -> chunk beam search -> labels to the host ->
+    simple_assembly consensus strings (stitch workers), results in input order; everything but fast5 parsing / FASTA IO."""
+    import contextlib
+    from radian_amd import Backend, basecall, synthetic, weights
+    args = basecall.build_parser().parse_args(["-", "-", "--decode-type", "chunk", "--step-size", str(STEP), "--chunk-len", str(CHUNK),
+                                               "--beam-width", str(BEAM), "--rna-model", "None"])
+    args._lm_loaded = False
+    bes = [Backend(device) for _ in range(2)]
+    try:
+        for b in bes:
+            b.load_weights(weights.synthetic_weights(seed=1234))
+            b.set_precision(precision)
+
+        def go(n, seed):
+            raws = synthetic.synthetic_reads(n, READ_LEN, seed=seed)
+            reads = [_MemRead(f"{i:08d}", raws[i]) for i in range(n)]
+            with open(os.devnull, "w") as dn, contextlib.redirect_stdout(dn):
+                t0 = time.perf_counter()
+                res = basecall.run(args, bes, reads=iter(reads), writer=None, stitch_pool=pool)
+                dt = time.perf_counter() - t0
+            assert len(res) == n and all(len(r[2]) > 0 for r in res)
+            return dt
+        go(1024, 70001)                      # warm-up: allocations, plans, worker start
+        dt = go(n_reads, 70002)
+    finally:
+        for b in bes:
+            b.close()
+    return {"value": n_reads * READ_LEN / dt, "unit": "samples/s", "reads": n_reads, "seconds": dt,
+            "path": "host int16 -> H2D -> on-device mad_normalise -> streamed forward -> chunk beam search W=10 -> labels D2H -> "
+                    f"simple_assembly strings ({pool._max_workers if pool is not None else 0} stitch worker processes), 2 device contexts, "
+                    "batches of 512 reads; excludes fast5 parsing and FASTA writing"}
+
+
+def global_lm_leg(be, batches, read_off, reads_per_batch, steps):
+    """BASELINE configs[3] geometry on one GPU: global decode (one beam search per read over the assembled float64
+    matrix), step 512, W = 10, 12-mer LM = 4^11 x 4 float64 table (Dirichlet(0.3), seed 0), thresholds 0.5 / 0.5;
+    inputs resident in HBM, labels on the host at stop (unpipelined calls)."""
+    k = 11
+    table = np.random.default_rng(0).dirichlet([0.3] * 4, size=4 ** k)
+    be.load_lm(table, k)
+    del table
+    try:
+        labels = np.zeros(reads_per_batch * READ_LEN + 1, dtype=np.uint8)
+        lens = np.zeros(reads_per_batch, dtype=np.int32)
+        label_off = np.ascontiguousarray(read_off[:-1])
+
+        def call(i):
+            be.basecall_reads_global_resident(batches[i % len(batches)][3], read_off, reads_per_batch, CHUNK, STEP, BEAM, True, 0.5, 0.5,
+                                              labels, label_off, lens)
+        for i in range(2):
+            call(i)
+        be.sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            call(i)
+        be.sync()
+        dt = time.perf_counter() - t0
+        assert lens.min() > 0
+    finally:
+        be.load_lm(None, 0)
+    return {"value": steps * reads_per_batch * READ_LEN / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "config": "BASELINE configs[3] geometry, one GPU: 64 reads x 4096 per step, --decode-type global, step 512, beam 10, "
+                      "k=11 LM table (4^11 x 4 f64), sig/rna thresholds 0.5/0.5; streamed forward + assembly (f64) + LM beam search"}
 
 
 def main():
@@ -61,13 +189,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--windowed", action="store_true", help="evaluate all 512 windows per step like the reference (default: streamed forward)")
-    ap.add_argument("--precision", choices=["fp32", "f16x3"], default="fp32",
-                    help="matrix-product arithmetic of the forward: exact fp32 MFMA (default) or split-f16 products (fp32-equivalent accuracy)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary timed run in the other precision mode")
-    ap.add_argument("--check", action="store_true", help="untimed cross-check: streamed labels == windowed labels on one batch")
+    ap.add_argument("--precision", choices=["fp32", "f16x3", "bf16x3"], default="fp32",
+                    help="matrix-product arithmetic of the forward: exact fp32 MFMA (default), split-f16 products, or the "
+                         "three-term bf16 split (every fp32 operand reconstructed exactly, six bf16 MFMAs per product)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (other precision modes, global+LM, raw end to end)")
+    ap.add_argument("--check", action="store_true",
+                    help="untimed cross-checks on batch 0: streamed labels == windowed labels == the oracle's; probabilities within 1e-4 of the oracle's")
     ap.add_argument("--decode-group", type=int, default=8, help="batches per beam-search launch in the two-stream pipeline")
     ap.add_argument("--lanes", type=int, default=2, help="forward streams the pipelined batches rotate over (1..4)")
-    ap.add_argument("--cpu-reads", type=int, default=0, help="reads in the CPU-baseline sample (0: sized to the host core count)")
+    ap.add_argument("--cpu-reads", type=int, default=0, help="reads in the CPU-baseline sample (0: sized to the usable core count)")
+    ap.add_argument("--e2e-reads", type=int, default=8192, help="reads of the raw end-to-end secondary leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -79,10 +210,16 @@ def main():
         args.gpus = world
 
     from radian_amd import Backend, weights, synthetic
-    synthetic.mad_normalise = __import__('radian_amd.preprocess', fromlist=['mad_normalise']).mad_normalise
     from radian_amd.backend import RD_TIMER_CONV, RD_TIMER_DECODE, RD_TIMER_HEAD
 
-    be = Backend(int(os.environ.get("RD_BENCH_DEVICE", local_rank)))   # override only for rehearsals on a 1-GPU box
+    secondaries = world == 1 and not args.no_secondary and not args.windowed and args.precision == "fp32"
+    stitch_pool = None
+    if secondaries and args.e2e_reads > 0:
+        from radian_amd import basecall as _bc
+        stitch_pool = _bc.make_stitch_pool(min(4, max(1, effective_cores() // 4)))   # before this process touches the GPU
+
+    device = int(os.environ.get("RD_BENCH_DEVICE", local_rank))   # override only for rehearsals on a 1-GPU box
+    be = Backend(device)
     comm_kind = "single"
     comm = None
     if world > 1:
@@ -93,15 +230,11 @@ def main():
         os.dup2(2, 1)
         try:
             # the one collective of the job: rank 0 loads + repacks the weights, RCCL broadcasts the 8.8 MB device image
-            # over xGMI; the 128-byte RCCL id goes through a file keyed by the launcher's pid (no PyTorch in this process)
-            comm = dist.RcclComm(be, rank, world, dist.uid_path())
+            # over xGMI; the 128-byte RCCL id goes through a file keyed by the launcher's pid (no PyTorch in this process).
+            # All ranks agree on the transport before anyone uses it (dist.connect: RCCL on every rank, or the file
+            # transport on every rank -- never a mix, which would leave one side inside ncclBroadcast forever).
+            comm, comm_kind = dist.connect(be, rank, world, dist.uid_path())
             comm.bcast_artifacts(be, lambda b: b.load_weights(weights.synthetic_weights(seed=1234)))
-            comm_kind = "rccl"
-        except Exception as e:  # keep the scaling run alive: file-based barrier, every rank loads its own weights
-            print(f"[bench rank {rank}] RCCL start-up failed ({e}); falling back to file-based barrier", file=sys.stderr)
-            comm = dist.FileComm(rank, world, dist.uid_path() + ".fc")
-            be.load_weights(weights.synthetic_weights(seed=1234))
-            comm_kind = "file-fallback"
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd1, 1)
@@ -173,33 +306,60 @@ def main():
         return el
 
     if args.check:
-        # untimed: the reads-level (streamed) path must reproduce the window-level labels exactly
+        # untimed: the reads-level (streamed) path must reproduce the window-level labels exactly ...
         la, na = np.zeros_like(labels), np.zeros_like(lens)
         be.basecall_chunk_resident(batches[0][0], BATCH_WINDOWS, CHUNK, batches[0][1], BEAM, la, na)
         step(0)
         assert np.array_equal(na, lens) and all(np.array_equal(la[i, :na[i]], labels[i, :na[i]]) for i in range(BATCH_WINDOWS)), \
             "streamed != windowed labels"
+        # ... and the timed entry point (pipelined submit) must reproduce the oracle's labels on the GPU's probabilities
+        if args.precision == "fp32":
+            def piped():
+                (submit_windowed if args.windowed else submit)(0)
+                be.pipe_flush()
+                return out[0]
+            check_against_oracle(be, batches[0], piped)
     elapsed = timed(submit_windowed if args.windowed else submit)
     for lab, ln in out[: max(1, min(len(out), args.steps))]:
         assert ln.min() >= 0 and ln.max() <= CHUNK and ln.sum() > 0
 
     samples_per_step = reads_per_batch * READ_LEN  # input samples basecalled per step per GPU
     value = world * args.steps * samples_per_step / elapsed
-    # secondary, reported beside the headline: the same job with split-f16 ("f16x3") matrix products -- every fp32 operand
-    # as an f16 hi+lo pair, three f16 MFMAs per product, fp32 accumulate; same softmax error vs a float64-accumulated
-    # reference as the fp32-MFMA mode (tests/test_gpu_forward.py::test_forward_split_f16x3_accuracy)
-    secondary = None
+    # secondaries, reported beside the headline (one GPU, fp32 headline only): the same job in the other matrix-product
+    # modes; configs[3]'s global + LM geometry; the raw-reads end-to-end driver loop
+    sec = {}
     if args.precision == "fp32" and not args.no_secondary and not args.windowed:
+        for mode, key, desc, acc in (
+                ("bf16x3", "secondary_bf16x3",
+                 "three-term bf16 split: hi+mid+lo reconstructs every finite fp32 operand exactly; six v_mfma_f32_32x32x16_bf16 per "
+                 "product (terms below 2^-24 relative dropped), fp32 accumulate",
+                 "tests/test_gpu_forward.py::test_forward_bf16x3_*"),
+                ("f16x3", "secondary_f16x3",
+                 "f16x3 split products (3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate; 22-bit operands)",
+                 "max |softmax - float64-accumulated reference|: 6.6e-6 / 6.5e-5 (peaky head) vs 1.1e-5 / 7.1e-5 for the fp32-MFMA mode "
+                 "(tests/test_gpu_forward.py)")):
+            try:
+                be.set_precision(mode)
+            except Exception:
+                continue
+            try:
+                el2 = timed(submit)
+            finally:
+                be.set_precision("fp32")
+            sec[key] = {"precision": desc, "value": world * args.steps * samples_per_step / el2, "unit": "samples/s",
+                        "ms_per_step": el2 / args.steps * 1e3, "accuracy": acc}
+    if secondaries:
         try:
-            be.set_precision("f16x3")
-            el2 = timed(submit)
-        finally:
-            be.set_precision("fp32")
-        secondary = {"precision": "f16x3 split products (3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate)",
-                     "value": world * args.steps * samples_per_step / el2, "unit": "samples/s",
-                     "ms_per_step": el2 / args.steps * 1e3,
-                     "accuracy": "max |softmax - float64-accumulated reference|: 6.6e-6 / 6.5e-5 (peaky head) vs 1.1e-5 / 7.1e-5 for "
-                                 "the fp32-MFMA mode (tests/test_gpu_forward.py)"}
+            sec["secondary_global_lm"] = global_lm_leg(be, batches, read_off, reads_per_batch, args.steps)
+        except Exception as e:
+            print(f"[bench] secondary_global_lm failed: {e}", file=sys.stderr)
+        if args.e2e_reads > 0:
+            try:
+                sec["secondary_e2e_raw"] = e2e_raw_leg(device, stitch_pool, args.e2e_reads, args.precision)
+            except Exception as e:
+                print(f"[bench] secondary_e2e_raw failed: {e}", file=sys.stderr)
+    if stitch_pool is not None:
+        stitch_pool.shutdown()
     halo = 252
     # probability rows produced per step: every window row (windowed) or every time step once + 7 window heads (streamed)
     rows_streamed = BATCH_WINDOWS * CHUNK if args.windowed else reads_per_batch * (READ_LEN + 7 * halo)
@@ -226,33 +386,43 @@ def main():
         flop_per_launch = tc["flops"] / max(1, tc["launches"])
         avg_s = tc["total_ms"] / max(1, tc["launches"]) * 1e-3
         achieved = flop_per_launch / avg_s / 1e12
-        peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else F16_MFMA_PEAK_TFLOPS / 3.0
+        peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "f16x3": F16_MFMA_PEAK_TFLOPS / 3.0, "bf16x3": F16_MFMA_PEAK_TFLOPS / 6.0}[args.precision]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        tsrc = None
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("conv_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("conv_hbm_bytes_per_launch")
+                tsrc = f"profiles/traffic.json ({tj.get('source', 'offline rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE')}); not measured in this run"
             except Exception:
                 traffic = None
+        conv_flops_per_step = tc["flops"] / n_prof   # the same batches and geometry as every step of the timed region
         roof = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "traffic": traffic,
-            "kernel": ("tcn_gemm_kernel<4,3,*> (dilated causal conv 256->256, k=3, v_mfma_f32_32x32x2_f32)" if args.precision == "fp32" else
-                       "tcn_gemm_split_kernel<4,3,*> (same conv, 3 x v_mfma_f32_32x32x16_f16 per fp32 product; peak = 2516/3 TFLOP/s)"),
+            "frac": achieved / peak, "traffic": traffic, "traffic_source": tsrc,
+            "kernel": {"fp32": "tcn_gemm_kernel<4,3,*> (dilated causal conv 256->256, k=3, v_mfma_f32_32x32x2_f32)",
+                       "f16x3": "tcn_gemm_split_kernel<4,3,*> (same conv, 3 x v_mfma_f32_32x32x16_f16 per fp32 product; peak = 2516/3 TFLOP/s)",
+                       "bf16x3": "tcn_gemm_bf3_kernel<4,3,*> (same conv, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product; peak = 2516/6 TFLOP/s)"}[args.precision],
             "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_s * 1e3, "launches_timed": tc["launches"],
+            # the fraction that refers to the TIMED REGION: all conv FLOPs the region issued / its wall time / the peak
+            # (includes the head, the C_in=1 layer, beam search tails and launch gaps as lost time)
+            "pipeline_frac": conv_flops_per_step * args.steps / elapsed / 1e12 / peak,
+            "pipeline_conv_tflops": conv_flops_per_step * args.steps / elapsed / 1e12,
             "conv_ms_per_step": tc["total_ms"] / n_prof, "decode_ms_per_step": td["total_ms"] / n_prof,
             "head_ms_per_step": th["total_ms"] / n_prof,
-            "timing": "HIP events around every launch of a forward + beam search run on ONE stream after the timed region "
-                      "(launches back to back: the kernel's own duration; = profiles/*_kernel_stats.csv, taken with --lanes 1). "
+            "timing": "frac/achieved: HIP events around every launch of a forward + beam search run on ONE stream after the timed "
+                      "region (launches back to back: the kernel's own duration; = profiles/*_kernel_stats.csv, taken with --lanes 1). "
                       "In the timed region the launches of consecutive batches overlap on two lanes, so a launch's bracketed "
-                      "duration there also counts the time it shares the chip (profiles/*_kernel_stats_default_2lanes.csv)",
+                      "duration there also counts the time it shares the chip (profiles/*_kernel_stats_default_2lanes.csv); "
+                      "pipeline_frac is the timed region's own figure",
             "decode_timesteps_per_s": float(sum(b[1].sum() for b in batches[:n_prof])) / max(1e-9, td["total_ms"] * 1e-3),
         }
         if world == 1 and not args.no_cpu_baseline:
-            ncores = os.cpu_count() or 1
-            nr = args.cpu_reads or max(2, min(reads_per_batch, ncores // 4))   # ~10-30 s of CPU work, all cores busy
+            cores = effective_cores()
+            nr = args.cpu_reads or max(2, min(reads_per_batch, 4 * cores))   # ~10-20 s of CPU work, all usable cores busy
             try:
-                cpu = cpu_baseline(batches[0][2][: nr * 8], batches[0][1][: nr * 8], nr)
+                cpu = cpu_baseline(batches[0][2], batches[0][1], nr, cores, max(1, min(8, nr)))
             except Exception as e:   # the oracle is test infrastructure: its absence must not cost the GPU line
                 print(f"[bench] cpu_baseline unavailable: {e}", file=sys.stderr)
                 cpu = None
@@ -262,12 +432,17 @@ def main():
             "metric": "signal samples/s basecalled (chunk=1024, beam=10)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16x3 split (f32 accumulate)", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": {"fp32": "f32", "f16x3": "f16x3 split (f32 accumulate)", "bf16x3": "bf16x3 split of f32 operands (f32 accumulate)"}[args.precision],
+            "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[2]: synthetic Gaussian int16 reads x 4096 samples (round(N(500,80))), "
                             "MAD-normalised, chunk=1024 step=512 -> 8 windows/read; step = 512 windows (64 reads): "
                             "TCN forward fp32 + chunk-mode CTC beam search W=10 over every window (LM unused in chunk "
                             "mode, reference basecall.py:110-121) + labels to host; random He-normal weights seed 1234",
+                "timed_region": "starts with MAD-normalised float32 reads resident in HBM; ends with every window's labels on the host. "
+                                "Excludes H2D of the raw signal, mad_normalise and the host string stitch -- those are inside "
+                                "secondary_e2e_raw",
                 "forward": ("windowed: all 512 windows x 1024 rows through the model, as the reference does" if args.windowed else
                             "streamed: each read's time steps are evaluated once (4096 + 7*252 rows per read instead of "
                             "8*1024); probabilities and labels bit-identical to the windowed evaluation "
@@ -279,8 +454,7 @@ def main():
             },
             "roofline": roof,
         }
-        if secondary is not None:
-            out["secondary_f16x3"] = secondary
+        out.update(sec)
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = value / cpu["value"]

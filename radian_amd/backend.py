@@ -297,6 +297,13 @@ class Backend:
         self._check(self._L.rd_basecall_reads_chunk_resident(self._h, d_signal, _p(read_off), int(n_reads), int(chunk_len),
                                                              int(step), int(beam_width), _p(labels), _p(lens)))
 
+    def basecall_reads_global_resident(self, d_signal, read_off, n_reads, chunk_len, step, beam_width, use_lm, s_threshold,
+                                       r_threshold, labels, label_off, lens):
+        """Global mode over normalised reads resident in HBM (rd_basecall_reads_global_resident)."""
+        self._check(self._L.rd_basecall_reads_global_resident(self._h, d_signal, _p(read_off), int(n_reads), int(chunk_len),
+                                                              int(step), int(beam_width), 1 if use_lm else 0, float(s_threshold),
+                                                              float(r_threshold), _p(labels), _p(label_off), _p(lens)))
+
     def pipe_config(self, group_batches):
         self._check(self._L.rd_pipe_config(self._h, int(group_batches)))
 
@@ -327,6 +334,9 @@ class Backend:
     def rccl_init(self, rank, nranks, uid):
         buf = (ctypes.c_uint8 * 128).from_buffer_copy(uid)
         self._check(self._L.rd_rccl_init(self._h, rank, nranks, ctypes.cast(buf, ctypes.c_void_p)))
+
+    def rccl_finalize(self):
+        self._check(self._L.rd_rccl_finalize(self._h))
 
     def rccl_bcast_model(self, root=0):
         self._check(self._L.rd_rccl_bcast_model(self._h, root))

@@ -163,19 +163,50 @@ def host_finish(labels, args):
     return consensus_sequence([labels_to_str(f) for f in labels])
 
 
-def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue=None):
-    """The driver loop (basecall.py:69-141) over `reads` (default: every read under args.fast5_dir).
-    shard=(rank, world): this process handles reads whose index % world == rank -- or, with queue (a dist.WorkQueue
-    shared by the ranks of the node), the blocks of consecutive reads it claims from that queue -- and returns
-    [(read_index, read_id, sequence)] instead of writing when writer is None.
+def _owned_reads(args, reads, shard, queue, sources):
+    """(key, read) pairs this process basecalls, in input order.  key orders the merged output: the read's index in the
+    enumeration, or (file index, read index in the file) with file-level sources."""
+    rank, world = shard
+    if sources is not None:
+        if queue is not None:          # dist.FileReadQueue: claim blocks of reads file by file; open only claimed files
+            last = None
+            for fi, lo, hi in queue.claims(sources):
+                if last is not None and last != fi:
+                    sources[last].close()
+                last = fi
+                for ri, read in sources[fi].reads(lo, hi):
+                    yield (fi, ri), read
+            if last is not None:
+                sources[last].close()
+        else:                          # static: whole files round-robin over the ranks
+            for fi, src in enumerate(sources):
+                if fi % world != rank:
+                    continue
+                for ri, read in src.reads(0, src.n_reads()):
+                    yield (fi, ri), read
+                src.close()
+        return
+    if reads is None:
+        reads = fast5.iter_directory(args.fast5_dir)
+    for idx, read in enumerate(reads):
+        if (not queue.owns(idx)) if queue is not None else (idx % world != rank):
+            continue
+        yield idx, read
+
+
+def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue=None, sources=None, on_result=None):
+    """The driver loop (basecall.py:69-141) over `reads` (default: every read under args.fast5_dir), or over file-level
+    `sources` (fast5.Fast5Source per file: the multi-GPU launcher's form).
+    shard=(rank, world): this process handles reads whose index % world == rank -- or, with a queue shared by the ranks
+    of the node (dist.WorkQueue over read indices / dist.FileReadQueue over files then reads), the blocks it claims --
+    and returns [(key, read_id, sequence)] instead of writing when writer is None; on_result(key, read_id, sequence), if
+    given, receives each result as it is finished (in order) instead of the list growing.
     `be` is one Backend or a list of Backends on the same GPU (independent rd_ctx / HIP streams): batches go to them
     round robin on one thread each, so the MFMA-bound forward of one batch overlaps the latency-bound beam search of
     the previous one.  Reading/batching (HDF5 through ctypes), the device calls and the host work on the results
     (string stitch, FASTA write) run concurrently; output order is the input order."""
     from concurrent.futures import ThreadPoolExecutor
     backends = list(be) if isinstance(be, (list, tuple)) else [be]
-    if reads is None:
-        reads = fast5.iter_directory(args.fast5_dir)
     if args.step_size <= 0:
         raise ValueError("Step size must be > 0")            # preprocess.py:5-8
     if args.step_size > args.chunk_len:
@@ -204,7 +235,10 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
             seq = next(seqs) if seqs is not None else host_finish(lab, args)
             if writer is not None:
                 writer.write(rid, seq)
-            results.append((idx, rid, seq))
+            if on_result is not None:
+                on_result(idx, rid, seq)
+            else:
+                results.append((idx, rid, seq))
             print(f"Basecalled read {rid} in {dur:.2f} sec.")
 
     def on_device(backend, b):
@@ -238,9 +272,7 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
         finishing.clear()
 
     try:
-        for idx, read in enumerate(reads):
-            if (not queue.owns(idx)) if queue is not None else (idx % world != rank):
-                continue
+        for idx, read in _owned_reads(args, reads, shard, queue, sources):
             raw = np.asarray(read.get_raw_data())
             n = raw.shape[0]
             if n == 0:
@@ -266,12 +298,12 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
     return results
 
 
-def setup_backend(args, be):
-    """Load weights and (when given) the RNA model into a Backend; mirrors basecall.py:47-62."""
+def load_artifacts(args):
+    """Host-only half of basecall.py:47-62: parse / validate the signal model and (global mode) the RNA model.
+    Returns {"dilations", "weights", "lm_table", "lm_k"}; raises what the reference would (KeyError for a context
+    length that does not match the RNA model, FileNotFoundError for a missing file) before any GPU is touched."""
     dil = load_dilations(args.sig_config)
-    be.load_weights(load_sig_model(args.sig_model, dil), dil)
-    be.set_precision(getattr(args, "precision", "fp32"))
-    args._lm_loaded = False
+    art = {"dilations": dil, "weights": load_sig_model(args.sig_model, dil), "lm_table": None, "lm_k": 0}
     if args.rna_model != "None":
         if os.path.exists(args.rna_model):
             table, k = lm_mod.load_json(args.rna_model)
@@ -279,10 +311,25 @@ def setup_backend(args, be):
                 if k != args.context_len:
                     raise KeyError(f"--context-len {args.context_len} does not match the RNA model's context length {k} "
                                    "(the reference fails with KeyError at decode.py:83)")
-                be.load_lm(table, k)
-                args._lm_loaded = True
+                art["lm_table"], art["lm_k"] = table, k
         elif args.decode_type == "global":
             raise FileNotFoundError(args.rna_model)
+    return art
+
+
+def apply_artifacts(args, be, art):
+    """Device half: hand the parsed artefacts to a Backend."""
+    be.load_weights(art["weights"], art["dilations"])
+    be.set_precision(getattr(args, "precision", "fp32"))
+    args._lm_loaded = False
+    if art["lm_table"] is not None:
+        be.load_lm(art["lm_table"], art["lm_k"])
+        args._lm_loaded = True
+
+
+def setup_backend(args, be):
+    """Load weights and (when given) the RNA model into a Backend; mirrors basecall.py:47-62."""
+    apply_artifacts(args, be, load_artifacts(args))
 
 
 def main(argv=None):
@@ -292,9 +339,11 @@ def main(argv=None):
         return run_multi_gpu(args, argv if argv is not None else sys.argv[1:])
     pool = make_stitch_pool(args.stitch_workers) if args.decode_type == "chunk" else None   # before the GPU is touched
     from .backend import Backend
+    art = load_artifacts(args)
     bes = [Backend(args.device) for _ in range(max(1, args.device_contexts))]
     for b in bes:
-        setup_backend(args, b)
+        apply_artifacts(args, b, art)
+    del art
     writer = FastaWriter(args.fasta_dir)
     try:
         run(args, bes, writer=writer, stitch_pool=pool)

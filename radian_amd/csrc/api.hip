@@ -29,18 +29,25 @@ extern "C" int rd_version(void) { return 1; }
 int DevBuf::reserve(size_t bytes)
 {
     if (bytes <= cap) return 0;
+    // allocate, then swap: a failed growth leaves the old (smaller, still valid) buffer in place.  Only if the new block
+    // does not fit BESIDE the old one is the old one given up first (workspaces carry no state between calls).
     size_t want = align_up(bytes + bytes / 8, 1 << 20);
     void* np = nullptr;
-    if (p) {
+    hipError_t e = hipMalloc(&np, want);
+    if (e != hipSuccess && p) {
+        (void)hipGetLastError();
         (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        e = hipMalloc(&np, want);
+        if (e != hipSuccess) e = hipMalloc(&np, want = align_up(bytes, 1 << 20));
     }
-    hipError_t e = hipMalloc(&np, want);
     if (e != hipSuccess) {
+        (void)hipGetLastError();
         rd_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
         return -1;
     }
+    if (p) (void)hipFree(p);
     p = np;
     cap = want;
     return 0;
@@ -462,19 +469,33 @@ int prepare_seq_meta(rd_ctx* ctx, const int64_t* seq_off, const int64_t* seq_off
     sm.d_label_len = (int32_t*)p;
     sm.total_nodes = nodes;
     sm.total_labels = labs;
-    RD_HIP(hipMemcpyAsync(sm.d_seq_off, seq_off, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    RD_HIP(hipMemcpyAsync(sm.d_seq_len, seq_len, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    RD_HIP(hipMemcpyAsync(sm.d_node_off, node_off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
-    RD_HIP(hipMemcpyAsync(sm.d_label_off, lab_off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (seq_off2) {
-        RD_HIP(hipMemcpyAsync(sm.d_seq_off2, seq_off2, n * 8, hipMemcpyHostToDevice, ctx->stream));
-        RD_HIP(hipMemcpyAsync(sm.d_split, split, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    } else {
+    // The metadata goes through the context's pinned staging block in ONE copy that needs no host-side wait: the block
+    // is only rewritten by the next call on this context, and every caller ends with a stream synchronisation
+    // (decode_and_fetch) before that can happen.
+    const size_t stage_bytes = 4 * a8 + 2 * a4;   // seq_off | seq_off2 | node_off | label_off | seq_len | split
+    if (ctx->h_stage_cap < stage_bytes) {
+        RD_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+        ctx->h_stage = nullptr;
+        ctx->h_stage_cap = 0;
+        const size_t want = align_up(stage_bytes + stage_bytes / 4, 1 << 16);
+        RD_HIP(hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault));
+        ctx->h_stage_cap = want;
+    }
+    char* hs = (char*)ctx->h_stage;
+    memcpy(hs, seq_off, n * 8);
+    if (seq_off2) memcpy(hs + a8, seq_off2, n * 8);
+    memcpy(hs + 2 * a8, node_off.data(), n * 8);
+    memcpy(hs + 3 * a8, lab_off.data(), n * 8);
+    memcpy(hs + 4 * a8, seq_len, n * 4);
+    if (split) memcpy(hs + 4 * a8 + a4, split, n * 4);
+    // device layout: 5 x a8 (seq_off, seq_off2, node_off, label_off, score) then 3 x a4 (seq_len, split, label_len)
+    RD_HIP(hipMemcpyAsync(sm.d_seq_off, hs, 4 * a8, hipMemcpyHostToDevice, ctx->stream));
+    RD_HIP(hipMemcpyAsync(sm.d_seq_len, hs + 4 * a8, 2 * a4, hipMemcpyHostToDevice, ctx->stream));
+    if (!seq_off2) {
         sm.d_seq_off2 = nullptr;
         sm.d_split = nullptr;
     }
-    // the host vectors must outlive the async copies
-    RD_HIP(hipStreamSynchronize(ctx->stream));
     return RD_OK;
 }
 
@@ -838,6 +859,7 @@ int plan_reads_chunk(const Model& m, const int64_t* read_off, int n_reads, int c
 
 struct PlanCache {
     int chunk = -1, step = -1, halo = -1, mode = -1, nblocks = -1;
+    int dil[RD_MAX_BLOCKS] = {0};   // per-layer head lengths depend on every block's dilation, not only on their sum
     std::vector<int64_t> lens;
     ReadsPlan plan;
     bool streamed = false;
@@ -1193,8 +1215,11 @@ int get_plan(rd_ctx* ctx, const int64_t* read_off, int n_reads, int chunk, int s
     for (int r = 0; r < n_reads; r++) lens[r] = read_off[r + 1] - read_off[r];
     bool hit = pc->chunk == chunk && pc->step == step && pc->halo == halo && pc->mode == mode && pc->lens == lens &&
                read_off[0] == 0 && pc->d_tiles.p && pc->nblocks == ctx->model.nblocks;
+    for (int b = 0; hit && b < ctx->model.nblocks; b++) hit = pc->dil[b] == ctx->model.dil[b];
     if (!hit) {
         RD_REQUIRE(read_off[0] == 0, "read_off[0] must be 0");
+        pc->chunk = -1;   // the cached key is void from here on: a failure below must not leave a half-built plan reachable
+        pc->lens.clear();
         pc->plan = ReadsPlan();
         int rc = mode == 0 ? plan_reads_chunk(ctx->model, read_off, n_reads, chunk, step, halo, pc->plan)
                            : plan_reads_global(ctx->model, read_off, n_reads, chunk, step, halo, pc->plan, &pc->streamed);
@@ -1247,6 +1272,7 @@ int get_plan(rd_ctx* ctx, const int64_t* read_off, int n_reads, int chunk, int s
         pc->mode = mode;
         pc->lens = lens;
         pc->nblocks = ctx->model.nblocks;
+        for (int b = 0; b < RD_MAX_BLOCKS; b++) pc->dil[b] = b < ctx->model.nblocks ? ctx->model.dil[b] : 0;
     }
     *out = &pc->plan;
     *lists = &pc->lists;

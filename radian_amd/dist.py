@@ -1,11 +1,16 @@
-"""Process-group plumbing for the multi-GPU path: one process per GPU, reads sharded by index, ONE start-up
-broadcast of the artefacts, no data-path collective.
+"""Process-group plumbing for the multi-GPU path: one process per GPU, reads sharded over the ranks, ONE start-up
+broadcast of the artefacts, no data-path collective (SURVEY.md section 8e).
 
-Two interchangeable transports behind the same four calls (barrier, allreduce_max, bcast_artifacts, close):
+Transports behind the same four calls (barrier, allreduce_max, bcast_artifacts, close):
   * RcclComm  -- RCCL over xGMI through libradian_hip.so's rd_rccl_* (the GPU path; no PyTorch in the process);
-  * GlooComm  -- torch.distributed `gloo` on CPU tensors (used by the CPU tests to exercise the same
-                 sharding / merge logic with world_size 2, and usable on hosts without RCCL).
+  * FileComm  -- files in a directory shared by the ranks of one node (no collective library): the agreed fallback when
+                 RCCL cannot be used by EVERY rank.
+`connect()` makes the choice collectively: every rank reports whether its RCCL start-up worked and RCCL is used only if
+all of them did -- a rank never sits in ncclBroadcast while another waits at a file barrier.
+(The torch.distributed `gloo` transport used by the CPU tests lives in tests/_gloo_comm.py, not in the product.)
 """
+import heapq
+import json
 import os
 import time
 
@@ -24,14 +29,41 @@ def _proc_start_time(pid):
         return "0"
 
 
-def uid_path(tag=None):
-    """Rendezvous file for the RCCL unique id.  All ranks of one launch are children of the same launcher process
-    (torch.distributed.run's agent, or radian_amd.launch), so its pid + start time names the launch uniquely and a
-    file left behind by an earlier, crashed launch can never be picked up."""
+def uid_path(tag=None, directory=None):
+    """Rendezvous path for one launch.  With `directory` (the launcher's private mkdtemp scratch) the name is unique by
+    construction.  Otherwise (bench.py under torch.distributed.run): all ranks are children of the same launcher
+    process, so its pid + start time names the launch and a file left by an earlier, crashed launch can never match."""
+    if directory is not None:
+        return os.path.join(directory, "rccl_uid")
     if tag is None:
         ppid = os.getppid()
         tag = f"{os.environ.get('MASTER_PORT', '29500')}_{ppid}_{_proc_start_time(ppid)}"
     return f"/tmp/radian_rccl_uid_{tag}"
+
+
+class Rendezvous:
+    """All-gather of one short string per rank through files in a directory (atomic rename, polling)."""
+
+    def __init__(self, directory, rank, world, timeout=120.0):
+        self.dir, self.rank, self.world, self.timeout = directory, rank, world, timeout
+        os.makedirs(directory, exist_ok=True)
+
+    def gather(self, phase, value):
+        mine = os.path.join(self.dir, f"{phase}.{self.rank}")
+        with open(mine + ".tmp", "w") as f:
+            f.write(value)
+        os.replace(mine + ".tmp", mine)
+        out = []
+        t0 = time.time()
+        for r in range(self.world):
+            p = os.path.join(self.dir, f"{phase}.{r}")
+            while not os.path.exists(p):
+                if time.time() - t0 > self.timeout:
+                    raise RuntimeError(f"rendezvous '{phase}': timed out after {self.timeout:.0f}s waiting for rank {r}")
+                time.sleep(0.002)
+            with open(p) as f:
+                out.append(f.read())
+        return out
 
 
 def exchange_uid(make_uid, rank, path, timeout=120.0):
@@ -69,12 +101,10 @@ class SingleComm:
 
 
 class RcclComm:
-    """RCCL communicator owned by the Backend's rd_ctx."""
+    """RCCL communicator owned by the Backend's rd_ctx (created by connect(): every rank has one, or none has)."""
 
-    def __init__(self, be, rank, world, uid_file):
-        self.be, self.rank, self.world, self._uid_file = be, rank, world, uid_file
-        uid = exchange_uid(be.rccl_unique_id, rank, uid_file)
-        be.rccl_init(rank, world, uid)
+    def __init__(self, be, rank, world):
+        self.be, self.rank, self.world = be, rank, world
 
     def barrier(self):
         self.be.rccl_barrier()
@@ -89,16 +119,14 @@ class RcclComm:
         be.rccl_bcast_model(0)
 
     def close(self):
-        if self.rank == 0 and os.path.exists(self._uid_file):
-            os.remove(self._uid_file)
+        pass
 
 
 class FileComm:
-    """Last-resort transport through a shared directory on one node (no collective library): used by bench.py only if
-    the RCCL communicator cannot be created, so that a scaling run still reports.  Every rank loads the artefacts itself."""
+    """Transport through a shared directory on one node (no collective library).  Every rank loads the artefacts itself."""
 
-    def __init__(self, rank, world, base):
-        self.rank, self.world, self._base, self._seq = rank, world, base, 0
+    def __init__(self, rank, world, base, timeout=600.0):
+        self.rank, self.world, self._base, self._seq, self._timeout = rank, world, base, 0, timeout
 
     def _exchange(self, value):
         self._seq += 1
@@ -111,7 +139,7 @@ class FileComm:
         for r in range(self.world):
             p = f"{self._base}.x{self._seq}.{r}"
             while not os.path.exists(p):
-                if time.time() - t0 > 600:
+                if time.time() - t0 > self._timeout:
                     raise RuntimeError("FileComm: timed out waiting for rank %d" % r)
                 time.sleep(0.0005)
             with open(p) as f:
@@ -130,7 +158,7 @@ class FileComm:
     def close(self):
         self.barrier()
         # once everyone has passed exchange k, every file of exchanges < k has been read by all ranks; the files of the
-        # last exchange stay (a few bytes, named after the launcher's pid + start time, never reused)
+        # last exchange stay (a few bytes, named after the launch, never reused)
         for q in range(1, self._seq):
             try:
                 os.remove(f"{self._base}.x{q}.{self.rank}")
@@ -138,57 +166,57 @@ class FileComm:
                 pass
 
 
-class GlooComm:
-    """torch.distributed gloo; artefacts travel as host bytes and every rank loads them itself."""
+def connect(be, rank, world, uid_file, allow_file_fallback=True, timeout=120.0, force_collective=False):
+    """Collective choice of the transport -> (comm, kind) with kind 'rccl' | 'file-fallback' | 'single'.
 
-    def __init__(self, rank, world, init_method=None):
-        import torch.distributed as dist
-        self._dist = dist
-        self.rank, self.world = rank, world
-        if not dist.is_initialized():
-            dist.init_process_group("gloo", rank=rank, world_size=world, init_method=init_method)
+    Phase 1 (nothing collective has been called yet): every rank checks that librccl loads (rank 0 also draws the unique
+    id) and publishes ok / fail; if anyone failed, NO rank calls ncclCommInitRank.  Phase 2: every rank calls
+    ncclCommInitRank and publishes its outcome; RCCL is used only if all succeeded, otherwise every rank drops its
+    communicator and uses the file transport (or raises, with allow_file_fallback=False, so that the launcher can report
+    and stop the job).  A rank that dies in between makes the others' gather time out and raise."""
+    if world == 1 and not force_collective:   # (force_collective: a one-rank RCCL communicator, for the worker-route test)
+        return SingleComm(), "single"
+    rdv = Rendezvous(uid_file + ".rdv", rank, world, timeout)
+    uid, mine = None, "ok"
+    try:
+        uid = be.rccl_unique_id()          # dlopen(librccl) + ncclGetUniqueId: a purely local test on every rank
+    except Exception as e:
+        mine = f"fail: {e}"
+    if rank == 0 and uid is not None:
+        mine = "ok:" + uid.hex()
+    phase1 = rdv.gather("pre", mine)
+    errors = [f"rank {r}: {v[5:].strip()}" for r, v in enumerate(phase1) if v.startswith("fail")]
+    if not errors:
+        uid0 = bytes.fromhex(phase1[0][3:])
+        try:
+            be.rccl_init(rank, world, uid0)
+            mine = "ok"
+        except Exception as e:
+            mine = f"fail: {e}"
+        phase2 = rdv.gather("init", mine)
+        errors = [f"rank {r}: {v[5:].strip()}" for r, v in enumerate(phase2) if v.startswith("fail")]
+        if not errors:
+            return RcclComm(be, rank, world), "rccl"
+        if mine == "ok":
+            try:
+                be.rccl_finalize()
+            except Exception:
+                pass
+    msg = "RCCL start-up failed on " + "; ".join(errors)
+    if not allow_file_fallback:
+        raise RuntimeError(msg)
+    if rank == 0:
+        import sys
+        print(f"[radian_amd.dist] {msg}; all {world} ranks use the file transport and load the artefacts themselves", file=sys.stderr)
+    return FileComm(rank, world, uid_file + ".fc"), "file-fallback"
 
-    def barrier(self):
-        self._dist.barrier()
 
-    def allreduce_max(self, values):
-        import torch
-        t = torch.tensor(np.asarray(values, dtype=np.float64))
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
-        return t.numpy()
-
-    def bcast_artifacts(self, be, load_fn):
-        """load_fn(be) must call be.load_weights(flat, dilations) / be.load_lm(table, k); rank 0 runs it against a
-        recorder, the recorded host arrays are broadcast, every rank replays them into its own backend."""
-        rec = _Recorder()
-        if self.rank == 0:
-            load_fn(rec)
-        box = [rec.calls if self.rank == 0 else None]
-        self._dist.broadcast_object_list(box, src=0)
-        for name, a, kw in box[0]:
-            getattr(be, name)(*a, **kw)
-
-    def close(self):
-        if self._dist.is_initialized():
-            self._dist.destroy_process_group()
-
-
-class _Recorder:
-    def __init__(self):
-        self.calls = []
-
-    def load_weights(self, *a, **kw):
-        self.calls.append(("load_weights", a, kw))
-
-    def load_lm(self, *a, **kw):
-        self.calls.append(("load_lm", a, kw))
-
-
+# ------------------------------------------------------------------------------------------------ work distribution
 class WorkQueue:
-    """Per-node work queue over read indices ("per-rank work queue over fast5 files/reads for real input").
-    The ranks of one node share a counter file; a rank claims the next block of `block` consecutive read indices by
-    advancing the counter under an fcntl lock, so a rank with long reads simply claims fewer blocks.  Every rank walks
-    the same read sequence and asks owns(idx) in increasing idx order; results are merged by index (merge_results)."""
+    """Per-node work queue over read INDICES: the ranks share a counter file; a rank claims the next block of `block`
+    consecutive read indices by advancing the counter under a lock.  Every rank walks the same read sequence and asks
+    owns(idx) in increasing idx order.  Used when the reads come from an in-memory sequence; for fast5 directories the
+    file-level FileReadQueue below is used, so that a rank only opens the files it claimed from."""
 
     def __init__(self, path, block=256):
         import fcntl
@@ -226,13 +254,81 @@ class WorkQueue:
             self._fd = None
 
 
+class FileReadQueue:
+    """Per-node work queue over FILES, THEN READS ("per-rank work queue over fast5 files/reads"; the
+    reference's loop nest is files -> reads, basecall.py:70-72).  Shared state, under an fcntl lock: (file index, first
+    unclaimed read of that file).  A claim takes the next `block` reads of the current file, or what is left of it, and
+    moves the cursor to the next file when the file is used up.  Only the claimant needs the file's read count, so a
+    rank opens exactly the files it takes work from; claims come out in increasing (file, read) order."""
+
+    def __init__(self, path, block=256):
+        import fcntl
+        self._fcntl = fcntl
+        self.block = int(block)
+        if self.block < 1:
+            raise ValueError("work-queue block must be >= 1")
+        self._fd = os.open(path, os.O_RDWR | os.O_CREAT, 0o600)
+        self.claimed = []          # [(file, lo, hi)]
+        self.opened = set()        # files whose read count this rank had to look up
+
+    def claims(self, sources):
+        """Generator of (file_index, lo, hi) blocks owned by this rank; sources[i].n_reads() gives a file's read count."""
+        f = self._fcntl
+        while True:
+            f.flock(self._fd, f.LOCK_EX)
+            try:
+                os.lseek(self._fd, 0, os.SEEK_SET)
+                raw = os.read(self._fd, 64).split()
+                fi, r0 = (int(raw[0]), int(raw[1])) if len(raw) >= 2 else (0, 0)
+                got = None
+                while fi < len(sources):
+                    self.opened.add(fi)
+                    n = sources[fi].n_reads()
+                    if r0 >= n:
+                        fi, r0 = fi + 1, 0
+                        continue
+                    hi = min(n, r0 + self.block)
+                    got = (fi, r0, hi)
+                    fi, r0 = (fi + 1, 0) if hi == n else (fi, hi)
+                    break
+                os.lseek(self._fd, 0, os.SEEK_SET)
+                os.write(self._fd, b"%-31d %-31d\n" % (fi, r0))
+            finally:
+                f.flock(self._fd, f.LOCK_UN)
+            if got is None:
+                return
+            self.claimed.append(got)
+            yield got
+
+    def close(self):
+        if self._fd is not None:
+            os.close(self._fd)
+            self._fd = None
+
+
 def shard_indices(n, rank, world):
-    """Round-robin shard of read indices (what basecall.run uses: index % world == rank)."""
+    """Round-robin shard of read indices (what basecall.run uses without a queue: index % world == rank)."""
     return list(range(rank, n, world))
 
 
 def merge_results(per_rank_results):
-    """[(read_index, read_id, sequence)] lists from every rank -> one list in input order."""
+    """[(key, read_id, sequence)] lists from every rank -> one list in input order (small jobs / tests)."""
     merged = [r for rr in per_rank_results for r in rr]
-    merged.sort(key=lambda r: r[0])
+    merged.sort(key=lambda r: _key(r[0]))
     return merged
+
+
+def _key(k):
+    return tuple(k) if isinstance(k, (list, tuple)) else (k,)
+
+
+def iter_results_file(path):
+    with open(path) as f:
+        for line in f:
+            yield json.loads(line)
+
+
+def merge_result_files(paths):
+    """Streaming k-way merge of per-rank result files (JSON lines [key, read_id, sequence], each file in increasing key
+    order -- a rank works through its claims in order) into input order, one record in memory per rank."""
+    return heapq.merge(*[iter_results_file(p) for p in paths], key=lambda r: _key(r[0]))

@@ -38,11 +38,77 @@ def iter_reads(path):
                 yield Fast5Read(f, rid, f"/Raw/Reads/{n}/Signal")
 
 
+def list_files(fast5_dir):
+    """Every *.fast5 under fast5_dir, recursive, in Path.rglob order (basecall.py:70)."""
+    return [str(p) for p in Path(fast5_dir).rglob("*.fast5")]
+
+
 def iter_directory(fast5_dir):
     """Every read of every *.fast5 under fast5_dir, recursive, in Path.rglob order (basecall.py:70-72)."""
-    for p in Path(fast5_dir).rglob("*.fast5"):
+    for p in list_files(fast5_dir):
         for r in iter_reads(p):
             yield r
+
+
+class Fast5Source:
+    """One fast5 file as a unit of the multi-GPU work queue (dist.FileReadQueue): opened lazily, by the ranks that claim
+    reads from it only.  n_reads() / reads(lo, hi) address the file's reads in iter_reads order."""
+
+    def __init__(self, path):
+        self.path = path
+        self._f = None
+        self._entries = None   # [(read_id or None, group path, signal path)]
+
+    def _open(self):
+        if self._entries is not None:
+            return
+        self._f = h5.File(self.path, "r")
+        f = self._f
+        names = f.keys("/")
+        multi = [n for n in names if n.startswith("read_")]
+        if multi:
+            self._entries = [(n[len("read_"):], None, f"/{n}/Raw/Signal") for n in multi]
+        elif f.exists("/Raw/Reads"):
+            self._entries = [(None, f"/Raw/Reads/{n}", f"/Raw/Reads/{n}/Signal") for n in f.keys("/Raw/Reads")]
+        else:
+            self._entries = []
+
+    def n_reads(self):
+        self._open()
+        return len(self._entries)
+
+    def reads(self, lo, hi):
+        self._open()
+        for i in range(lo, min(hi, len(self._entries))):
+            rid, grp, sig = self._entries[i]
+            if rid is None:
+                rid = self._f.attr(grp, "read_id", default=grp.rsplit("/", 1)[1])
+                if isinstance(rid, bytes):
+                    rid = rid.decode()
+            yield i, Fast5Read(self._f, rid, sig)
+
+    def close(self):
+        if self._f is not None:
+            self._f.close()
+            self._f = None
+            self._entries = None
+
+
+class ListSource:
+    """An in-memory sequence of reads with the Fast5Source interface (synthetic runs, tests)."""
+
+    def __init__(self, reads):
+        self._reads = reads
+
+    def n_reads(self):
+        return len(self._reads)
+
+    def reads(self, lo, hi):
+        for i in range(lo, min(hi, len(self._reads))):
+            yield i, self._reads[i]
+
+    def close(self):
+        pass
 
 
 def write_multi_fast5(path, reads):

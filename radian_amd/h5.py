@@ -79,6 +79,7 @@ def lib():
         "H5Tis_variable_str": (ctypes.c_int, [hid_t]),
         "H5Tcopy": (hid_t, [hid_t]),
         "H5Tset_size": (herr_t, [hid_t, ctypes.c_size_t]),
+        "H5Tset_strpad": (herr_t, [hid_t, ctypes.c_int]),
         "H5Tclose": (herr_t, [hid_t]),
         "H5Aexists": (ctypes.c_int, [hid_t, ctypes.c_char_p]),
         "H5Aopen": (hid_t, [hid_t, ctypes.c_char_p, hid_t]),
@@ -321,14 +322,29 @@ class File:
         if dcpl != H5P_DEFAULT:
             L.H5Pclose(dcpl)
 
-    def set_attr_str(self, obj_path, name, value):
-        """Fixed-length string attribute (scalar str) or 1-D array of fixed-length strings (list of str)."""
+    def set_attr_str(self, obj_path, name, value, kind="nullterm"):
+        """String attribute: scalar (str) or 1-D array (list of str), in one of the three forms found in the wild:
+        kind "nullterm" fixed-length, NUL-terminated (the C default); "nullpad" fixed-length NUL-padded with no room for
+        a terminator -- what h5py writes for a NumPy 'S' array, i.e. Keras 2.4's `layer_names` / `weight_names`;
+        "vlen" variable-length strings -- what h5py 3 writes for str objects."""
         L = lib()
         vals = [value] if isinstance(value, str) else list(value)
         enc = [v.encode("utf-8") for v in vals]
-        size = max(1, max(len(e) for e in enc) + 1)
         tid = L.H5Tcopy(_types["c_s1"])
-        L.H5Tset_size(tid, size)
+        keep = None
+        if kind == "vlen":
+            L.H5Tset_size(tid, ctypes.c_size_t(-1).value)   # H5T_VARIABLE
+            keep = [ctypes.create_string_buffer(e) for e in enc]
+            buf = (ctypes.c_char_p * len(enc))(*[ctypes.cast(k, ctypes.c_char_p) for k in keep])
+        else:
+            longest = max(len(e) for e in enc) if enc else 0
+            size = max(1, longest + (0 if kind == "nullpad" else 1))
+            L.H5Tset_size(tid, size)
+            if kind == "nullpad":
+                L.H5Tset_strpad(tid, 1)                      # H5T_STR_NULLPAD
+            elif kind != "nullterm":
+                raise ValueError(f"unknown string attribute kind {kind!r}")
+            buf = ctypes.create_string_buffer(b"".join(e.ljust(size, b"\0") for e in enc), max(1, size * len(enc)))
         if isinstance(value, str):
             sid = L.H5Screate(0)  # H5S_SCALAR
         else:
@@ -336,11 +352,11 @@ class File:
             sid = L.H5Screate_simple(1, dims, None)
         oid = L.H5Oopen(self.id, _b(obj_path), H5P_DEFAULT)
         aid = L.H5Acreate2(oid, _b(name), tid, sid, H5P_DEFAULT, H5P_DEFAULT)
-        buf = ctypes.create_string_buffer(b"".join(e.ljust(size, b"\0") for e in enc), size * len(enc))
         rc = L.H5Awrite(aid, tid, buf)
         L.H5Aclose(aid)
         L.H5Oclose(oid)
         L.H5Sclose(sid)
         L.H5Tclose(tid)
+        del keep
         if rc < 0:
             raise H5Error(f"cannot write attribute {obj_path}@{name}")

@@ -15,10 +15,11 @@ def main():
     out_dir, mode = sys.argv[1], sys.argv[2]
     queue_block = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     from radian_amd import basecall, dist, weights
+    from _gloo_comm import GlooComm
     from _oracle_backend import OracleBackend
     from _reads import golden_reads
     rank, _, world = dist.env_rank_world()
-    comm = dist.GlooComm(rank, world, init_method=f"tcp://127.0.0.1:{os.environ['MASTER_PORT']}")
+    comm = GlooComm(rank, world, init_method=f"tcp://127.0.0.1:{os.environ['MASTER_PORT']}")
     args = basecall.build_parser().parse_args(
         ["unused_in", "unused_out", "--chunk-len", "256", "--step-size", "128", "--beam-width", "4", "--decode-type", mode,
          "--gpu-batch-windows", "24", "--context-len", "3"])

@@ -112,3 +112,140 @@ def test_work_queue_many_claimers(tmp_path):
     assert all(p.wait(timeout=120) == 0 for p in procs)
     owned = [json.load(open(tmp_path / f"own{r}.json")) for r in range(4)]
     assert sorted(i for o in owned for i in o) == list(range(n))   # (a late starter may find nothing left: fine)
+
+
+def _spawn(script_args, world, extra_env=None, timeout=300):
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), OMP_NUM_THREADS="1", **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable] + script_args, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=timeout)[0].decode() for p in procs]
+    return procs, outs
+
+
+def test_world8_file_queue_order_and_fasta_rotation(tmp_path):
+    """8 ranks (file transport), 10 500 reads in 6 fast5 files of uneven size + one empty file, through the launcher's
+    worker route: every read exactly once, a rank opens only files it claimed reads from, the streaming merge restores
+    input order and the FASTA rotates every 1000 reads (basecall.py:134-138)."""
+    import numpy as np
+    from radian_amd import fast5, launch
+    world = 8
+    in_dir = tmp_path / "in"
+    (in_dir / "sub").mkdir(parents=True)
+    rng = np.random.default_rng(11)
+    counts = [4000, 1, 2999, 0, 1500, 1900, 100]
+    for fi, n in enumerate(counts):
+        reads = {f"f{fi}-{i:05d}": rng.integers(0, 2000, size=24).astype(np.int16) for i in range(n)}
+        if fi == 2:
+            reads["f2-00007"] = np.full(24, 9, dtype=np.int16)   # MAD == 0 -> skipped, leaves a gap in the keys
+        fast5.write_multi_fast5(str((in_dir / "sub" if fi % 2 else in_dir) / f"r{fi}.fast5"), reads)
+    files = fast5.list_files(str(in_dir))
+    assert len(files) == len(counts)
+    scratch = tmp_path / "scratch"
+    scratch.mkdir()
+    json.dump(files, open(scratch / "files.json", "w"))
+    procs, outs = _spawn([os.path.join(ROOT, "tests", "_queue_worker.py"), str(scratch), "0.002"], world)
+    assert all(p.returncode == 0 for p in procs), outs
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    n = launch.merge_to_fasta(str(scratch), world, str(out_dir))
+    # expected: the single-process order = files in list order, reads in name order
+    exp = []
+    for path in files:
+        for r in fast5.iter_reads(path):
+            raw = r.get_raw_data()
+            if (raw == raw[0]).all():
+                continue
+            exp.append((r.read_id, "".join("ACGT"[c] for c in (raw[:16] % 4))[::-1]))
+    assert n == len(exp) == sum(counts) - 1
+    got = []
+    nfiles = n // 1000 + 1
+    assert sorted(os.listdir(out_dir)) == sorted(f"reads-{i}.fasta" for i in range(nfiles))
+    for i in range(nfiles):
+        lines = open(out_dir / f"reads-{i}.fasta").read().split("\n")[:-1]
+        assert len(lines) == (2000 if i < nfiles - 1 else 2 * (n - 1000 * (nfiles - 1)))
+        got += [(lines[j][1:], lines[j + 1]) for j in range(0, len(lines), 2)]
+    assert got == exp
+    # queue accounting
+    all_claims = []
+    for rank in range(world):
+        q = json.load(open(scratch / f"queue{rank}.json"))
+        claimed_files = {c[0] for c in q["claimed"]}
+        empty = {i for i, p in enumerate(files) if p.endswith("r3.fast5")}
+        assert set(q["opened"]) <= claimed_files | empty, (rank, q["opened"], claimed_files)
+        all_claims += [tuple(c) for c in q["claimed"]]
+    all_claims.sort()
+    covered = {}
+    for fi, lo, hi in all_claims:
+        assert covered.get(fi, 0) == lo and hi - lo <= 96
+        covered[fi] = hi
+    sizes = {i: fast5.Fast5Source(p).n_reads() for i, p in enumerate(files)}
+    assert covered == {i: nreads for i, nreads in sizes.items() if nreads}
+    assert len({c[0] for c in all_claims}) == 6 and len(all_claims) >= sum(counts) // 96
+
+
+def test_transport_agreement(tmp_path):
+    """dist.connect with stand-in rccl_* calls, 3 ranks: (a) all fine -> 'rccl' everywhere; (b) rank 1's
+    ncclCommInitRank fails -> every rank drops RCCL and the file transport's barrier / max work; (c) rank 2 cannot even
+    load librccl -> NO rank calls ncclCommInitRank.  Never a mix."""
+    script = tmp_path / "c.py"
+    script.write_text(
+        "import os, sys, json\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from radian_amd import dist\n"
+        "rank, _, world = dist.env_rank_world()\n"
+        "case = sys.argv[1]\n"
+        "class Be:\n"
+        "    inits = 0; finals = 0\n"
+        "    def rccl_unique_id(self):\n"
+        "        if case == 'c' and rank == 2: raise RuntimeError('cannot dlopen librccl')\n"
+        "        return bytes([rank + 1]) * 128\n"
+        "    def rccl_init(self, r, w, uid):\n"
+        "        Be.inits += 1\n"
+        "        assert uid == bytes([1]) * 128 and (r, w) == (rank, world)\n"
+        "        if case == 'b' and rank == 1: raise RuntimeError('ncclCommInitRank: invalid usage')\n"
+        "    def rccl_finalize(self): Be.finals += 1\n"
+        "    def rccl_barrier(self): pass\n"
+        "    def rccl_allreduce_max(self, v): return v\n"
+        f"comm, kind = dist.connect(Be(), rank, world, os.path.join({str(tmp_path)!r}, 'uid_' + case), timeout=60)\n"
+        "comm.barrier()\n"
+        "m = comm.allreduce_max([float(rank)])\n"
+        "if kind != 'rccl': assert m[0] == world - 1\n"
+        "comm.close()\n"
+        f"json.dump([kind, type(comm).__name__, Be.inits, Be.finals], open(os.path.join({str(tmp_path)!r}, f'res_{{case}}_{{rank}}.json'), 'w'))\n")
+    for case, exp_kind, exp_inits in (("a", "rccl", 1), ("b", "file-fallback", 1), ("c", "file-fallback", 0)):
+        procs, outs = _spawn([str(script), case], 3, timeout=120)
+        assert all(p.returncode == 0 for p in procs), outs
+        res = [json.load(open(tmp_path / f"res_{case}_{r}.json")) for r in range(3)]
+        assert [r[0] for r in res] == [exp_kind] * 3, res
+        assert [r[2] for r in res] == [exp_inits] * 3, res
+        if case == "b":   # the ranks whose init had succeeded gave their communicator back
+            assert [r[3] for r in res] == [1, 0, 1], res
+    # without the fallback the failure is raised on every rank (the launcher then stops the job)
+    from radian_amd import dist
+
+    class Bad:
+        def rccl_unique_id(self):
+            raise RuntimeError("no librccl")
+    with pytest.raises(RuntimeError, match="RCCL start-up failed on rank 0"):
+        dist.connect(Bad(), 0, 1, str(tmp_path / "uid_d"), allow_file_fallback=False, force_collective=True)
+
+
+def test_launcher_stops_job_when_a_worker_fails(tmp_path):
+    """launch.wait_all: one worker exits non-zero while the others would block forever -> they are terminated and the
+    exit codes come back promptly; a missing artefact is reported by the parent before anything is spawned."""
+    import time
+    from radian_amd import basecall, launch
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"]) for _ in range(2)]
+    procs.insert(1, subprocess.Popen([sys.executable, "-c", "import sys, time; time.sleep(0.3); sys.exit(3)"]))
+    rcs = launch.wait_all(procs)
+    assert rcs[1] == 3 and all(rc not in (0, None) for rc in rcs) and time.time() - t0 < 30
+    (tmp_path / "in").mkdir()
+    (tmp_path / "out").mkdir()
+    argv = [str(tmp_path / "in"), str(tmp_path / "out"), "--sig-model", str(tmp_path / "nope.h5"), "--gpus", "2"]
+    with pytest.raises((FileNotFoundError, OSError, RuntimeError)):
+        launch.run_multi_gpu(basecall.build_parser().parse_args(argv), argv)
+    argv = [str(tmp_path / "in"), str(tmp_path / "out"), "--sig-model", "synthetic:1", "--sig-config", "none", "--gpus", "2"]
+    with pytest.raises(FileNotFoundError):   # default --rna-model is not shipped; global mode needs it
+        launch.run_multi_gpu(basecall.build_parser().parse_args(argv), argv)

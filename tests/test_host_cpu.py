@@ -42,6 +42,63 @@ def test_product_stitch_matches_golden(golden_dir):
         assert S.consensus_sequence(c["fragments"]) == c["seq"]
 
 
+def test_product_stitch_matches_oracle_hypothesis(oracle):
+    """random fragment lists (overlapping, unrelated, empty, lower case, >= 200 characters = difflib autojunk, more than
+    1000 columns = the reference's matrix growth) against the oracle's statement-level restatement of
+    sequence_assembly.py:19-48; the IndexError of the reference's fixed growth step is kept too"""
+    from hypothesis import given, settings, strategies as st
+    from radian_amd import sequence_assembly as S
+
+    @st.composite
+    def fragment_lists(draw):
+        n = draw(st.integers(0, 7))
+        base = draw(st.text("ACGT", min_size=0, max_size=700))
+        frags = []
+        pos = 0
+        for _ in range(n):
+            kind = draw(st.integers(0, 4))
+            if kind == 0 or not base:
+                f = draw(st.text("ACGTacgt", min_size=0, max_size=draw(st.sampled_from([5, 40, 260, 450]))))
+            else:   # a noisy slice of a common sequence, advancing like consecutive windows do
+                pos = min(len(base), pos + draw(st.integers(0, 120)))
+                f = base[pos: pos + draw(st.integers(0, 420))]
+                if f and draw(st.booleans()):
+                    i = draw(st.integers(0, len(f) - 1))
+                    f = f[:i] + draw(st.sampled_from("ACGT")) + f[i + 1:]
+            frags.append(f)
+        return frags
+
+    @settings(max_examples=300, deadline=None)
+    @given(fragment_lists())
+    def check(frags):
+        try:
+            exp = oracle.simple_assembly(frags)
+        except IndexError:
+            with pytest.raises(IndexError):
+                S.simple_assembly(frags)
+            return
+        got = S.simple_assembly(frags)
+        assert got.shape == exp.shape and got.dtype == exp.dtype and np.array_equal(got, exp)
+        assert S.consensus_sequence(frags) == oracle.chunk_consensus(frags)
+
+    check()
+    # deterministic corner cases: one fragment (L = 0), growth by exactly one step, overflow of the fixed step, bad letters
+    long = "ACGT" * 260                                   # 1040 characters
+    assert S.simple_assembly(["ACGT"]).shape == (4, 0) and S.consensus_sequence(["ACGTT"]) == ""
+    assert np.array_equal(S.simple_assembly(["A" * 900, "C" * 950]), oracle.simple_assembly(["A" * 900, "C" * 950]))
+    for bad in ([long], ["A" * 990, "C", "C" + "G" * 1012]):
+        with pytest.raises(IndexError):
+            oracle.simple_assembly(bad)
+        with pytest.raises(IndexError):
+            S.simple_assembly(bad)
+    with pytest.raises(KeyError):
+        S.simple_assembly(["ACGT", "ACNT"])
+    v = np.zeros((4, 6))
+    S.add_count(v, -2, "ACGTA")
+    assert v[:, :3].tolist() == [[0, 0, 1], [0, 0, 0], [1, 0, 0], [0, 1, 0]] and v.sum() == 3
+    assert S.index2base([0, 3, 2, 1]) == "ATGC"
+
+
 def test_lm_json_loader(tmp_path):
     from radian_amd import lm
     rng = np.random.default_rng(0)
@@ -99,6 +156,22 @@ def test_keras_h5_converter_roundtrip(tmp_path):
     assert np.array_equal(h5weights.read_keras_weights(p), w)
     with pytest.raises(ValueError):
         h5weights.read_keras_weights(p, dilations=(1, 2, 4))
+    # the forms a Keras / h5py-written file can take (written here through libhdf5 in exactly those HDF5 encodings):
+    # NumPy-'S' arrays (NUL-padded fixed strings, Keras 2.4 + h5py 2.10 -- the reference's pin), variable-length
+    # strings (h5py 3), NUL-terminated; the tree at the root (save_weights) or under /model_weights (model.save);
+    # `weight_names` split into weight_names0.. chunks
+    for i, (kind, root, chunk) in enumerate([("nullpad", "/", 0), ("vlen", "/", 0), ("nullterm", "/model_weights", 0),
+                                             ("vlen", "/model_weights", 7), ("nullpad", "/", 5)]):
+        q = str(tmp_path / f"form{i}.h5")
+        h5weights.write_keras_weights(q, w, attr_kind=kind, root=root, chunk_names=chunk)
+        assert np.array_equal(h5weights.read_keras_weights(q), w), (kind, root, chunk)
+    from radian_amd import h5
+    with h5.File(str(tmp_path / "form0.h5"), "r") as f:     # exact-fit NUL-padded strings come back whole
+        assert f.attr("/", "layer_names") == ["inputs", "tcn", "dense", "activation", "dense_1", "activation_1"]
+        assert f.attr("/tcn", "weight_names")[0] == "tcn/residual_block_0/conv1D_0/kernel:0"
+    (tmp_path / "junk.h5").write_bytes(b"not hdf5")
+    with pytest.raises(Exception):
+        h5weights.read_keras_weights(str(tmp_path / "junk.h5"))
 
 
 def test_cli_flags_match_reference():
