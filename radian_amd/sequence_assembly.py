@@ -5,7 +5,7 @@ arguments, results and error behaviour) plus the two lines of radian/basecall.py
 a string.  The formulation is this repository's own: the placement of every fragment is computed first (one
 `difflib.SequenceMatcher` per consecutive pair -- the stdlib class the reference calls, including its autojunk heuristic
 for fragments >= 200 characters), then all votes are counted in one `numpy.bincount` over a matrix sized once.
-Behaviour is pinned by tests/golden/seq_assembly_cases.json (from the reference) and a hypothesis test against the oracle.
+Behaviour is pinned by tests/golden/seq_assembly_cases.json (from the reference) and by the randomised comparison in tests/test_host_cpu.py.
 """
 import difflib
 
