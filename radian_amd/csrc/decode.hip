@@ -28,12 +28,112 @@ namespace {
 
 constexpr double kLogE2 = 0.693147180559945309417232121458176568;
 
-// numpy npy_logaddexp (decode.py:172-201 call np.logaddexp on python floats)
+// ---- logaddexp --------------------------------------------------------------------------------------------------------
+// numpy's npy_logaddexp (decode.py:172-201 call np.logaddexp on Python floats) is  hi + log1p(exp(lo - hi)).  The two
+// transcendentals are evaluated by the routines below instead of the generic device-library ones: the argument ranges are
+// known (exp of a non-positive number, log1p of a number in [0, 1]), which makes both a short fma chain -- 75 instructions
+// for the pair against ~175 (the generic log1p runs a double-double reduction) -- at the same accuracy class: measured
+// against 80-bit references over 2.5e7 arguments, exp_nonpos <= 0.68 ulp, log1p_unit <= 0.63 ulp, their composition
+// <= 1.55 ulp (glibc's: 0.51 / 0.82 / 1.54).  So scores keep agreeing with the reference's to a few ulp.
+#pragma clang fp contract(off)
+// Horner chains with the coefficients in scalar register pairs.  As plain C++ hipcc keeps all ~30 coefficients in VGPRs
+// across the time loop and spends a v_mov_b64 + v_fmac_f64 per step (the VOP2 form accumulates into the coefficient's
+// copy); here a step is one v_fma_f64 and no vector register.  One asm statement per chain (no hazard padding between
+// the steps: each v_fma_f64 only reads the previous one's result, which the hardware interlocks).
+__device__ __forceinline__ double horner10(double q, double x, double c0, double c1, double c2, double c3, double c4, double c5,
+                                           double c6, double c7, double c8, double c9)
+{
+    asm("v_fma_f64 %0, %0, %1, %2\n\tv_fma_f64 %0, %0, %1, %3\n\tv_fma_f64 %0, %0, %1, %4\n\tv_fma_f64 %0, %0, %1, %5\n\t"
+        "v_fma_f64 %0, %0, %1, %6\n\tv_fma_f64 %0, %0, %1, %7\n\tv_fma_f64 %0, %0, %1, %8\n\tv_fma_f64 %0, %0, %1, %9\n\t"
+        "v_fma_f64 %0, %0, %1, %10\n\tv_fma_f64 %0, %0, %1, %11"
+        : "+v"(q)
+        : "v"(x), "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6), "s"(c7), "s"(c8), "s"(c9));
+    return q;
+}
+__device__ __forceinline__ double horner16(double q, double x, double c0, double c1, double c2, double c3, double c4, double c5,
+                                           double c6, double c7, double c8, double c9, double c10, double c11, double c12,
+                                           double c13, double c14, double c15)
+{
+    asm("v_fma_f64 %0, %0, %1, %2\n\tv_fma_f64 %0, %0, %1, %3\n\tv_fma_f64 %0, %0, %1, %4\n\tv_fma_f64 %0, %0, %1, %5\n\t"
+        "v_fma_f64 %0, %0, %1, %6\n\tv_fma_f64 %0, %0, %1, %7\n\tv_fma_f64 %0, %0, %1, %8\n\tv_fma_f64 %0, %0, %1, %9\n\t"
+        "v_fma_f64 %0, %0, %1, %10\n\tv_fma_f64 %0, %0, %1, %11\n\tv_fma_f64 %0, %0, %1, %12\n\tv_fma_f64 %0, %0, %1, %13\n\t"
+        "v_fma_f64 %0, %0, %1, %14\n\tv_fma_f64 %0, %0, %1, %15\n\tv_fma_f64 %0, %0, %1, %16\n\tv_fma_f64 %0, %0, %1, %17"
+        : "+v"(q)
+        : "v"(x), "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6), "s"(c7), "s"(c8), "s"(c9), "s"(c10), "s"(c11),
+          "s"(c12), "s"(c13), "s"(c14), "s"(c15));
+    return q;
+}
+// e^d for d <= 0 (d = -inf and d < -745.2 give 0; subnormal results are rounded by v_ldexp_f64)
+__device__ __forceinline__ double exp_nonpos(double d)
+{
+    constexpr double L2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double dd = fmax(d, -746.0);
+    const double kf = rint(dd * L2E);
+    const double rh = __builtin_fma(-kf, LN2_HI, dd);   // exact: LN2_HI has 32 significant bits, |kf| < 2^11
+    const double tl = kf * LN2_LO;
+    const double r = rh - tl;
+    const double rl = (rh - r) - tl;                    // r + rl = rh - tl to ~2^-106
+    double q = 1.0 / 6227020800.0;                      // Taylor: e^r = 1 + r + r^2 (1/2! + r/3! + ... + r^11/13!), |r| <= ln2/2
+    q = horner10(q, r, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0,
+                 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0);
+    q = __builtin_fma(q, r, 0.5);
+    const double s1 = 1.0 + r;
+    const double e1 = (1.0 - s1) + r;                   // exact (|r| < 1)
+    const double p = s1 + (__builtin_fma(r * r, q, rl) + e1);
+    return ldexp(p, (int)kf);
+}
+// log(1 + t) for 0 <= t <= 1:  2 atanh(t / (2 + t)) = 2 (s + s^3/3 + s^5/5 + ...), s <= 1/3.  The quotient s comes from
+// a Newton-refined reciprocal (2 <= 2 + t <= 3: no scaling cases) and its rounding is compensated to first order, which
+// is worth more than a correctly rounded division would be.
+__device__ __forceinline__ double log1p_unit(double t)
+{
+    const double d = 2.0 + t;
+    const double dlo = t - (d - 2.0);                   // exact
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);                         // 1 / d to working precision
+    const double s = t * y;
+    double r = __builtin_fma(-s, d, t);
+    r = __builtin_fma(-s, dlo, r);                      // t - s (2 + t)
+    const double slo = r * y;
+    const double z = s * s;
+    double P = 1.0 / 35.0;
+    P = horner16(P, z, 1.0 / 33.0, 1.0 / 31.0, 1.0 / 29.0, 1.0 / 27.0, 1.0 / 25.0, 1.0 / 23.0, 1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0,
+                 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0, 1.0 / 5.0, 1.0 / 3.0);
+    const double corr = __builtin_fma(s * z, P, slo);
+    const double v = 2.0 * (s + corr);
+    return t < 0x1p-60 ? t : v;
+}
+#pragma clang fp contract(on)
+
+// rank += number of k0..k3 that are > key (NaN compares false).  Four compares into four scalar mask pairs, then four
+// add-with-carry: 8 vector instructions per 4 keys, and each mask is read >= 3 instructions after the compare that wrote
+// it (a VALU-written SGPR needs 2 wait states before a VALU reads it as carry-in; as C++ the compiler chains everything
+// through VCC with an s_nop behind every compare and a v_cndmask per pair).
+__device__ __forceinline__ int count4_gt(int rank, double k0, double k1, double k2, double k3, double key)
+{
+    unsigned long long m0, m1, m2, m3;
+    asm("v_cmp_gt_f64_e64 %1, %5, %9\n\t"
+        "v_cmp_gt_f64_e64 %2, %6, %9\n\t"
+        "v_cmp_gt_f64_e64 %3, %7, %9\n\t"
+        "v_cmp_gt_f64_e64 %4, %8, %9\n\t"
+        "v_addc_co_u32_e64 %0, %1, %0, 0, %1\n\t"
+        "v_addc_co_u32_e64 %0, %2, %0, 0, %2\n\t"
+        "v_addc_co_u32_e64 %0, %3, %0, 0, %3\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, 0, %4"
+        : "+v"(rank), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(k0), "v"(k1), "v"(k2), "v"(k3), "v"(key));
+    return rank;
+}
+
+// numpy npy_logaddexp
 __device__ __forceinline__ double lae(double x, double y)
 {
-    if (x == y) return x + kLogE2;
-    double hi = fmax(x, y), lo = fmin(x, y);
-    return hi + log1p(exp(lo - hi));
+    const double hi = fmax(x, y), lo = fmin(x, y);
+    const double r = hi + log1p_unit(exp_nonpos(lo - hi));
+    return x == y ? x + kLogE2 : r;    // (also the -inf / -inf case: lo - hi would be NaN)
 }
 
 // The workgroup IS one wave (launch bounds 64), so LDS hand-offs between lanes need no s_barrier and -- the point -- no
@@ -87,10 +187,20 @@ struct DecodeArgs {
     double* best_score;
 };
 
+// node id -> beam slot, one byte per entry, indexed by the low bits of the id.  Entries are never cleared: a hit is
+// verified against the live node array, so a stale byte is harmless.  Two kept beams whose ids collide in the table are
+// detected when the table is filled (once per step) and that step falls back to comparing against every beam.
+template <int R>
+struct Tab {
+    static constexpr int N = 512 * R;
+};
+
 template <typename PT, int R, bool LM>
 __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
 {
     constexpr int WM = Cfg<R>::WM;
+    constexpr int NC = Cfg<R>::NC;
+    constexpr int TN = Tab<R>::N;
     const int lane = threadIdx.x;
     const int seq = blockIdx.x;
     const int T = a.seq_len[seq];
@@ -110,6 +220,8 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
     __shared__ double lp[64][5];
     __shared__ double praw[LM ? 64 : 1][5];
     __shared__ double sent[LM ? 64 : 1];
+    __shared__ __attribute__((aligned(16))) double keyC[NC + 4];   // keys of the ranking's survivors, compacted in insertion order
+    __shared__ unsigned char tabslot[TN];
 
     // decode.py:128-132: the empty labeling with pr_blank = pr_total = log(1)
     if (lane == 0) {
@@ -123,10 +235,12 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
         for (int c = 0; c < 4; c++) st[0].child[c][0] = 0;
         childtab[0] = make_int4(0, 0, 0, 0);
         backptr[0] = 0;
+        tabslot[0] = 0;
     }
-    int nb = 1;        // beams currently kept (wave-uniform)
-    int next_id = 1;   // next free trie node id (wave-uniform)
+    int nb = 1;              // beams currently kept (wave-uniform)
+    int next_id = 1;         // next free trie node id (wave-uniform)
     int cur = 0;
+    bool tab_ok = true;      // the node -> slot table resolves every kept beam (wave-uniform)
     wave_sync();
 
     for (int t0 = 0; t0 < T; t0 += 64) {
@@ -172,7 +286,7 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
             BeamState<WM>& ns = st[cur ^ 1];
             const int ncand = 5 * nb;
 
-            // ---------------- Phase A: candidate scores -------------------------------------------------
+            // ---------------- Phase A: candidate scores; which extension equals which kept labeling? -------------
             bool valid[R];
             int bi[R], kk[R], pj[R], dcopy[R];
             double c_ptot[R], c_pnb[R], c_pb[R];
@@ -226,70 +340,63 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                     c_pb[s] = pb_c;
                     c_ptot[s] = 0.0;  // lae(pb_c, pnb_c) below
                     dcopy[s] = i;
+                    if (valid[s]) {
+                        cpy_pnb[i] = pnb_c;
+                        cpy_pb[i] = pb_c;
+                        mb_q[i] = -1;
+                    }
                 } else {
                     // EXTEND decode.py:186-201
                     const double v = ((last_i == k - 1) ? pb_i : ptot_i) + lpc;
                     c_pnb[s] = v;
                     c_pb[s] = -INFINITY;
                     c_ptot[s] = v;
-                }
-            }
-            // total of the copy candidates: logaddexp(pr_blank, pr_non_blank) decode.py:174-175
-#pragma unroll
-            for (int s = 0; s < R; s++) {
-                const double tot = lae(c_pb[s], c_pnb[s]);
-                if (kk[s] == 0) {
-                    c_ptot[s] = tot;
-                    if (valid[s]) {
-                        cpy_pnb[bi[s]] = c_pnb[s];
-                        cpy_tot[bi[s]] = tot;
-                        cpy_pb[bi[s]] = c_pb[s];
-                        mb_q[bi[s]] = -1;
+                    // the labeling "beam i + label" is already kept iff its trie id is some kept beam's id
+                    const int x = valid[s] ? os.child[k - 1][i] : 0;
+                    if (tab_ok) {
+                        int sl = tabslot[x & (TN - 1)];
+                        sl = sl < WM ? sl : WM - 1;
+                        if (x != 0 && sl < nb && os.node[sl] == x) pj[s] = sl;
+                    } else {
+                        int found = -1;
+                        for (int j = 0; j < nb; j++)
+                            if (os.node[j] == x) found = j;
+                        if (x != 0) pj[s] = found;
                     }
                 }
             }
             wave_sync();
 
-            // ---------------- Phase C: which extension equals which kept labeling? ----------------------
-            const int node_reg = lane < nb ? os.node[lane] : -1;   // beam j's trie id lives in lane j
-#pragma unroll
-            for (int s = 0; s < R; s++) {
-                const int x = (valid[s] && kk[s] > 0) ? os.child[kk[s] - 1][bi[s]] : 0;
-                int found = -1;
-#pragma unroll
-                for (int j = 0; j < WM; j++)   // lanes >= nb hold -1: constant lane selects, no loop-carried scalar
-                    if (__builtin_amdgcn_readlane(node_reg, j) == x) found = j;
-                if (x != 0 && found >= 0) {
-                    pj[s] = found;
-                    mb_q[found] = s * 64 + lane;
-                    mb_v[found] = c_ptot[s];
-                }
-            }
-            wave_sync();
+            // ---------------- lae pass 1: copies: pr_total = logaddexp(pr_blank, pr_non_blank) (decode.py:174-175);
+            //                  merging extensions: pr_non_blank of the merged entry = logaddexp(copy.pnb, v) (decode.py:199)
             bool any_merge = false;
 #pragma unroll
             for (int s = 0; s < R; s++) {
-                const bool m = valid[s] && ((kk[s] == 0) ? (mb_q[bi[s]] >= 0) : (pj[s] >= 0));
-                any_merge |= __any(m);
+                const bool mext = pj[s] >= 0;
+                const double x = mext ? cpy_pnb[pj[s]] : c_pb[s];
+                const double y = mext ? c_ptot[s] : c_pnb[s];
+                const double r = lae(x, y);
+                if (kk[s] == 0) {
+                    c_ptot[s] = r;
+                    if (valid[s]) cpy_tot[bi[s]] = r;
+                } else if (mext) {
+                    mb_q[pj[s]] = s * 64 + lane;
+                    mb_v[pj[s]] = c_ptot[s];
+                    mQ[pj[s]] = r;
+                }
+                any_merge |= __any(mext);
             }
             if (any_merge) {
-                // merged entry: pr_non_blank = lae(copy.pnb, v); pr_total = lae(copy.total, v)   (decode.py:172-175,199-201)
+                wave_sync();
+                // ---------- lae pass 2: pr_total of the merged entry = logaddexp(copy.total, v) (decode.py:200-201), by the copy's lane
 #pragma unroll
                 for (int s = 0; s < R; s++) {
-                    double x = -INFINITY, y = -INFINITY;
-                    const bool is_copy = kk[s] == 0;
-                    const bool m = valid[s] && (is_copy ? (mb_q[bi[s]] >= 0) : (pj[s] >= 0));
-                    if (m) {
-                        if (is_copy) { x = c_ptot[s]; y = mb_v[bi[s]]; }
-                        else { x = cpy_pnb[pj[s]]; y = c_ptot[s]; }
-                    }
-                    const double r = lae(x, y);
-                    if (m) {
-                        if (is_copy) mP[bi[s]] = r;
-                        else mQ[pj[s]] = r;
-                    }
+                    const bool m = valid[s] && kk[s] == 0 && mb_q[bi[s]] >= 0;
+                    const double r = lae(c_ptot[s], m ? mb_v[bi[s]] : -INFINITY);
+                    if (m) mP[bi[s]] = r;
                 }
                 wave_sync();
+                // the merged entry lives in whichever of the two candidates was inserted first (dict order); the other is gone
 #pragma unroll
                 for (int s = 0; s < R; s++) {
                     const int q = s * 64 + lane;
@@ -314,78 +421,75 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
             }
 
             // ---------------- Phase D: rank by (pr_total desc, insertion order asc)  decode.py:35-39,145 ------
-            // rank = number of candidates ahead.  Candidate qq's key is broadcast out of its lane's register with
-            // v_readlane (a scalar operand of the compares): no LDS round trip per candidate.
-            int nvalid = 0;
+            // Only candidates that can reach the top W are ranked.  Every kept labeling survives this step as an entry
+            // (its copy, merged or not) whose pr_total >= pr_total_old + log p(blank) >= tau := the weakest kept beam's
+            // pr_total + log p(blank): with W beams kept there are W entries >= tau, so an entry below tau is not among
+            // the best W.  The survivors' keys are compacted into LDS in insertion order and each survivor counts the
+            // keys ahead of it (16-B LDS broadcasts, two keys per read).
+            int nvalid = 0, S = 0;
             double key[R];
+            bool surv[R];
+            int cidx[R];
+            const double tau = (nb == W) ? os.ptot[nb - 1] + lp_blank : -INFINITY;
 #pragma unroll
             for (int s = 0; s < R; s++) {
                 key[s] = valid[s] ? c_ptot[s] : __builtin_nan("");
-                nvalid += __popcll(__ballot(valid[s]));
+                surv[s] = valid[s] && key[s] >= tau;
+                const unsigned long long mv = __ballot(valid[s]), ms = __ballot(surv[s]);
+                nvalid += __popcll(mv);
+                cidx[s] = S + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ms >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ms, 0u));
+                S += __popcll(ms);
             }
-            // Fast count: candidates with a strictly greater key, four broadcasts per trip (lanes past ncand hold NaN and
-            // count for nothing).  Two candidates get the same count iff their keys are equal, so a collision among the
-            // counts below W -- found by letting the lanes claim rk_owner[count] -- means a tie that matters; only then is
-            // the count redone with the insertion-order rule (exact 0 probabilities make such ties; softmax rows do not).
+            if (lane < 4) keyC[S + lane] = -INFINITY;   // padding of the last group of four
+#pragma unroll
+            for (int s = 0; s < R; s++)
+                if (surv[s]) keyC[cidx[s]] = key[s];
+            wave_sync();
             int rank[R];
 #pragma unroll
             for (int s = 0; s < R; s++) rank[s] = 0;
+            for (int j = 0; j < S; j += 4) {
+                const double2 ka = *(const double2*)&keyC[j], kb = *(const double2*)&keyC[j + 2];
 #pragma unroll
-            for (int s2 = 0; s2 < R; s2++) {
-                const int cnt = (ncand - s2 * 64) < 64 ? (ncand - s2 * 64) : 64;   // wave-uniform
-                const int klo = __double2loint(key[s2]), khi = __double2hiint(key[s2]);
-                for (int l = 0; l < cnt; l += 4) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int ll = (l + u) & 63;
-                        const double kv = __hiloint2double(__builtin_amdgcn_readlane(khi, ll), __builtin_amdgcn_readlane(klo, ll));
-#pragma unroll
-                        for (int s = 0; s < R; s++) rank[s] += (kv > key[s]) ? 1 : 0;
-                    }
-                }
-            }
-            bool tie = false;
-#pragma unroll
-            for (int s = 0; s < R; s++)
-                if (valid[s] && rank[s] < W) rk_owner[rank[s]] = s * 64 + lane;
-            wave_sync();
-#pragma unroll
-            for (int s = 0; s < R; s++) tie |= valid[s] && rank[s] < W && rk_owner[rank[s]] != s * 64 + lane;
-            if (__any(tie)) {
-#pragma unroll
-                for (int s = 0; s < R; s++) rank[s] = 0;
-#pragma unroll
-                for (int s2 = 0; s2 < R; s2++) {
-                    const int cnt = (ncand - s2 * 64) < 64 ? (ncand - s2 * 64) : 64;
-                    const int klo = __double2loint(key[s2]), khi = __double2hiint(key[s2]);
-                    for (int l = 0; l < cnt; l++) {
-                        const double kv = __hiloint2double(__builtin_amdgcn_readlane(khi, l), __builtin_amdgcn_readlane(klo, l));
-                        const int qq = s2 * 64 + l;
-#pragma unroll
-                        for (int s = 0; s < R; s++) {
-                            const int q = s * 64 + lane;
-                            const bool ahead = (kv > key[s]) || (kv == key[s] && qq < q);
-                            rank[s] += ahead ? 1 : 0;
-                        }
-                    }
-                }
+                for (int s = 0; s < R; s++) rank[s] = count4_gt(rank[s], ka.x, ka.y, kb.x, kb.y, key[s]);
             }
             const int nb_new = nvalid < W ? nvalid : W;
 
-            // ---------------- Phase E: scatter the kept candidates to their new beam slot ---------------------
+            // ---------------- Phase E: the kept candidates move to their new beam slot ------------------------
+            // The count above is of strictly greater keys: equal keys get the same count, so two candidates claiming one
+            // slot below W means a tie that matters; only then is the count redone with the insertion-order rule (exact 0
+            // probabilities make such ties; softmax rows do not) and the slots are written again.
+            auto scatter = [&]() {
 #pragma unroll
-            for (int s = 0; s < R; s++) {
-                if (valid[s] && rank[s] < W) {
-                    const int r = rank[s];
-                    ns.ptot[r] = c_ptot[s];
-                    ns.pb[r] = c_pb[s];
-                    ns.pnb[r] = c_pnb[s];
-                    d_copy[r] = dcopy[s];
-                    d_par[r] = bi[s];
-                    d_c[r] = kk[s] - 1;
+                for (int s = 0; s < R; s++) {
+                    if (surv[s] && rank[s] < W) {
+                        const int r = rank[s];
+                        ns.ptot[r] = c_ptot[s];
+                        ns.pb[r] = c_pb[s];
+                        ns.pnb[r] = c_pnb[s];
+                        d_copy[r] = dcopy[s];
+                        d_par[r] = bi[s];
+                        d_c[r] = kk[s] - 1;
+                        rk_owner[r] = s * 64 + lane;
+                    }
                 }
-            }
+            };
+            scatter();
             wave_sync();
+            bool tie = false;
+#pragma unroll
+            for (int s = 0; s < R; s++) tie |= surv[s] && rank[s] < W && rk_owner[rank[s]] != s * 64 + lane;
+            if (__any(tie)) {
+#pragma unroll
+                for (int s = 0; s < R; s++) rank[s] = 0;
+                for (int j = 0; j < S; j++) {
+                    const double kv = keyC[j];
+#pragma unroll
+                    for (int s = 0; s < R; s++) rank[s] += ((kv > key[s]) || (kv == key[s] && j < cidx[s])) ? 1 : 0;
+                }
+                scatter();
+                wave_sync();
+            }
 
             // ---------------- Phase F: trie ids for the new beam set ------------------------------------------
             int my_node = 0, my_par = 0, my_c = 0;
@@ -422,16 +526,19 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                 }
             }
             wave_sync();
+            int new_node = -1;
             if (lane < nb_new) {
                 const int j = d_copy[lane];
                 if (j >= 0) {
-                    ns.node[lane] = os.node[j];
+                    new_node = os.node[j];
+                    ns.node[lane] = new_node;
                     ns.len[lane] = os.len[j];
                     ns.last[lane] = os.last[j];
                     ns.hist[lane] = os.hist[j];
 #pragma unroll
                     for (int c = 0; c < 4; c++) ns.child[c][lane] = os.child[c][j];
                 } else {
+                    new_node = my_node;
                     ns.node[lane] = my_node;
                     ns.len[lane] = os.len[my_par] + 1;
                     ns.last[lane] = my_c;
@@ -441,10 +548,12 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                     ns.child[2][lane] = ch.z;
                     ns.child[3][lane] = ch.w;
                 }
+                tabslot[new_node & (TN - 1)] = (unsigned char)lane;
             }
             nb = nb_new;
             cur ^= 1;
             wave_sync();
+            tab_ok = !__any(lane < nb_new && tabslot[new_node & (TN - 1)] != (unsigned char)lane);
         }
     }
 
