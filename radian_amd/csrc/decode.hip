@@ -150,13 +150,17 @@ __device__ __forceinline__ void wave_sync()
 // decode.py:16-17
 __device__ __forceinline__ double safe_log(double x) { return x == 0.0 ? -INFINITY : log(x); }
 
-template <int WM>
-struct BeamState {
-    double ptot[WM], pb[WM], pnb[WM];
-    int node[WM], len[WM], last[WM];
-    unsigned hist[WM];
-    int child[4][WM];
+// One kept labeling, 64 B in LDS: a candidate lane fetches its parent with three 16-B reads.
+struct __attribute__((aligned(16))) Beam {
+    double ptot, pb;        //  0: pr_total, pr_blank          (log)
+    double pnb;             // 16: pr_non_blank
+    int last, len;          // 24: last label (-1: empty labeling), labeling length
+    int node;               // 32: canonical trie id
+    unsigned hist;          // 36: last 16 labels, 2 bits each (LM context)
+    int pad0, pad1;
+    int child[4];           // 48: trie ids of the four children (0 = never created)
 };
+static_assert(sizeof(Beam) == 64, "Beam is one 64-B LDS record");
 
 template <int R>
 struct Cfg {
@@ -213,10 +217,10 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
     const int W = a.W;
     const unsigned ctx_mask = LM ? ((a.k >= 16) ? 0xffffffffu : ((1u << (2 * a.k)) - 1u)) : 0u;
 
-    __shared__ BeamState<WM> st[2];
-    __shared__ double cpy_pnb[WM], cpy_tot[WM], cpy_pb[WM], mb_v[WM], mP[WM], mQ[WM];
+    __shared__ Beam st[2][WM];
+    __shared__ double cpy_pnb[WM], cpy_pb[WM], mb_v[WM], mP[WM], mQ[WM];
     __shared__ int mb_q[WM];
-    __shared__ int d_copy[WM], d_par[WM], d_c[WM], rk_owner[WM];
+    __shared__ int d_copy[WM], d_par[WM], d_c[WM], rk_owner[WM], newslot[WM];
     __shared__ double lp[64][5];
     __shared__ double praw[LM ? 64 : 1][5];
     __shared__ double sent[LM ? 64 : 1];
@@ -225,14 +229,16 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
 
     // decode.py:128-132: the empty labeling with pr_blank = pr_total = log(1)
     if (lane == 0) {
-        st[0].ptot[0] = 0.0;
-        st[0].pb[0] = 0.0;
-        st[0].pnb[0] = -INFINITY;
-        st[0].node[0] = 0;
-        st[0].len[0] = 0;
-        st[0].last[0] = -1;
-        st[0].hist[0] = 0u;
-        for (int c = 0; c < 4; c++) st[0].child[c][0] = 0;
+        Beam& b = st[0][0];
+        b.ptot = 0.0;
+        b.pb = 0.0;
+        b.pnb = -INFINITY;
+        b.last = -1;
+        b.len = 0;
+        b.node = 0;
+        b.hist = 0u;
+        b.pad0 = b.pad1 = 0;
+        for (int c = 0; c < 4; c++) b.child[c] = 0;
         childtab[0] = make_int4(0, 0, 0, 0);
         backptr[0] = 0;
         tabslot[0] = 0;
@@ -240,7 +246,6 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
     int nb = 1;              // beams currently kept (wave-uniform)
     int next_id = 1;         // next free trie node id (wave-uniform)
     int cur = 0;
-    bool tab_ok = true;      // the node -> slot table resolves every kept beam (wave-uniform)
     wave_sync();
 
     for (int t0 = 0; t0 < T; t0 += 64) {
@@ -282,15 +287,19 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
 
         const int tend = (T - t0) < 64 ? (T - t0) : 64;
         for (int tt = 0; tt < tend; tt++) {
-            BeamState<WM>& os = st[cur];
-            BeamState<WM>& ns = st[cur ^ 1];
+            const Beam* __restrict__ os = st[cur];
+            Beam* __restrict__ ns = st[cur ^ 1];
             const int ncand = 5 * nb;
 
             // ---------------- Phase A: candidate scores; which extension equals which kept labeling? -------------
-            bool valid[R];
-            int bi[R], kk[R], pj[R], dcopy[R];
+            // Written without divergent branches: every lane issues the same LDS reads (clamped indices) and selects.
+            bool valid[R], is_copy[R];
+            int bi[R], kk[R], pj[R], dcopy[R], xch[R];
             double c_ptot[R], c_pnb[R], c_pb[R];
             const double lp_blank = lp[tt][4];
+            // the node -> slot table resolves every kept beam iff each beam finds itself in it
+            const int myn = st[cur][lane < nb ? lane : 0].node;
+            const bool tab_ok = !__any(lane < nb && tabslot[myn & (TN - 1)] != (unsigned char)lane);
 #pragma unroll
             for (int s = 0; s < R; s++) {
                 const int q = s * 64 + lane;
@@ -299,19 +308,21 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                 const int k = q - 5 * (q / 5);
                 bi[s] = i;
                 kk[s] = k;
-                pj[s] = -1;
-                dcopy[s] = -1;
-                const double ptot_i = os.ptot[i], pb_i = os.pb[i], pnb_i = os.pnb[i];
-                const int last_i = os.last[i];
-                const int len_i = os.len[i];
-                const int c = (k == 0) ? last_i : k - 1;  // label whose probability this candidate consumes
-                double lpc = (c >= 0) ? lp[tt][c] : -INFINITY;
+                is_copy[s] = k == 0;
+                const double2 pp = *(const double2*)&os[i].ptot;               // pr_total, pr_blank
+                const double pnb_i = os[i].pnb;
+                const int2 ll = *(const int2*)&os[i].last;                     // last, len
+                const int last_i = ll.x, len_i = ll.y;
+                const int chx = os[i].child[(k - 1) & 3];
+                const int c = is_copy[s] ? last_i : k - 1;  // label whose probability this candidate consumes
+                double lpc = lp[tt][c < 0 ? 0 : c];
+                lpc = c < 0 ? -INFINITY : lpc;
                 if constexpr (LM) {
                     // decode.py:157-163 (copy: context excludes the last label) and :180-184 (extend)
-                    const int need = (k == 0) ? a.k + 1 : a.k;
+                    const int need = is_copy[s] ? a.k + 1 : a.k;
                     if (valid[s] && c >= 0 && len_i >= need) {
-                        const unsigned h = os.hist[i];
-                        const unsigned ctx = ((k == 0) ? (h >> 2) : h) & ctx_mask;
+                        const unsigned h = os[i].hist;
+                        const unsigned ctx = (is_copy[s] ? (h >> 2) : h) & ctx_mask;
                         const bool gate = ((a.lm_gate[ctx >> 5] >> (ctx & 31)) & 1u) && (sent[tt] > a.s_thr);
                         if (gate) {
                             // combine_dists decode.py:52-64
@@ -332,37 +343,34 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                         }
                     }
                 }
-                if (k == 0) {
-                    // COPY decode.py:150-175
-                    const double pnb_c = (last_i >= 0) ? pnb_i + lpc : -INFINITY;
-                    const double pb_c = ptot_i + lp_blank;
-                    c_pnb[s] = pnb_c;
-                    c_pb[s] = pb_c;
-                    c_ptot[s] = 0.0;  // lae(pb_c, pnb_c) below
-                    dcopy[s] = i;
-                    if (valid[s]) {
-                        cpy_pnb[i] = pnb_c;
-                        cpy_pb[i] = pb_c;
-                        mb_q[i] = -1;
-                    }
-                } else {
-                    // EXTEND decode.py:186-201
-                    const double v = ((last_i == k - 1) ? pb_i : ptot_i) + lpc;
-                    c_pnb[s] = v;
-                    c_pb[s] = -INFINITY;
-                    c_ptot[s] = v;
-                    // the labeling "beam i + label" is already kept iff its trie id is some kept beam's id
-                    const int x = valid[s] ? os.child[k - 1][i] : 0;
-                    if (tab_ok) {
-                        int sl = tabslot[x & (TN - 1)];
-                        sl = sl < WM ? sl : WM - 1;
-                        if (x != 0 && sl < nb && os.node[sl] == x) pj[s] = sl;
-                    } else {
-                        int found = -1;
-                        for (int j = 0; j < nb; j++)
-                            if (os.node[j] == x) found = j;
-                        if (x != 0) pj[s] = found;
-                    }
+                // COPY decode.py:150-175 / EXTEND decode.py:186-201
+                const double pnb_c = (last_i >= 0) ? pnb_i + lpc : -INFINITY;
+                const double pb_c = pp.x + lp_blank;
+                const double v = ((last_i == k - 1) ? pp.y : pp.x) + lpc;
+                c_pnb[s] = is_copy[s] ? pnb_c : v;
+                c_pb[s] = is_copy[s] ? pb_c : -INFINITY;
+                c_ptot[s] = is_copy[s] ? 0.0 : v;            // copies: lae(pb_c, pnb_c) below
+                dcopy[s] = is_copy[s] ? i : -1;
+                if (valid[s] && is_copy[s]) {
+                    cpy_pnb[i] = pnb_c;
+                    cpy_pb[i] = pb_c;
+                    mb_q[i] = -1;
+                    newslot[i] = -1;
+                }
+                // the labeling "beam i + label" is already kept iff its trie id is some kept beam's id
+                const int x = (valid[s] && !is_copy[s]) ? chx : 0;
+                xch[s] = x;
+                int sl = tabslot[x & (TN - 1)];
+                sl = sl < WM ? sl : WM - 1;
+                const int nd = os[sl].node;
+                pj[s] = (tab_ok && x != 0 && sl < nb && nd == x) ? sl : -1;
+            }
+            if (!tab_ok) {   // two kept beams share a table entry (rare): compare against every beam
+                for (int j = 0; j < nb; j++) {
+                    const int nj = os[j].node;
+#pragma unroll
+                    for (int s = 0; s < R; s++)
+                        if (xch[s] != 0 && nj == xch[s]) pj[s] = j;
                 }
             }
             wave_sync();
@@ -373,13 +381,12 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
 #pragma unroll
             for (int s = 0; s < R; s++) {
                 const bool mext = pj[s] >= 0;
-                const double x = mext ? cpy_pnb[pj[s]] : c_pb[s];
+                const double cp = cpy_pnb[mext ? pj[s] : 0];
+                const double x = mext ? cp : c_pb[s];
                 const double y = mext ? c_ptot[s] : c_pnb[s];
                 const double r = lae(x, y);
-                if (kk[s] == 0) {
-                    c_ptot[s] = r;
-                    if (valid[s]) cpy_tot[bi[s]] = r;
-                } else if (mext) {
+                c_ptot[s] = is_copy[s] ? r : c_ptot[s];
+                if (mext) {
                     mb_q[pj[s]] = s * 64 + lane;
                     mb_v[pj[s]] = c_ptot[s];
                     mQ[pj[s]] = r;
@@ -391,8 +398,10 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                 // ---------- lae pass 2: pr_total of the merged entry = logaddexp(copy.total, v) (decode.py:200-201), by the copy's lane
 #pragma unroll
                 for (int s = 0; s < R; s++) {
-                    const bool m = valid[s] && kk[s] == 0 && mb_q[bi[s]] >= 0;
-                    const double r = lae(c_ptot[s], m ? mb_v[bi[s]] : -INFINITY);
+                    const int qe = mb_q[bi[s]];
+                    const double mv = mb_v[bi[s]];
+                    const bool m = valid[s] && is_copy[s] && qe >= 0;
+                    const double r = lae(c_ptot[s], m ? mv : -INFINITY);
                     if (m) mP[bi[s]] = r;
                 }
                 wave_sync();
@@ -400,22 +409,20 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
 #pragma unroll
                 for (int s = 0; s < R; s++) {
                     const int q = s * 64 + lane;
-                    if (valid[s]) {
-                        if (kk[s] == 0) {
-                            const int qe = mb_q[bi[s]];
-                            if (qe >= 0) {
-                                if (q < qe) { c_ptot[s] = mP[bi[s]]; c_pnb[s] = mQ[bi[s]]; }
-                                else valid[s] = false;
-                            }
-                        } else if (pj[s] >= 0) {
-                            const int qc = 5 * pj[s];
-                            if (q < qc) {
-                                c_ptot[s] = mP[pj[s]];
-                                c_pnb[s] = mQ[pj[s]];
-                                c_pb[s] = cpy_pb[pj[s]];
-                                dcopy[s] = pj[s];
-                            } else valid[s] = false;
+                    const int j = is_copy[s] ? bi[s] : (pj[s] >= 0 ? pj[s] : 0);      // the copy's beam
+                    const int qe = mb_q[j];
+                    const double P = mP[j], Q = mQ[j], cb = cpy_pb[j];
+                    const bool merged = valid[s] && (is_copy[s] ? qe >= 0 : pj[s] >= 0);
+                    const int qother = is_copy[s] ? qe : 5 * j;
+                    const bool keep = q < qother;
+                    if (merged) {
+                        c_ptot[s] = keep ? P : c_ptot[s];
+                        c_pnb[s] = keep ? Q : c_pnb[s];
+                        if (!is_copy[s]) {
+                            c_pb[s] = keep ? cb : c_pb[s];
+                            dcopy[s] = keep ? j : dcopy[s];
                         }
+                        valid[s] = keep;
                     }
                 }
             }
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
             double key[R];
             bool surv[R];
             int cidx[R];
-            const double tau = (nb == W) ? os.ptot[nb - 1] + lp_blank : -INFINITY;
+            const double tau = (nb == W) ? os[nb - 1].ptot + lp_blank : -INFINITY;
 #pragma unroll
             for (int s = 0; s < R; s++) {
                 key[s] = valid[s] ? c_ptot[s] : __builtin_nan("");
@@ -464,13 +471,13 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                 for (int s = 0; s < R; s++) {
                     if (surv[s] && rank[s] < W) {
                         const int r = rank[s];
-                        ns.ptot[r] = c_ptot[s];
-                        ns.pb[r] = c_pb[s];
-                        ns.pnb[r] = c_pnb[s];
+                        *(double2*)&ns[r].ptot = make_double2(c_ptot[s], c_pb[s]);
+                        ns[r].pnb = c_pnb[s];
                         d_copy[r] = dcopy[s];
                         d_par[r] = bi[s];
                         d_c[r] = kk[s] - 1;
                         rk_owner[r] = s * 64 + lane;
+                        if (dcopy[s] >= 0) newslot[dcopy[s]] = r;
                     }
                 }
             };
@@ -487,28 +494,33 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
 #pragma unroll
                     for (int s = 0; s < R; s++) rank[s] += ((kv > key[s]) || (kv == key[s] && j < cidx[s])) ? 1 : 0;
                 }
+                if (lane < nb) newslot[lane] = -1;      // the first attempt may have placed a labeling that is not kept after all
                 scatter();
                 wave_sync();
             }
 
-            // ---------------- Phase F: trie ids for the new beam set ------------------------------------------
-            int my_node = 0, my_par = 0, my_c = 0;
-            bool fresh = false, reload = false;
-            const bool is_new_ext = (lane < nb_new) && (d_copy[lane] < 0);
-            if (is_new_ext) {
-                my_par = d_par[lane];
-                my_c = d_c[lane];
-                my_node = os.child[my_c][my_par];
-                fresh = (my_node == 0);
-                reload = !fresh;
-            }
+            // ---------------- Phase F: the new beam set: trie ids, labeling state ------------------------------
+            // Lane r < nb_new builds beam r.  A copy takes its record from the old beam; an extension takes its parent's,
+            // appends its label and gets its canonical id: the parent's child id if that child was ever created (its own
+            // child ids then come back from the HBM trie), else a fresh id.  A fresh id is also patched into the parent's
+            // NEW record when the parent is kept (newslot), so that child ids stay canonical.
+            const bool act = lane < nb_new;
+            const int j = act ? d_copy[lane] : 0;
+            const int par = act ? d_par[lane] : 0;
+            const int cl = act ? d_c[lane] : 0;
+            const bool is_ext = act && j < 0;
+            const int src = is_ext ? par : j;
+            const int4 meta = *(const int4*)&os[src].node;       // node, hist, pad, pad
+            const int2 ll = *(const int2*)&os[src].last;         // last, len
+            const int4 chs = *(const int4*)&os[src].child[0];
+            const int nid_old = os[src].child[cl & 3];           // (extensions: cl = the appended label)
+            const bool fresh = is_ext && nid_old == 0;
+            const bool reload = is_ext && nid_old != 0;
             const unsigned long long fmask = __ballot(fresh);
+            const int my_node = fresh ? next_id + __popcll(fmask & ((1ull << lane) - 1ull)) : nid_old;
             if (fresh) {
-                my_node = next_id + __popcll(fmask & ((1ull << lane) - 1ull));
-                os.child[my_c][my_par] = my_node;  // keeps the parent's child ids canonical (copied in F2)
-                const int pnode = os.node[my_par];
-                backptr[my_node] = (pnode << 2) | my_c;
-                ((int*)&childtab[pnode])[my_c] = my_node;
+                backptr[my_node] = (meta.x << 2) | cl;
+                ((int*)&childtab[meta.x])[cl] = my_node;
                 childtab[my_node] = make_int4(0, 0, 0, 0);
             }
             next_id += __popcll(fmask);
@@ -525,44 +537,29 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                     ch.w = __hip_atomic_load(cp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            wave_sync();
-            int new_node = -1;
-            if (lane < nb_new) {
-                const int j = d_copy[lane];
-                if (j >= 0) {
-                    new_node = os.node[j];
-                    ns.node[lane] = new_node;
-                    ns.len[lane] = os.len[j];
-                    ns.last[lane] = os.last[j];
-                    ns.hist[lane] = os.hist[j];
-#pragma unroll
-                    for (int c = 0; c < 4; c++) ns.child[c][lane] = os.child[c][j];
-                } else {
-                    new_node = my_node;
-                    ns.node[lane] = my_node;
-                    ns.len[lane] = os.len[my_par] + 1;
-                    ns.last[lane] = my_c;
-                    ns.hist[lane] = (os.hist[my_par] << 2) | (unsigned)my_c;
-                    ns.child[0][lane] = ch.x;
-                    ns.child[1][lane] = ch.y;
-                    ns.child[2][lane] = ch.z;
-                    ns.child[3][lane] = ch.w;
-                }
+            if (act) {
+                const int new_node = is_ext ? my_node : meta.x;
+                *(int2*)&ns[lane].last = make_int2(is_ext ? cl : ll.x, is_ext ? ll.y + 1 : ll.y);
+                *(int4*)&ns[lane].node = make_int4(new_node, is_ext ? (int)(((unsigned)meta.y << 2) | (unsigned)cl) : meta.y, 0, 0);
+                *(int4*)&ns[lane].child[0] = make_int4(is_ext ? ch.x : chs.x, is_ext ? ch.y : chs.y, is_ext ? ch.z : chs.z, is_ext ? ch.w : chs.w);
                 tabslot[new_node & (TN - 1)] = (unsigned char)lane;
+            }
+            if (fresh) {   // (after the record writes above in program order: LDS operations of a wave execute in order)
+                const int ps = newslot[par];
+                if (ps >= 0) ns[ps].child[cl] = my_node;
             }
             nb = nb_new;
             cur ^= 1;
             wave_sync();
-            tab_ok = !__any(lane < nb_new && tabslot[new_node & (TN - 1)] != (unsigned char)lane);
         }
     }
 
     // ---------------- traceback of the best labeling (slot 0 = rank 0; decode.py:207-210) --------------------
     __builtin_amdgcn_s_waitcnt(0);
     if (lane == 0) {
-        const BeamState<WM>& fs = st[cur];
-        int n = fs.node[0];
-        const int len = fs.len[0];
+        const Beam& fs = st[cur][0];
+        int n = fs.node;
+        const int len = fs.len;
         uint8_t* out = a.labels + a.label_off[seq];
         for (int p = len - 1; p >= 0; p--) {
             const int bp = __hip_atomic_load(&backptr[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -570,7 +567,7 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
             n = bp >> 2;
         }
         a.label_len[seq] = len;
-        if (a.best_score) a.best_score[seq] = fs.ptot[0];
+        if (a.best_score) a.best_score[seq] = fs.ptot;
     }
 }
 
