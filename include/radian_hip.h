@@ -46,10 +46,17 @@ int rd_decode_max_width(void);        /* largest supported --beam-width (51) */
 int rd_create(int device_id, rd_ctx** out);
 int rd_destroy(rd_ctx* ctx);
 int rd_sync(rd_ctx* ctx);             /* wait for the context's stream */
-/* Matrix-product arithmetic of the forward: 0 (default) exact fp32 MFMA; 1 split-f16 "f16x3": every fp32 operand
- * carried as an f16 hi+lo pair (22 significant bits), products hi*hi + hi*lo + lo*hi accumulated in fp32 on the f16
- * matrix pipe -- same measured softmax error vs a float64 reference as mode 0. */
+/* Matrix-product arithmetic of the forward (sig_model.predict, radian/basecall.py:88-93; the reference computes in fp32):
+ *   0 (default) exact fp32 MFMA;
+ *   1 split-f16 "f16x3": every fp32 operand carried as an f16 hi+lo pair (22 significant bits), products
+ *     hi*hi + hi*lo + lo*hi accumulated in fp32 on the f16 matrix pipe;
+ *   2 three-term bf16 split "bf16x3": every fp32 operand carried EXACTLY as hi+mid+lo bf16 (3 x 8 significant bits,
+ *     fp32's exponent range), the six cross products down to 2^-16 relative accumulated in fp32 on the bf16 matrix pipe;
+ *     the dropped terms are below one fp32 rounding of the product. */
 int rd_set_precision(rd_ctx* ctx, int mode);
+/* Diagnostic of mode 2: split n fp32 values on the device exactly as the kernels do; terms_out[t * n + i] is the bf16 bit
+ * pattern of term t (0 hi, 1 mid, 2 lo) of values[i]. */
+int rd_split3(rd_ctx* ctx, const float* values, size_t n, uint16_t* terms_out);
 
 /* ---- model artefacts ----------------------------------------------------------------------- */
 /* Replaces model.load_weights(checkpoint) -- radian/model.py:42-45.

@@ -26,6 +26,7 @@ SIGNATURES = {
     "rd_destroy": (c_i, [c_vp]),
     "rd_sync": (c_i, [c_vp]),
     "rd_set_precision": (c_i, [c_vp, c_i]),
+    "rd_split3": (c_i, [c_vp, c_vp, c_sz, c_vp]),
     "rd_load_weights": (c_i, [c_vp, c_vp, c_sz]),
     "rd_load_lm": (c_i, [c_vp, c_vp, c_i]),
     "rd_forward": (c_i, [c_vp, c_vp, c_i, c_i, c_vp]),

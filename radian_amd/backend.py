@@ -59,9 +59,17 @@ class Backend:
         self._check(self._L.rd_sync(self._h))
 
     def set_precision(self, mode):
-        """'fp32' (default, exact fp32 MFMA) or 'f16x3' (split-f16 matrix products, fp32-equivalent accuracy)."""
-        code = {"fp32": 0, "f16x3": 1}[mode] if isinstance(mode, str) else int(mode)
+        """'fp32' (default, exact fp32 MFMA), 'f16x3' (split-f16 matrix products, 22-bit operands) or 'bf16x3' (three-term
+        bf16 split: every fp32 operand exact, six bf16 MFMAs per product)."""
+        code = {"fp32": 0, "f16x3": 1, "bf16x3": 2}[mode] if isinstance(mode, str) else int(mode)
         self._check(self._L.rd_set_precision(self._h, code))
+
+    def split3(self, values):
+        """Device-side three-term bf16 split of float32 values -> uint16 [3, n] bit patterns (hi, mid, lo)."""
+        v = np.ascontiguousarray(values, dtype=np.float32).ravel()
+        out = np.zeros((3, v.size), dtype=np.uint16)
+        self._check(self._L.rd_split3(self._h, _p(v), v.size, _p(out)))
+        return out
 
     @property
     def max_beam_width(self):

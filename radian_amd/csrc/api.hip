@@ -155,7 +155,7 @@ extern "C" int rd_destroy(rd_ctx* ctx)
 extern "C" int rd_set_precision(rd_ctx* ctx, int mode)
 {
     RD_REQUIRE(ctx, "rd_set_precision: null context");
-    RD_REQUIRE(mode == 0 || mode == 1, "rd_set_precision: mode %d (0 = fp32 MFMA, 1 = split-f16 f16x3)", mode);
+    RD_REQUIRE(mode >= 0 && mode <= 2, "rd_set_precision: mode %d (0 = fp32 MFMA, 1 = split-f16 f16x3, 2 = three-term bf16x3)", mode);
     ctx->precision = mode;
     return RD_OK;
 }
@@ -174,7 +174,7 @@ constexpr size_t D1_PK = (size_t)RD_C * RD_H;
 
 struct ModelLayout {
     size_t sink, w_in, b_in, w_match, b_match, w_conv[2 * RD_MAX_BLOCKS], b_conv[2 * RD_MAX_BLOCKS], w_d1, b_d1, w_d2, b_d2;
-    size_t ws_conv[2 * RD_MAX_BLOCKS], ws_d1, total;
+    size_t ws_conv[2 * RD_MAX_BLOCKS], ws_d1, w3_conv[2 * RD_MAX_BLOCKS], w3_d1, total;
 };
 
 ModelLayout model_layout(int nblocks)
@@ -203,6 +203,12 @@ ModelLayout model_layout(int nblocks)
             L.ws_conv[2 * b + w] = take(CONV_PK);   // split-f16 image: same byte size as the fp32 one
         }
     L.ws_d1 = take(D1_PK);
+    for (int b = 0; b < nblocks; b++)
+        for (int w = 0; w < 2; w++) {
+            if (b == 0 && w == 0) continue;
+            L.w3_conv[2 * b + w] = take(CONV_PK * 3 / 2);   // three bf16 per weight = 6 B
+        }
+    L.w3_d1 = take(D1_PK * 3 / 2);
     L.w_d1 = take(D1_PK);
     L.b_d1 = take(RD_H);
     L.w_d2 = take(RD_H * RD_NCLS);
@@ -225,8 +231,10 @@ void model_bind(Model& m, const ModelLayout& L)
             m.w_conv[2 * b + w] = base + L.w_conv[2 * b + w];
             m.b_conv[2 * b + w] = base + L.b_conv[2 * b + w];
             m.ws_conv[2 * b + w] = base + L.ws_conv[2 * b + w];
+            m.w3_conv[2 * b + w] = base + L.w3_conv[2 * b + w];
         }
     m.ws_d1 = base + L.ws_d1;
+    m.w3_d1 = base + L.w3_d1;
     m.w_d1 = base + L.w_d1;
     m.b_d1 = base + L.b_d1;
     m.w_d2 = base + L.w_d2;
@@ -305,6 +313,53 @@ float pack_dense_split(const float* k, _Float16* dst)
     return 1.f / sc;
 }
 
+// fp32 -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does); finite inputs
+inline uint16_t f2bf(float v)
+{
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf2f(uint16_t h)
+{
+    const uint32_t u = (uint32_t)h << 16;
+    float v;
+    memcpy(&v, &u, 4);
+    return v;
+}
+// one 96-B row of a 16-channel chunk: six 16-B slots (term * 2 + k / 8), physical slot = slot ^ ((row >> 3) & 1)
+inline void bf3_store(uint16_t* row, int k, int rowidx, float v)
+{
+    const uint16_t hi = f2bf(v);
+    const float r1 = v - bf2f(hi);
+    const uint16_t mid = f2bf(r1);
+    const uint16_t lo = f2bf(r1 - bf2f(mid));
+    const int sw = (rowidx >> 3) & 1, kh = k >> 3, kl = k & 7;
+    row[((0 + kh) ^ sw) * 8 + kl] = hi;
+    row[((2 + kh) ^ sw) * 8 + kl] = mid;
+    row[((4 + kh) ^ sw) * 8 + kl] = lo;
+}
+// Keras conv kernel [j][ci][co] -> bf16x3 image [chunk = (ci/16)*3 + j][co][6 slots x 8]
+void pack_conv_bf3(const float* k, uint16_t* dst)
+{
+    for (int j = 0; j < RD_K; j++)
+        for (int ci = 0; ci < RD_C; ci++) {
+            const float* src = k + ((size_t)j * RD_C + ci) * RD_C;
+            const int chunk = (ci / 16) * RD_K + j;
+            uint16_t* d = dst + (size_t)chunk * RD_C * 48;
+            for (int co = 0; co < RD_C; co++) bf3_store(d + (size_t)co * 48, ci % 16, co, src[co]);
+        }
+}
+void pack_dense_bf3(const float* k, uint16_t* dst)
+{
+    for (int ci = 0; ci < RD_C; ci++) {
+        const float* src = k + (size_t)ci * RD_H;
+        uint16_t* d = dst + (size_t)(ci / 16) * RD_H * 48;
+        for (int h = 0; h < RD_H; h++) bf3_store(d + (size_t)h * 48, ci % 16, h, src[h]);
+    }
+}
+
 }  // namespace
 
 extern "C" int rd_load_weights(rd_ctx* ctx, const void* blob, size_t nbytes)
@@ -346,12 +401,14 @@ extern "C" int rd_load_weights(rd_ctx* ctx, const void* blob, size_t nbytes)
         } else {
             pack_conv(w + off, &host[L.w_conv[2 * b]]);
             m.inv_scale[2 * b] = pack_conv_split(w + off, (_Float16*)&host[L.ws_conv[2 * b]]);
+            pack_conv_bf3(w + off, (uint16_t*)&host[L.w3_conv[2 * b]]);
             off += CONV_PK;
             memcpy(&host[L.b_conv[2 * b]], w + off, sizeof(float) * RD_C);
             off += RD_C;
         }
         pack_conv(w + off, &host[L.w_conv[2 * b + 1]]);
         m.inv_scale[2 * b + 1] = pack_conv_split(w + off, (_Float16*)&host[L.ws_conv[2 * b + 1]]);
+        pack_conv_bf3(w + off, (uint16_t*)&host[L.w3_conv[2 * b + 1]]);
         off += CONV_PK;
         memcpy(&host[L.b_conv[2 * b + 1]], w + off, sizeof(float) * RD_C);
         off += RD_C;
@@ -364,6 +421,7 @@ extern "C" int rd_load_weights(rd_ctx* ctx, const void* blob, size_t nbytes)
     }
     pack_dense(w + off, &host[L.w_d1]);
     m.inv_scale_d1 = pack_dense_split(w + off, (_Float16*)&host[L.ws_d1]);
+    pack_dense_bf3(w + off, (uint16_t*)&host[L.w3_d1]);
     off += D1_PK;
     memcpy(&host[L.b_d1], w + off, sizeof(float) * RD_H);
     off += RD_H;
@@ -1552,6 +1610,20 @@ extern "C" int rd_memcpy_d2h(rd_ctx* ctx, void* dst, const void* d_src, size_t b
 {
     RD_REQUIRE(ctx && dst && d_src, "rd_memcpy_d2h: null argument");
     RD_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    return RD_OK;
+}
+
+extern "C" int rd_split3(rd_ctx* ctx, const float* values, size_t n, uint16_t* terms_out)
+{
+    RD_REQUIRE(ctx && values && terms_out, "rd_split3: null argument");
+    RD_HIP(hipSetDevice(ctx->device));
+    if (n == 0) return RD_OK;
+    if (ctx->ws_in.reserve(n * 4) || ctx->ws_misc.reserve(n * 6)) return RD_ERR_NOMEM;
+    RD_HIP(hipMemcpyAsync(ctx->ws_in.p, values, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = rd_split3_dev(ctx, ctx->ws_in.as<float>(), n, ctx->ws_misc.as<uint16_t>());
+    if (rc) return rc;
+    RD_HIP(hipMemcpyAsync(terms_out, ctx->ws_misc.p, n * 6, hipMemcpyDeviceToHost, ctx->stream));
     RD_HIP(hipStreamSynchronize(ctx->stream));
     return RD_OK;
 }

@@ -67,6 +67,9 @@ struct Model {
     float inv_scale[2 * RD_MAX_BLOCKS] = {0};
     void* ws_d1 = nullptr;
     float inv_scale_d1 = 0.f;
+    // three-term bf16 images (forward.hip, bf16x3 section): [chunk][co][6 slots x 8 bf16], slots swizzled, unscaled
+    void* w3_conv[2 * RD_MAX_BLOCKS] = {nullptr};
+    void* w3_d1 = nullptr;
     float* w_d2 = nullptr;      // [128][5] (Keras layout)
     float* b_d2 = nullptr;      // [5]
     DevBuf storage;
@@ -130,7 +133,7 @@ struct FwdLane {
 
 struct rd_ctx {
     int device = 0;
-    int precision = 0;   // 0: exact fp32 MFMA (default); 1: split-f16 (f16x3) matrix products
+    int precision = 0;   // 0: exact fp32 MFMA (default); 1: split-f16 (f16x3); 2: three-term bf16 split (bf16x3) matrix products
     hipStream_t stream = nullptr;
     Model model;
     LM lm;
@@ -153,6 +156,7 @@ int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_
 int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tiles, int64_t total_rows, float* d_probs, int lane = 0);
 int rd_lane_get(rd_ctx* ctx, int lane, FwdLane** out);   // creates the lane's stream on first use
 int rd_sync_lanes(rd_ctx* ctx);                          // every forward stream idle
+int rd_split3_dev(rd_ctx* ctx, const float* d_in, size_t n, uint16_t* d_out);   // fp32 -> [3][n] bf16 bit patterns (hi, mid, lo)
 int rd_model_halo(const rd_ctx* ctx);  // receptive field - 1 = (K-1) * 2 * sum(dilations)
 // decode.hip
 int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* d_seq_off, const int32_t* d_seq_len,

@@ -772,6 +772,401 @@ __global__ __launch_bounds__(256) void tcn_in_split_kernel(const float* __restri
     }
 }
 
+// =====================================================================================================================
+// Three-term bf16 split ("bf16x3"): the fp32 contraction on the bf16 matrix pipe with EVERY operand bit kept.
+//
+// v = hi + mid + lo with hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid), round-to-nearest: three 8-bit
+// significands with fp32's exponent range, so the three terms reconstruct every finite fp32 value exactly (as long as lo
+// is not below bf16's smallest subnormal: |v| >= 2^-110; below that the defect is < 2^-133 absolute).  A product a*b is
+// evaluated as the six cross terms of order 2^0, 2^-8 and 2^-16
+//      ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh)
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the dropped terms (am*bl + al*bm + al*bl) are < 2^-23 |a*b|, the
+// size of ONE fp32 rounding of the product.  Six MFMAs at 16x the fp32-MFMA rate: peak 2516 / 6 = 419 TFLOP/s-equivalent.
+//
+// Activation rows are 16 groups of 16 channels, each group 96 B = [16 hi | 16 mid | 16 lo]: a K-chunk (16 channels, one
+// MFMA k-step) of a row is one contiguous 96-B run in HBM and six 16-B slots (term * 2 + k-half) of a 96-B LDS row.  The
+// slots of LDS row r sit at physical slot s ^ ((r >> 3) & 1): rows r and r + 8, whose 96-B stride puts the same slot on
+// the same banks, swap neighbours, which makes every ds_read_b128 group (16 lanes, 16 distinct r mod 16) conflict-free.
+// Two 36-KiB stages (A 128 x 96 B + B 256 x 96 B), two workgroups per CU; chunk c+1 is copied by LDS-DMA (pieces issued
+// between the MFMA steps) while chunk c is multiplied.
+// =====================================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int ROW3 = 3 * RD_C;   // bf16 elements per activation row (768 = 1536 B)
+
+// fp32 -> (hi, mid, lo); exact: hi + mid + lo == v
+__device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo)
+{
+    hi = (__bf16)v;
+    const float r1 = v - (float)hi;
+    mid = (__bf16)r1;
+    lo = (__bf16)(r1 - (float)mid);
+}
+
+struct Bf3Args {
+    const __bf16* in;
+    __bf16* out;
+    const __bf16* wpk;     // [chunk][BN][6 slots x 8], slots pre-swizzled: the exact LDS image
+    const float* bias;
+    const __bf16* resid;
+    const float* x;
+    const float* wmatch;
+    const float* bmatch;
+    const float* w2;
+    const float* b2;
+    float* probs;
+    int zero_row;
+    float* sink;
+    const TileDesc* tiles;
+    int dil;
+};
+
+template <int NT, int TAPS, int EPI>
+__global__ __launch_bounds__(256, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
+{
+    constexpr int BN = 2 * NT * 32;
+    constexpr int NCHUNK = TAPS * (RD_C / 16);
+    constexpr int RB = 96;                                   // bytes per LDS row (16 channels x 3 terms x 2 B)
+    constexpr int STAGE_BYTES = (BM + BN) * RB;              // 36 KiB (conv) / 24 KiB (head)
+    constexpr int HEAD_FLOATS = BM * (RD_H + 1) + RD_H * 5 + 8;
+    constexpr int EPI_FLOATS = 4 * 32 * 68;
+    constexpr int STG_FLOATS = 2 * STAGE_BYTES / 4;
+    constexpr int SMEM_FLOATS = (EPI == EPI_HEAD && HEAD_FLOATS > STG_FLOATS) ? HEAD_FLOATS : (STG_FLOATS > EPI_FLOATS ? STG_FLOATS : EPI_FLOATS);
+
+    __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1;
+    const int wn = wave & 1;
+    const TileDesc* __restrict__ tds = a.tiles + (size_t)blockIdx.x * 4;   // four 32-row sub-tiles (see the fp32 kernel)
+    const TileDesc sdm[2] = {tds[wm * 2], tds[wm * 2 + 1]};
+    const bool mval[2] = {sdm[0].seg_len > sdm[0].t0, sdm[1].seg_len > sdm[1].t0};
+
+    // ---- DMA roles.  Wave w stages sub-tile w: 32 rows x 6 slots = 192 slots = 3 wave-instructions; slot g = 64 p + lane
+    // of the sub-tile is (row g / 6, physical slot g % 6).  B: the wave's BN / 4 rows are a linear copy of the packed weights.
+    const TileDesc sst = tds[wave];
+    const int64_t d_seg = sst.seg_row, d_alt = sst.alt_row;
+    const int d_t0 = sst.t0, d_ain = sst.alt_in;
+    const int d_len = sst.seg_len > sst.t0 ? sst.in_len : 0;
+    int arow[TAPS][3];        // source row of this lane's slot, per tap and piece
+    int aoff[3];              // byte offset of the slot inside the row's 96-B chunk
+#pragma unroll
+    for (int pc = 0; pc < 3; pc++) {
+        const int g = pc * 64 + lane;
+        const int r = g / 6, ps = g - 6 * r;
+        aoff[pc] = (ps ^ ((r >> 3) & 1)) * 16;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; tap++) {
+            const int t = d_t0 + r - (TAPS - 1 - tap) * a.dil;
+            arow[tap][pc] = (t >= 0 && t < d_len) ? (int)((t < d_ain ? d_seg : d_alt) + t) : a.zero_row;
+        }
+    }
+    const char* inb = (const char*)a.in;
+    const unsigned lane_off = lane * 16;
+
+    constexpr int PB = BN * 6 / 64 / 4;     // B pieces per wave per chunk: 6 (conv) / 3 (head)
+    constexpr int NPIECE = 3 + PB;
+    auto stage_piece = [&](int chunk, int tap, char* st, int pc) {
+        if (pc < 3) {
+            const int cc = chunk / TAPS;
+            const char* src = inb + (uint64_t)(unsigned)arow[tap][pc] * (ROW3 * 2) + cc * RB + aoff[pc];
+            glds16_uncounted((const float*)src, (float*)(st + (wave * 3 + pc) * 1024));
+        } else {
+            const int q = pc - 3;
+            const char* wb = (const char*)a.wpk + (size_t)chunk * BN * RB + (size_t)wave * PB * 1024 + (q >= 4 ? 4096 : 0);
+            float* dst = (float*)(st + BM * RB + wave * PB * 1024 + (q >= 4 ? 4096 : 0));
+            const int qq = q & 3;
+            if (qq == 0) glds16_uncounted_saddr<0>(lane_off, wb, dst);
+            else if (qq == 1) glds16_uncounted_saddr<1024>(lane_off, wb, dst);
+            else if (qq == 2) glds16_uncounted_saddr<2048>(lane_off, wb, dst);
+            else glds16_uncounted_saddr<3072>(lane_off, wb, dst);
+        }
+    };
+
+    const int fr = lane & 31;
+    const int fh = lane >> 5;
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+        const float bias = a.bias[wn * NT * 32 + n * 32 + fr];
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[m][n][e] = bias;
+    }
+
+    // fragment addresses: row (.. + fr), term t -> logical slot 2 t + fh -> physical slot ^ ((row >> 3) & 1)
+    const int sw = (fr >> 3) & 1;
+    int toff[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) toff[t] = ((2 * t + fh) ^ sw) * 16;
+    const int a_off = (wm * 64 + fr) * RB;
+    const int b_off = BM * RB + (wn * NT * 32 + fr) * RB;
+
+    const bool work = mval[0] || mval[1];
+    auto chunk_step = [&](const char* st, int next, int next_tap, char* nst) {
+        const char* Ab = st + a_off;
+        const char* Bb = st + b_off;
+        bf16x8 af[2][3], bf[2][3];
+        const bool st_ok = next < NCHUNK;
+        if (work) {
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int t = 0; t < 3; t++) af[m][t] = *(const bf16x8*)(Ab + m * 32 * RB + toff[t]);
+#pragma unroll
+            for (int t = 0; t < 3; t++) bf[0][t] = *(const bf16x8*)(Bb + toff[t]);
+        }
+        constexpr int PPS = (NPIECE + NT - 1) / NT;   // DMA pieces issued after each N step
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            if (work) {
+                if (n + 1 < NT) {
+#pragma unroll
+                    for (int t = 0; t < 3; t++) bf[(n + 1) & 1][t] = *(const bf16x8*)(Bb + (n + 1) * 32 * RB + toff[t]);
+                }
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    // smallest terms first: 2^-16 order, 2^-8 order, then hi*hi
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][2], bf[n & 1][0], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[n & 1][2], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][1], bf[n & 1][1], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][1], bf[n & 1][0], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[n & 1][1], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[n & 1][0], acc[m][n], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < PPS; q++)
+                if (st_ok && n * PPS + q < NPIECE) stage_piece(next, next_tap, nst, n * PPS + q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    char* st0 = (char*)smem;
+    char* st1 = (char*)smem + STAGE_BYTES;
+    static_assert(TAPS == 3 || TAPS == 1, "tap of a chunk is a literal in the unrolled loop");
+    constexpr bool T3 = TAPS == 3;
+#pragma unroll
+    for (int pc = 0; pc < NPIECE; pc++) stage_piece(0, 0, st0, pc);
+    // Two stages: at the top of chunk c its pieces (issued during chunk c-1) must have landed -- vmcnt(0) -- and every
+    // wave must be past its reads of chunk c-1, whose stage chunk c+1 is about to overwrite -- the barrier.
+    // chunk -> tap is chunk % 3: the loop advances by 6 chunks so that taps and stages are literals.
+    static_assert(NCHUNK % 2 == 0, "two-stage loop");
+    auto step = [&](int c, const char* st, int tap1, char* nst) {
+        wait_dma_and_barrier<0>();
+        chunk_step(st, c + 1, tap1, nst);
+    };
+    if constexpr (T3) {
+        for (int chunk = 0; chunk < NCHUNK; chunk += 6) {
+            step(chunk, st0, 1, st1);
+            step(chunk + 1, st1, 2, st0);
+            step(chunk + 2, st0, 0, st1);
+            step(chunk + 3, st1, 1, st0);
+            step(chunk + 4, st0, 2, st1);
+            step(chunk + 5, st1, 0, st0);
+        }
+    } else {
+        for (int chunk = 0; chunk < NCHUNK; chunk += 2) {
+            step(chunk, st0, 0, st1);
+            step(chunk + 1, st1, 0, st0);
+        }
+    }
+    __syncthreads();
+
+    if constexpr (EPI != EPI_HEAD) {
+        constexpr int TSTR = 68;
+        float* ts = smem + wave * (32 * TSTR);
+        bf16x4* sinkh = (bf16x4*)a.sink + threadIdx.x;   // past-the-end rows store here (nobody reads it)
+        const int rrow = lane >> 4;
+        const int c4 = (lane & 15) * 4;
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            if (!mval[m]) continue;
+            const TileDesc sd = sdm[m];
+            const int T = sd.seg_len;
+            __bf16* __restrict__ outw = a.out + (size_t)sd.seg_row * ROW3;
+            const __bf16* __restrict__ resw = a.resid + (size_t)sd.seg_row * ROW3;
+            const __bf16* __restrict__ resalt = a.resid + (size_t)sd.alt_row * ROW3;
+            const bool interior = sd.t0 + 32 <= T;
+#pragma unroll
+            for (int np = 0; np < NT / 2; np++) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int n = 2 * np + j;
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int rl = (e & 3) + 8 * (e >> 2) + 4 * fh;
+                        const float v = acc[m][n][e];
+                        ts[rl * TSTR + j * 32 + fr] = v > 0.f ? v : 0.f;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int ch = wn * NT * 32 + np * 64 + c4;                // first of this lane's 4 channels
+                const int hoff = (ch >> 4) * 48 + (ch & 15);               // element offset of their hi terms in a row
+                float4 wm4 = make_float4(0.f, 0.f, 0.f, 0.f), bm4 = wm4;
+                if constexpr (EPI == EPI_RES_MATCH) {
+                    wm4 = *(const float4*)(a.wmatch + ch);
+                    bm4 = *(const float4*)(a.bmatch + ch);
+                }
+                bf16x4 r3[8][3];
+                int tt[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int t = sd.t0 + i * 4 + rrow;
+                    tt[i] = t;
+                    if constexpr (EPI == EPI_RES_IDENT) {
+                        const int tc = (interior || t < T) ? t : T - 1;
+                        const __bf16* rb = (tc < sd.alt_res ? resw : resalt) + (size_t)tc * ROW3 + hoff;
+#pragma unroll
+                        for (int q = 0; q < 3; q++) r3[i][q] = *(const bf16x4*)(rb + 16 * q);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float4 p = *(const float4*)(ts + (i * 4 + rrow) * TSTR + c4);
+                    float v[4] = {p.x, p.y, p.z, p.w};
+                    const int t = tt[i];
+                    const bool inb = interior || t < T;
+                    if constexpr (EPI == EPI_RES_IDENT) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            // hi + mid + lo is exact in fp32 in this order (each partial sum is a prefix of the 24 bits)
+                            v[q] += ((float)r3[i][0][q] + (float)r3[i][1][q]) + (float)r3[i][2][q];
+                            v[q] = v[q] > 0.f ? v[q] : 0.f;
+                        }
+                    } else if constexpr (EPI == EPI_RES_MATCH) {
+                        const float xv = a.x[(size_t)sd.src_row + (inb ? t : T - 1)];
+                        const float wq[4] = {wm4.x, wm4.y, wm4.z, wm4.w}, bq[4] = {bm4.x, bm4.y, bm4.z, bm4.w};
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            v[q] = (bq[q] + xv * wq[q]) + v[q];
+                            v[q] = v[q] > 0.f ? v[q] : 0.f;
+                        }
+                    }
+                    bf16x4 o3[3];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        __bf16 h, md, l;
+                        split3(v[q], h, md, l);
+                        o3[0][q] = h;
+                        o3[1][q] = md;
+                        o3[2][q] = l;
+                    }
+                    __bf16* ob = outw + (size_t)t * ROW3 + hoff;
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        bf16x4* d = inb ? (bf16x4*)(ob + 16 * q) : sinkh;
+                        *d = o3[q];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    } else {
+        constexpr int LDH = RD_H + 1;
+        float* hs = smem;
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            const int hcol = wn * NT * 32 + n * 32 + fr;
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int row = wm * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    const float v = acc[m][n][e];
+                    hs[row * LDH + hcol] = v > 0.f ? v : 0.f;
+                }
+        }
+        float* w2s = smem + BM * LDH;
+        for (int i = tid; i < RD_H * 5; i += 256) w2s[i] = a.w2[i];
+        if (tid < 5) w2s[RD_H * 5 + tid] = a.b2[tid];
+        __syncthreads();
+        if (tid < BM) {
+            const TileDesc sd = tds[tid >> 5];
+            const int t = sd.t0 + (tid & 31);
+            const int64_t seg_row = sd.seg_row;
+            if (t < sd.seg_len) {
+                float lg[5];
+#pragma unroll
+                for (int o = 0; o < 5; o++) lg[o] = w2s[RD_H * 5 + o];
+                for (int j = 0; j < RD_H; j++) {
+                    const float h = hs[tid * LDH + j];
+#pragma unroll
+                    for (int o = 0; o < 5; o++) lg[o] += h * w2s[j * 5 + o];
+                }
+                float mx = lg[0];
+#pragma unroll
+                for (int o = 1; o < 5; o++) mx = lg[o] > mx ? lg[o] : mx;
+                float e[5], s = 0.f;
+#pragma unroll
+                for (int o = 0; o < 5; o++) {
+                    e[o] = expf(lg[o] - mx);
+                    s += e[o];
+                }
+                float* pr = a.probs + ((size_t)seg_row + t) * 5;
+#pragma unroll
+                for (int o = 0; o < 5; o++) pr[o] = e[o] / s;
+            }
+        }
+    }
+}
+
+// Block 0, first conv (C_in = 1) writing three-term bf16 rows.
+__global__ __launch_bounds__(256) void tcn_in_bf3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                          __bf16* __restrict__ out, const TileDesc* __restrict__ tiles, int dil)
+{
+    const TileDesc td = tiles[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];   // wave w owns sub-tile w
+    const int c4 = (threadIdx.x & 63) * 4;
+    const float4 w0 = *(const float4*)(w + c4), w1 = *(const float4*)(w + 256 + c4), w2 = *(const float4*)(w + 512 + c4);
+    const float4 bb = *(const float4*)(b + c4);
+    const float* xw = x + td.src_row;
+    __bf16* ow = out + (size_t)td.seg_row * ROW3;
+    const int hoff = (c4 >> 4) * 48 + (c4 & 15);
+    const int tend = td.t0 + 32 < td.seg_len ? td.t0 + 32 : td.seg_len;
+    for (int t = td.t0; t < tend; t++) {
+        const float x2 = xw[t];
+        const float x1 = t - dil >= 0 ? xw[t - dil] : 0.f;
+        const float x0 = t - 2 * dil >= 0 ? xw[t - 2 * dil] : 0.f;
+        float v[4];
+        v[0] = bb.x + x0 * w0.x + x1 * w1.x + x2 * w2.x;
+        v[1] = bb.y + x0 * w0.y + x1 * w1.y + x2 * w2.y;
+        v[2] = bb.z + x0 * w0.z + x1 * w1.z + x2 * w2.z;
+        v[3] = bb.w + x0 * w0.w + x1 * w1.w + x2 * w2.w;
+        bf16x4 o3[3];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float r = v[q] > 0.f ? v[q] : 0.f;
+            __bf16 h, md, l;
+            split3(r, h, md, l);
+            o3[0][q] = h;
+            o3[1][q] = md;
+            o3[2][q] = l;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) *(bf16x4*)(ow + (size_t)t * ROW3 + hoff + 16 * q) = o3[q];
+    }
+}
+
+// test hook: split an fp32 array on the device, [n] -> [3][n] bf16 bit patterns
+__global__ void split3_kernel(const float* __restrict__ v, uint16_t* __restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    __bf16 h, m, l;
+    split3(v[i], h, m, l);
+    out[i] = *(const uint16_t*)&h;
+    out[n + i] = *(const uint16_t*)&m;
+    out[2 * n + i] = *(const uint16_t*)&l;
+}
+
 int timer_begin(hipStream_t st, KernelTimer& tm)
 {
     if (tm.enabled && tm.used < tm.starts.size()) RD_HIP(hipEventRecord(tm.starts[tm.used], st));
@@ -803,7 +1198,53 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
     if (n <= 0) return RD_OK;
     Model& m = ctx->model;
     const bool split = ctx->precision == 1;
+    const bool bf3 = ctx->precision == 2;
     int rc;
+    if (bf3) {
+        Bf3Args h = {};
+        h.zero_row = zero_row;
+        h.sink = m.sink;
+        h.tiles = tiles;
+        if (kind == 0) {
+            if ((rc = timer_begin(st, ctx->timer_in))) return rc;
+            hipLaunchKernelGGL(tcn_in_bf3_kernel, dim3(n), dim3(256), 0, st, d_signal, m.w_in, m.b_in, (__bf16*)MID, tiles, m.dil[0]);
+            RD_HIP(hipGetLastError());
+            return timer_end(st, ctx->timer_in, 2.0 * rows * RD_C * RD_K, rows * (RD_C * 6.0 + 4.0));
+        }
+        if (kind == 3) {
+            if ((rc = timer_begin(st, ctx->timer_head))) return rc;
+            h.in = (const __bf16*)Xin;
+            h.wpk = (const __bf16*)m.w3_d1;
+            h.bias = m.b_d1;
+            h.w2 = m.w_d2;
+            h.b2 = m.b_d2;
+            h.probs = d_probs;
+            hipLaunchKernelGGL((tcn_gemm_bf3_kernel<2, 1, EPI_HEAD>), dim3(n), dim3(256), 0, st, h);
+            RD_HIP(hipGetLastError());
+            return timer_end(st, ctx->timer_head, 2.0 * rows * (RD_C * RD_H + RD_H * 5), rows * (RD_C * 6.0 + 20.0));
+        }
+        const int wi = 2 * b + (kind == 2 ? 1 : 0);
+        h.dil = m.dil[b];
+        h.wpk = (const __bf16*)m.w3_conv[wi];
+        h.bias = m.b_conv[wi];
+        if (kind == 1) {
+            h.in = (const __bf16*)Xin;
+            h.out = (__bf16*)MID;
+        } else {
+            h.in = (const __bf16*)MID;
+            h.out = (__bf16*)Xout;
+            h.resid = (const __bf16*)Xin;
+            h.x = d_signal;
+            h.wmatch = m.w_match;
+            h.bmatch = m.b_match;
+        }
+        if ((rc = timer_begin(st, ctx->timer_conv))) return rc;
+        if (kind == 1) hipLaunchKernelGGL((tcn_gemm_bf3_kernel<4, 3, EPI_RELU>), dim3(n), dim3(256), 0, st, h);
+        else if (b == 0) hipLaunchKernelGGL((tcn_gemm_bf3_kernel<4, 3, EPI_RES_MATCH>), dim3(n), dim3(256), 0, st, h);
+        else hipLaunchKernelGGL((tcn_gemm_bf3_kernel<4, 3, EPI_RES_IDENT>), dim3(n), dim3(256), 0, st, h);
+        RD_HIP(hipGetLastError());
+        return timer_end(st, ctx->timer_conv, 2.0 * rows * RD_C * RD_C * RD_K, (kind == 2 && b > 0 ? 3.0 : 2.0) * rows * RD_C * 6.0);
+    }
     if (kind == 0) {
         if ((rc = timer_begin(st, ctx->timer_in))) return rc;
         if (split)
@@ -896,6 +1337,14 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
 
 }  // namespace
 
+int rd_split3_dev(rd_ctx* ctx, const float* d_in, size_t n, uint16_t* d_out)
+{
+    if (n == 0) return RD_OK;
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, d_out, n);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
 int rd_lane_get(rd_ctx* ctx, int lane, FwdLane** out)
 {
     if (lane < 0 || lane >= RD_MAX_LANES) {
@@ -936,16 +1385,16 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl
         return RD_ERR_ARG;
     }
     // each activation tensor carries one extra row of zeros behind its last row: the source of the causal left padding
-    const size_t row_bytes = (size_t)RD_C * sizeof(float);
+    const size_t row_bytes = (size_t)RD_C * (ctx->precision == 2 ? 6 : 4);   // bf16x3 rows carry three bf16 per channel
     const size_t act_bytes = (size_t)(total_rows + 1) * row_bytes;
     if (L->act[0].reserve(act_bytes) || L->act[1].reserve(act_bytes) || L->act[2].reserve(act_bytes)) return RD_ERR_NOMEM;
     float* Xin = L->act[0].as<float>();
     float* Xout = L->act[1].as<float>();
     float* MID = L->act[2].as<float>();
     const int zero_row = (int)total_rows;
-    RD_HIP(hipMemsetAsync(Xin + (size_t)zero_row * RD_C, 0, row_bytes, L->st));
-    RD_HIP(hipMemsetAsync(Xout + (size_t)zero_row * RD_C, 0, row_bytes, L->st));
-    RD_HIP(hipMemsetAsync(MID + (size_t)zero_row * RD_C, 0, row_bytes, L->st));
+    RD_HIP(hipMemsetAsync((char*)Xin + (size_t)zero_row * row_bytes, 0, row_bytes, L->st));
+    RD_HIP(hipMemsetAsync((char*)Xout + (size_t)zero_row * row_bytes, 0, row_bytes, L->st));
+    RD_HIP(hipMemsetAsync((char*)MID + (size_t)zero_row * row_bytes, 0, row_bytes, L->st));
     const int nl = 2 * m.nblocks + 1;
     for (int li = 0; li < nl; li++) {
         const int b = li == nl - 1 ? m.nblocks : li / 2;

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Workload of tools/prof_decode.sh: a few beam-search launches over n windows x 1024 rows (bench weights or the soft head)."""
+import os, sys
+import numpy as np
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, R)
+from radian_amd import Backend, weights, synthetic
+
+n, W, soft = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+T = 1024
+be = Backend(0)
+w = weights.synthetic_weights(seed=1234).copy()
+if soft:
+    w[-645:-5] *= np.float32(0.05)
+be.load_weights(w)
+reads = synthetic.synthetic_reads(n // 8, 4096, seed=5)
+win, valid = synthetic.reads_to_windows(reads, T, 512)[:2]
+win = np.ascontiguousarray(win, dtype=np.float32)
+d_w = be.dev_alloc(win.nbytes)
+be.h2d(d_w, win)
+d_p = be.dev_alloc(n * T * 5 * 4)
+be.forward_resident(d_w, n, T, d_p)
+valid = np.ascontiguousarray(valid, dtype=np.int32)
+labels = np.zeros((n, T), np.uint8)
+lens = np.zeros(n, np.int32)
+for _ in range(3):
+    be.decode_resident(d_p, n, T, valid, W, labels, lens)
+print(f"n={n} W={W} soft={soft} timesteps_per_launch={int(valid.sum())} mean_len={lens.mean():.1f}")
+be.close()
