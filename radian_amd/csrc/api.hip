@@ -331,7 +331,12 @@ inline float bf2f(uint16_t h)
 // one 96-B row of a 16-channel chunk: six 16-B slots (term * 2 + k / 8), physical slot = slot ^ ((row >> 3) & 1)
 inline void bf3_store(uint16_t* row, int k, int rowidx, float v)
 {
-    const uint16_t hi = f2bf(v);
+    uint16_t hi = f2bf(v);
+    if ((hi & 0x7fffu) == 0x7f80u && std::isfinite(v)) {   // rounded up to infinity: truncate (as split3 on the device)
+        uint32_t u;
+        memcpy(&u, &v, 4);
+        hi = (uint16_t)(u >> 16);
+    }
     const float r1 = v - bf2f(hi);
     const uint16_t mid = f2bf(r1);
     const uint16_t lo = f2bf(r1 - bf2f(mid));
@@ -1283,8 +1288,8 @@ int get_plan(rd_ctx* ctx, const int64_t* read_off, int n_reads, int chunk, int s
                            : plan_reads_global(ctx->model, read_off, n_reads, chunk, step, halo, pc->plan, &pc->streamed);
         if (rc) return rc;
         ReadsPlan& P = pc->plan;
-        auto pad4 = [](std::vector<TileDesc>& v) {          // pad the last workgroup tile with empty sub-tiles
-            while (v.size() % 4) {
+        auto pad4 = [](std::vector<TileDesc>& v) {          // pad the last workgroup tile with empty sub-tiles (to eight: the bf16x3 kernel's tile)
+            while (v.size() % 8) {
                 TileDesc e = {};
                 e.alt_in = e.alt_res = INT32_MAX;
                 v.push_back(e);

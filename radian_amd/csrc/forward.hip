@@ -798,6 +798,11 @@ constexpr int ROW3 = 3 * RD_C;   // bf16 elements per activation row (768 = 1536
 __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo)
 {
     hi = (__bf16)v;
+    if (__builtin_isinf((float)hi)) {   // |v| within half a bf16 ulp of 2^128 rounds to infinity: truncate instead (v itself infinite: stays)
+        const unsigned u = __float_as_uint(v) & 0xffff0000u;
+        const float tv = __uint_as_float(u);
+        hi = __builtin_isinf(v) ? hi : (__bf16)tv;
+    }
     const float r1 = v - (float)hi;
     mid = (__bf16)r1;
     lo = (__bf16)(r1 - (float)mid);
@@ -821,16 +826,24 @@ struct Bf3Args {
     int dil;
 };
 
+// One 512-thread workgroup per CU: 8 waves as 4 (time) x 2 (channels), each 64 x 128 as in the other kernels, so a workgroup
+// tile is 256 time steps x all 256 output channels = EIGHT 32-row sub-tile descriptors.  Against two 256-thread workgroups
+// per CU this halves the weight traffic into the CU (the B tile is shared by twice the rows) -- the split kernels are
+// bound by the L2 -> LDS copy volume, not by the matrix pipe -- and frees LDS for a third stage:
+// 3 x (A 256 x 96 B + B 256 x 96 B) = 144 KiB.
+constexpr int BM3 = 256;
+
 template <int NT, int TAPS, int EPI>
-__global__ __launch_bounds__(256, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
+__global__ __launch_bounds__(512, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
 {
     constexpr int BN = 2 * NT * 32;
     constexpr int NCHUNK = TAPS * (RD_C / 16);
     constexpr int RB = 96;                                   // bytes per LDS row (16 channels x 3 terms x 2 B)
-    constexpr int STAGE_BYTES = (BM + BN) * RB;              // 36 KiB (conv) / 24 KiB (head)
-    constexpr int HEAD_FLOATS = BM * (RD_H + 1) + RD_H * 5 + 8;
-    constexpr int EPI_FLOATS = 4 * 32 * 68;
-    constexpr int STG_FLOATS = 2 * STAGE_BYTES / 4;
+    constexpr int STAGE_BYTES = (BM3 + BN) * RB;             // 48 KiB (conv) / 36 KiB (head)
+    constexpr int NSTAGE = 3;
+    constexpr int HEAD_FLOATS = BM3 * (RD_H + 1) + RD_H * 5 + 8;
+    constexpr int EPI_FLOATS = 8 * 32 * 68;
+    constexpr int STG_FLOATS = NSTAGE * STAGE_BYTES / 4;
     constexpr int SMEM_FLOATS = (EPI == EPI_HEAD && HEAD_FLOATS > STG_FLOATS) ? HEAD_FLOATS : (STG_FLOATS > EPI_FLOATS ? STG_FLOATS : EPI_FLOATS);
 
     __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
@@ -838,14 +851,14 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1;
+    const int wm = wave >> 1;   // 0..3: 64 time steps each
     const int wn = wave & 1;
-    const TileDesc* __restrict__ tds = a.tiles + (size_t)blockIdx.x * 4;   // four 32-row sub-tiles (see the fp32 kernel)
+    const TileDesc* __restrict__ tds = a.tiles + (size_t)blockIdx.x * 8;   // eight 32-row sub-tiles (see the fp32 kernel)
     const TileDesc sdm[2] = {tds[wm * 2], tds[wm * 2 + 1]};
     const bool mval[2] = {sdm[0].seg_len > sdm[0].t0, sdm[1].seg_len > sdm[1].t0};
 
     // ---- DMA roles.  Wave w stages sub-tile w: 32 rows x 6 slots = 192 slots = 3 wave-instructions; slot g = 64 p + lane
-    // of the sub-tile is (row g / 6, physical slot g % 6).  B: the wave's BN / 4 rows are a linear copy of the packed weights.
+    // of the sub-tile is (row g / 6, physical slot g % 6).  B: the wave's BN / 8 rows are a linear copy of the packed weights.
     const TileDesc sst = tds[wave];
     const int64_t d_seg = sst.seg_row, d_alt = sst.alt_row;
     const int d_t0 = sst.t0, d_ain = sst.alt_in;
@@ -866,8 +879,12 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
     const char* inb = (const char*)a.in;
     const unsigned lane_off = lane * 16;
 
-    constexpr int PB = BN * 6 / 64 / 4;     // B pieces per wave per chunk: 6 (conv) / 3 (head)
-    constexpr int NPIECE = 3 + PB;
+    constexpr int PBX2 = BN * 6 / 64 / 4;   // B pieces per PAIR of waves per chunk: 6 (conv) / 3 (head)
+    static_assert(BN * RB % (8 * 512) == 0, "B rows split evenly over 8 waves in 512-B halves");
+    // B share of a wave: BN * 96 / 8 bytes = 3072 (conv: 3 pieces) / 1536 (head: 1.5 pieces -> waves pair up: even waves 2 pieces, odd 1)
+    constexpr int BSH = BN * RB / 8;        // bytes per wave
+    constexpr int PBW = (BSH + 1023) / 1024;                   // pieces a wave may issue: 3 (conv) / 2 (head)
+    constexpr int NPIECE = 3 + PBW;
     auto stage_piece = [&](int chunk, int tap, char* st, int pc) {
         if (pc < 3) {
             const int cc = chunk / TAPS;
@@ -875,15 +892,23 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
             glds16_uncounted((const float*)src, (float*)(st + (wave * 3 + pc) * 1024));
         } else {
             const int q = pc - 3;
-            const char* wb = (const char*)a.wpk + (size_t)chunk * BN * RB + (size_t)wave * PB * 1024 + (q >= 4 ? 4096 : 0);
-            float* dst = (float*)(st + BM * RB + wave * PB * 1024 + (q >= 4 ? 4096 : 0));
-            const int qq = q & 3;
-            if (qq == 0) glds16_uncounted_saddr<0>(lane_off, wb, dst);
-            else if (qq == 1) glds16_uncounted_saddr<1024>(lane_off, wb, dst);
-            else if (qq == 2) glds16_uncounted_saddr<2048>(lane_off, wb, dst);
-            else glds16_uncounted_saddr<3072>(lane_off, wb, dst);
+            if constexpr (BSH % 1024 == 0) {
+                const char* wb = (const char*)a.wpk + (size_t)chunk * BN * RB + (size_t)wave * BSH;
+                float* dst = (float*)(st + BM3 * RB + wave * BSH);
+                if (q == 0) glds16_uncounted_saddr<0>(lane_off, wb, dst);
+                else if (q == 1) glds16_uncounted_saddr<1024>(lane_off, wb, dst);
+                else glds16_uncounted_saddr<2048>(lane_off, wb, dst);
+            } else {
+                // head: 12 pieces over 8 waves: wave w takes piece w, waves 0..3 also piece 8 + w (always issued by every
+                // wave so that the hand-counted vmcnt is uniform: waves 4..7 re-copy piece w: same bytes, same place)
+                const int piece = q == 0 ? wave : 8 + (wave & 3);
+                const char* wb = (const char*)a.wpk + (size_t)chunk * BN * RB + (size_t)piece * 1024;
+                float* dst = (float*)(st + BM3 * RB + piece * 1024);
+                glds16_uncounted_saddr<0>(lane_off, wb, dst);
+            }
         }
     };
+    (void)PBX2;
 
     const int fr = lane & 31;
     const int fh = lane >> 5;
@@ -903,7 +928,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
 #pragma unroll
     for (int t = 0; t < 3; t++) toff[t] = ((2 * t + fh) ^ sw) * 16;
     const int a_off = (wm * 64 + fr) * RB;
-    const int b_off = BM * RB + (wn * NT * 32 + fr) * RB;
+    const int b_off = BM3 * RB + (wn * NT * 32 + fr) * RB;
 
     const bool work = mval[0] || mval[1];
     auto chunk_step = [&](const char* st, int next, int next_tap, char* nst) {
@@ -911,6 +936,16 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
         const char* Bb = st + b_off;
         bf16x8 af[2][3], bf[2][3];
         const bool st_ok = next < NCHUNK;
+#ifdef RD_BF3_NOLDS
+        if (work) {   // experiment: operands from registers (no fragment reads)
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int t = 0; t < 3; t++) af[m][t] = (bf16x8)(__bf16)(float)(toff[t] + m);
+#pragma unroll
+            for (int t = 0; t < 3; t++) bf[0][t] = bf[1][t] = (bf16x8)(__bf16)(float)(toff[t] + 7);
+        }
+#else
         if (work) {
 #pragma unroll
             for (int m = 0; m < 2; m++)
@@ -919,16 +954,23 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
 #pragma unroll
             for (int t = 0; t < 3; t++) bf[0][t] = *(const bf16x8*)(Bb + toff[t]);
         }
+#endif
         constexpr int PPS = (NPIECE + NT - 1) / NT;   // DMA pieces issued after each N step
 #pragma unroll
         for (int n = 0; n < NT; n++) {
             if (work) {
+#ifndef RD_BF3_NOLDS
                 if (n + 1 < NT) {
 #pragma unroll
                     for (int t = 0; t < 3; t++) bf[(n + 1) & 1][t] = *(const bf16x8*)(Bb + (n + 1) * 32 * RB + toff[t]);
                 }
+#endif
 #pragma unroll
                 for (int m = 0; m < 2; m++) {
+#ifdef RD_BF3_NOMFMA
+                    asm volatile("" ::"v"(af[m][0]), "v"(af[m][1]), "v"(af[m][2]), "v"(bf[n & 1][0]), "v"(bf[n & 1][1]), "v"(bf[n & 1][2]));
+                    continue;
+#endif
                     // smallest terms first: 2^-16 order, 2^-8 order, then hi*hi
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][2], bf[n & 1][0], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[n & 1][2], acc[m][n], 0, 0, 0);
@@ -937,52 +979,78 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[n & 1][1], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[n & 1][0], acc[m][n], 0, 0, 0);
                 }
+#ifndef RD_BF3_NOLDS
                 __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < PPS; q++)
-                if (st_ok && n * PPS + q < NPIECE) stage_piece(next, next_tap, nst, n * PPS + q);
+                if (st_ok && n * PPS + q < NPIECE) {
+#if defined(RD_BF3_SKIPALL)
+                    (void)0;
+#elif defined(RD_BF3_SKIPA)
+                    if (n * PPS + q >= 3) stage_piece(next, next_tap, nst, n * PPS + q);     // experiment: B pieces only
+#elif defined(RD_BF3_SKIPB)
+                    if (n * PPS + q < 3) stage_piece(next, next_tap, nst, n * PPS + q);      // experiment: A pieces only
+#elif defined(RD_BF3_NODMA)
+                    stage_piece(0, 0, nst, n * PPS + q);     // experiment: always the first chunk (cache-resident): no HBM / L2 misses
+#elif defined(RD_BF3_NOA)
+                    if (n * PPS + q >= 3) stage_piece(next, next_tap, nst, n * PPS + q); else stage_piece(0, 0, nst, n * PPS + q);
+#elif defined(RD_BF3_NOB)
+                    if (n * PPS + q < 3) stage_piece(next, next_tap, nst, n * PPS + q); else stage_piece(0, 0, nst, n * PPS + q);
+#else
+                    stage_piece(next, next_tap, nst, n * PPS + q);
+#endif
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    auto stage = [&](int chunk, int tap, char* st) {
+#pragma unroll
+        for (int pc = 0; pc < NPIECE; pc++) stage_piece(chunk, tap, st, pc);
+    };
 
+    // Three stages, one barrier per chunk (see the fp32 kernel): while chunk c is multiplied, c+1 is landing and c+2 is issued;
+    // the wait at the top of a chunk leaves the newest chunk's NPIECE instructions of this wave in flight.
     char* st0 = (char*)smem;
     char* st1 = (char*)smem + STAGE_BYTES;
+    char* st2 = (char*)smem + 2 * STAGE_BYTES;
     static_assert(TAPS == 3 || TAPS == 1, "tap of a chunk is a literal in the unrolled loop");
     constexpr bool T3 = TAPS == 3;
-#pragma unroll
-    for (int pc = 0; pc < NPIECE; pc++) stage_piece(0, 0, st0, pc);
-    // Two stages: at the top of chunk c its pieces (issued during chunk c-1) must have landed -- vmcnt(0) -- and every
-    // wave must be past its reads of chunk c-1, whose stage chunk c+1 is about to overwrite -- the barrier.
-    // chunk -> tap is chunk % 3: the loop advances by 6 chunks so that taps and stages are literals.
-    static_assert(NCHUNK % 2 == 0, "two-stage loop");
-    auto step = [&](int c, const char* st, int tap1, char* nst) {
-        wait_dma_and_barrier<0>();
-        chunk_step(st, c + 1, tap1, nst);
+    stage(0, 0, st0);
+    stage(1, T3 ? 1 : 0, st1);
+#if defined(RD_BF3_SKIPALL)
+    constexpr int NWAIT = 0;
+#elif defined(RD_BF3_SKIPA)
+    constexpr int NWAIT = NPIECE - 3;
+#elif defined(RD_BF3_SKIPB)
+    constexpr int NWAIT = 3;
+#else
+    constexpr int NWAIT = NPIECE;
+#endif
+    auto step = [&](int c, const char* st, int tap2, char* nst) {
+        if (c + 1 < NCHUNK && c >= 2) wait_dma_and_barrier<NWAIT>(); else if (c + 1 < NCHUNK) wait_dma_and_barrier<(NWAIT < NPIECE ? 0 : NPIECE)>(); else wait_dma_and_barrier<0>();
+        chunk_step(st, c + 2, tap2, nst);
     };
-    if constexpr (T3) {
-        for (int chunk = 0; chunk < NCHUNK; chunk += 6) {
-            step(chunk, st0, 1, st1);
-            step(chunk + 1, st1, 2, st0);
-            step(chunk + 2, st0, 0, st1);
-            step(chunk + 3, st1, 1, st0);
-            step(chunk + 4, st0, 2, st1);
-            step(chunk + 5, st1, 0, st0);
-        }
-    } else {
-        for (int chunk = 0; chunk < NCHUNK; chunk += 2) {
-            step(chunk, st0, 0, st1);
-            step(chunk + 1, st1, 0, st0);
-        }
+    for (int chunk = 0; chunk < NCHUNK; chunk += 3) {
+        step(chunk, st0, T3 ? 2 : 0, st2);
+        if (chunk + 1 < NCHUNK) step(chunk + 1, st1, 0, st0);
+        if (chunk + 2 < NCHUNK) step(chunk + 2, st2, T3 ? 1 : 0, st1);
     }
     __syncthreads();
+#ifdef RD_BF3_NOEPI
+    if (a.dil >= 0) {   // experiment: no epilogue (keeps the accumulators alive)
+        asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[0][NT - 1]), "v"(acc[1][NT - 1]));
+        return;
+    }
+#endif
 
     if constexpr (EPI != EPI_HEAD) {
         constexpr int TSTR = 68;
         float* ts = smem + wave * (32 * TSTR);
-        bf16x4* sinkh = (bf16x4*)a.sink + threadIdx.x;   // past-the-end rows store here (nobody reads it)
+        bf16x4* sinkh = (bf16x4*)a.sink + (threadIdx.x & 255);   // past-the-end rows store here (nobody reads it)
         const int rrow = lane >> 4;
         const int c4 = (lane & 15) * 4;
 #pragma unroll
@@ -1037,8 +1105,8 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
                     if constexpr (EPI == EPI_RES_IDENT) {
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
-                            // hi + mid + lo is exact in fp32 in this order (each partial sum is a prefix of the 24 bits)
-                            v[q] += ((float)r3[i][0][q] + (float)r3[i][1][q]) + (float)r3[i][2][q];
+                            // hi + (mid + lo) is exact in fp32: mid + lo is the 16-bit remainder v - hi, and the sum is v
+                            v[q] += (float)r3[i][0][q] + ((float)r3[i][1][q] + (float)r3[i][2][q]);
                             v[q] = v[q] > 0.f ? v[q] : 0.f;
                         }
                     } else if constexpr (EPI == EPI_RES_MATCH) {
@@ -1085,11 +1153,11 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
                     hs[row * LDH + hcol] = v > 0.f ? v : 0.f;
                 }
         }
-        float* w2s = smem + BM * LDH;
-        for (int i = tid; i < RD_H * 5; i += 256) w2s[i] = a.w2[i];
+        float* w2s = smem + BM3 * LDH;
+        for (int i = tid; i < RD_H * 5; i += 512) w2s[i] = a.w2[i];
         if (tid < 5) w2s[RD_H * 5 + tid] = a.b2[tid];
         __syncthreads();
-        if (tid < BM) {
+        if (tid < BM3) {
             const TileDesc sd = tds[tid >> 5];
             const int t = sd.t0 + (tid & 31);
             const int64_t seg_row = sd.seg_row;
@@ -1219,7 +1287,7 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
             h.w2 = m.w_d2;
             h.b2 = m.b_d2;
             h.probs = d_probs;
-            hipLaunchKernelGGL((tcn_gemm_bf3_kernel<2, 1, EPI_HEAD>), dim3(n), dim3(256), 0, st, h);
+            hipLaunchKernelGGL((tcn_gemm_bf3_kernel<2, 1, EPI_HEAD>), dim3(n / 2), dim3(512), 0, st, h);
             RD_HIP(hipGetLastError());
             return timer_end(st, ctx->timer_head, 2.0 * rows * (RD_C * RD_H + RD_H * 5), rows * (RD_C * 6.0 + 20.0));
         }
@@ -1239,9 +1307,9 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
             h.bmatch = m.b_match;
         }
         if ((rc = timer_begin(st, ctx->timer_conv))) return rc;
-        if (kind == 1) hipLaunchKernelGGL((tcn_gemm_bf3_kernel<4, 3, EPI_RELU>), dim3(n), dim3(256), 0, st, h);
-        else if (b == 0) hipLaunchKernelGGL((tcn_gemm_bf3_kernel<4, 3, EPI_RES_MATCH>), dim3(n), dim3(256), 0, st, h);
-        else hipLaunchKernelGGL((tcn_gemm_bf3_kernel<4, 3, EPI_RES_IDENT>), dim3(n), dim3(256), 0, st, h);
+        if (kind == 1) hipLaunchKernelGGL((tcn_gemm_bf3_kernel<4, 3, EPI_RELU>), dim3(n / 2), dim3(512), 0, st, h);
+        else if (b == 0) hipLaunchKernelGGL((tcn_gemm_bf3_kernel<4, 3, EPI_RES_MATCH>), dim3(n / 2), dim3(512), 0, st, h);
+        else hipLaunchKernelGGL((tcn_gemm_bf3_kernel<4, 3, EPI_RES_IDENT>), dim3(n / 2), dim3(512), 0, st, h);
         RD_HIP(hipGetLastError());
         return timer_end(st, ctx->timer_conv, 2.0 * rows * RD_C * RD_C * RD_K, (kind == 2 && b > 0 ? 3.0 : 2.0) * rows * RD_C * 6.0);
     }
@@ -1415,7 +1483,7 @@ int rd_uniform_tiles(rd_ctx* ctx, int nW, int T, TileLists* out)
 {
     const int subs = (T + 31) / 32;                                  // 32-row sub-tiles per window
     const size_t nsub = (size_t)nW * subs;
-    const size_t n = (nsub + 3) / 4;                                  // workgroup tiles (four sub-tiles each)
+    const size_t n = (nsub + 7) / 8 * 2;                              // workgroup tiles (four sub-tiles each), an even number: the bf16x3 kernel's tiles are eight
     if (ctx->tiles_nW != nW || ctx->tiles_T != T) {
         std::vector<TileDesc> h(n * 4);
         for (size_t i = 0; i < n * 4; i++) {

@@ -23,7 +23,7 @@ for c in range(cases):
     x = np.clip(rng.normal(size=(nW, T)), -4, 4).astype(np.float32)
     ref = oracle.tcn_forward(w, x, dilations=dil, acc64=True)
     line = f"case {c}: blocks {nb} dil {dil} nW {nW} T {T}:"
-    for prec in ("fp32", "f16x3"):
+    for prec in ("fp32", "f16x3", "bf16x3"):
         be.set_precision(prec)
         got = be.forward(x)
         err = float(np.abs(got.astype(np.float64) - ref).max())

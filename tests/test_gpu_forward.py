@@ -217,3 +217,119 @@ def test_split_mode_streamed_equals_windowed():
     exp = b.basecall_chunk(w.astype(np.float32), valid, 10)
     assert all(np.array_equal(a, e) for a, e in zip(got, exp))
     b.close()
+
+
+def _bf16_to_f32(bits):
+    return (bits.astype(np.uint32) << 16).view(np.float32)
+
+
+def test_bf16x3_split_reconstructs_fp32_exactly():
+    """precision mode 2 carries every fp32 operand as hi + mid + lo bf16.  The device-side split (rd_split3: the function
+    the kernels' epilogues call) must give hi + mid + lo == v EXACTLY, term by term in float32 arithmetic, for every sampled
+    finite fp32: random bit patterns over the whole normal range down to 2^-100, activations-like and weight-like values,
+    powers of two, values one ulp around them, all-ones mantissas, +-0.  (Below 2^-110 the third term would fall under
+    bf16's smallest subnormal; such values are sampled separately and must be exact to 2^-133 absolute.)"""
+    from radian_amd import Backend
+    rng = np.random.default_rng(0)
+    n = 1 << 20
+    bits = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    e = (bits >> 23) & 0xFF
+    bits = bits[(e >= 27) & (e <= 254)]                       # finite, |v| >= 2^-100
+    vals = [bits.view(np.float32),
+            rng.normal(size=200000).astype(np.float32), (rng.normal(size=200000) * 0.05).astype(np.float32),
+            np.abs(rng.normal(size=100000)).astype(np.float32) * np.float32(37.0),
+            np.array([0.0, -0.0, 1.0, -1.0, 3.0, 1.0 + 2.0 ** -23, 2.0 - 2.0 ** -23, 255.0 / 256, 257.0 / 256, 1e-30, -1e30, 3.4028235e38,
+                      2.0 ** -100, 1.9999999 * 2.0 ** -100], dtype=np.float32),
+            (2.0 ** rng.integers(-100, 127, size=5000)).astype(np.float32)]
+    p2 = vals[-1]
+    vals += [np.nextafter(p2, np.float32(0)), np.nextafter(p2, np.float32(np.inf))]
+    v = np.concatenate(vals)
+    b = Backend(0)
+    try:
+        t = b.split3(v)
+        hi, mid, lo = (_bf16_to_f32(t[i]) for i in range(3))
+        rec = hi + (mid + lo)                                  # float32 adds (the epilogue's order); exact when the split is exact
+        bad = np.nonzero(rec.view(np.uint32) != v.view(np.uint32))[0]
+        bad = [i for i in bad if not (v[i] == 0 and rec[i] == 0)]       # -0.0 -> +0.0 is fine
+        assert not bad, (len(bad), v[bad[:5]], rec[bad[:5]])
+        assert np.array_equal(hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64), v.astype(np.float64))
+        # ordering of magnitudes: each term refines the previous one
+        nz = v != 0
+        assert np.all(np.abs(mid[nz]) <= np.abs(hi[nz]) * 2.0 ** -7) and np.all(np.abs(lo[nz]) <= np.abs(hi[nz]) * 2.0 ** -14)
+        # tiny values: absolute defect below bf16's subnormal spacing
+        tiny = (rng.random(20000).astype(np.float32) + np.float32(1.0)) * (2.0 ** rng.integers(-126, -101, size=20000)).astype(np.float32)
+        tt = b.split3(tiny)
+        rec = sum(_bf16_to_f32(tt[i]).astype(np.float64) for i in range(3))
+        assert np.abs(rec - tiny.astype(np.float64)).max() <= 2.0 ** -133
+    finally:
+        b.close()
+
+
+def test_forward_bf16x3_accuracy(oracle):
+    """precision mode 2 (six bf16 MFMAs per product on exactly split operands): against the float64-ACCUMULATED oracle the
+    softmax error must not exceed the exact-fp32-MFMA mode's on any shape (both are float32-accumulation noise), and it must
+    stay inside the 1e-4 bound against the float32 oracle."""
+    from radian_amd import Backend, weights
+    rng = np.random.default_rng(10)
+    shapes = [(1234, 1.0, (1, 2, 4, 8, 16, 32), 3, 1024), (77, 6.0, (1, 2, 4, 8, 16, 32), 3, 1024), (5, 3.0, (1, 2, 4), 3, 1024),
+              (9, 1.0, (1, 2, 4, 8, 16, 32), 2, 700), (11, 3.0, (32, 16, 8, 4, 2, 1), 4, 333), (13, 1.0, (1,), 5, 129),
+              (21, 3.0, (1, 2, 4, 8, 16, 32, 64), 2, 1500)]
+    for seed, gain, dil, nW, T in shapes:
+        w = weights.synthetic_weights(seed=seed, head_gain=gain, dilations=dil)
+        b = Backend(0)
+        try:
+            b.load_weights(w, dil)
+            x = np.clip(rng.normal(size=(nW, T)), -4, 4).astype(np.float32)
+            exp = oracle.tcn_forward(w, x, dilations=dil, acc64=True)
+            p32 = b.forward(x)
+            b.set_precision("bf16x3")
+            p3 = b.forward(x)
+            assert np.all(np.isfinite(p3)) and np.allclose(p3.sum(axis=2), 1.0, atol=1e-5)
+            e32, e3 = float(np.abs(p32 - exp).max()), float(np.abs(p3 - exp).max())
+            print(f"seed {seed} gain {gain} dil {dil} {nW}x{T}: max|dp| vs f64-accumulated reference: fp32 MFMA {e32:.2e}, bf16x3 {e3:.2e}")
+            assert e3 <= TOL and e32 <= TOL, (seed, e3, e32)
+            assert e3 <= max(e32, 2e-6), (seed, e3, e32)
+            assert np.abs(p3 - oracle.tcn_forward(w, x, dilations=dil)).max() <= TOL
+            for Ts in (1, 100, 300):
+                xs = rng.normal(size=(2, Ts)).astype(np.float32)
+                assert np.abs(b.forward(xs) - oracle.tcn_forward(w, xs, dilations=dil)).max() <= TOL, Ts
+            b.set_precision("fp32")
+            assert np.array_equal(b.forward(x), p32)
+        finally:
+            b.close()
+
+
+def test_bf16x3_streamed_equals_windowed_and_bench_labels(oracle):
+    """mode 2 on the reads-level (streamed) path: rows >= 252 of a window are bitwise the read's stream rows, fragments equal
+    the windowed evaluation's, and on a bench batch the labels are those of the oracle's beam search on the mode's own
+    probabilities (decode parity is independent of the forward's arithmetic)."""
+    from radian_amd import Backend, weights, synthetic
+    from radian_amd.preprocess import get_windows
+    b = Backend(0)
+    try:
+        b.load_weights(weights.synthetic_weights(seed=1234))
+        b.set_precision("bf16x3")
+        rng = np.random.default_rng(11)
+        sig = np.clip(rng.normal(size=3000), -4, 4).astype(np.float32)
+        stream = b.forward(sig[None, :])[0]
+        w, pad = get_windows(sig, 1024, 512)
+        probs = b.forward(w.astype(np.float32))
+        for i in range(w.shape[0]):
+            n = 1024 if i < w.shape[0] - 1 else 1024 - pad
+            assert np.array_equal(probs[i, 252:n], stream[i * 512 + 252: i * 512 + n]), i
+        got = b.basecall_reads_chunk([sig], 1024, 512, 10)[0]
+        valid = np.full(w.shape[0], 1024, dtype=np.int32)
+        valid[-1] = 1024 - pad
+        exp = b.basecall_chunk(w.astype(np.float32), valid, 10)
+        assert all(np.array_equal(a, e) for a, e in zip(got, exp))
+        reads = synthetic.synthetic_reads(16, 4096, seed=0)
+        win, valid, _, _ = synthetic.reads_to_windows(reads, 1024, 512)
+        pr = b.forward(win)
+        ref = oracle.tcn_forward(weights.synthetic_weights(seed=1234), win[:32])
+        assert float(np.abs(pr[:32] - ref).max()) <= TOL
+        frags = b.basecall_chunk(win, valid, 10)
+        off = np.arange(win.shape[0], dtype=np.int64) * 1024
+        lab = oracle.beam_search_batch(pr.reshape(-1, 5), off, valid, 10)
+        assert all(np.array_equal(a, e) for a, e in zip(frags, lab))
+    finally:
+        b.close()
