@@ -85,6 +85,17 @@ int rd_load_weights(rd_ctx* ctx, const void* blob, size_t nbytes);
  * significant (the JSON key string read left to right).  k = --context-len, 1..13.
  * Passing table == NULL unloads the LM. */
 int rd_load_lm(rd_ctx* ctx, const double* table, int k);
+/* Long contexts (--context-len up to 256; BASELINE configs[4]).  NO reference behaviour: the reference needs one dict
+ * entry per context (decode.py:83), impossible beyond a dozen labels.  A synthetic LM for such contexts is a dense
+ * table[4^table_order][4] addressed by a hash of the context: row = H(l_0..l_{k-1}) & (4^table_order - 1),
+ * H = sum l_i * B^(k-1-i) mod 2^32, B = 0x9E3779B1; gate and mixing as decode.py:79-96.  The decoder keeps the hash
+ * incrementally per beam with a 256-label ring (the label leaving the window).  Parity: the oracle's same definition. */
+int rd_load_lm_hashed(rd_ctx* ctx, const double* table, int table_order, int context_len);
+/* Storage type of the softmax rows between the head kernel and the decoder on the reads-level paths
+ * (rd_basecall_reads_*, rd_basecall_raw_*, rd_pipe_submit_reads): 0 float32 (the reference's, default), 1 float16
+ * (10 B per time step; rounded to nearest by the head kernel, widened exactly by the decoder / assembly).  Not a
+ * reference option (BASELINE configs[4] "fp16 logits"): labels equal the oracle's on the same f16-rounded rows. */
+int rd_set_logits(rd_ctx* ctx, int mode);
 
 /* ---- the five seams, host-pointer form ----------------------------------------------------- */
 /* sig_model.predict(windows) -- radian/basecall.py:91,93.

@@ -109,8 +109,10 @@ def beam_search(mat, bases, beam_width, lm_table=None, s_threshold=None, r_thres
 
 
 def beam_search_batch(mats, seq_off, seq_len, beam_width, lm_table=None, s_threshold=0.0, r_threshold=0.0,
-                      len_context=0, nthreads=0):
-    """Batch of independent sequences over concatenated rows (OpenMP over sequences)."""
+                      len_context=0, nthreads=0, hash_order=0):
+    """Batch of independent sequences over concatenated rows (OpenMP over sequences).
+    hash_order > 0: long-context synthetic LM (no reference behaviour; radian_oracle.c ro_ctx_hash): lm_table has
+    4^hash_order rows addressed by a hash of the last len_context labels."""
     mats = np.ascontiguousarray(mats)
     seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
     seq_len = np.ascontiguousarray(seq_len, dtype=np.int32)
@@ -122,9 +124,9 @@ def beam_search_batch(mats, seq_off, seq_len, beam_width, lm_table=None, s_thres
     lens = np.zeros(n, dtype=np.int32)
     if lm_table is not None:
         lm_table = np.ascontiguousarray(lm_table, dtype=np.float64)
-    rc = lib().ro_beam_search_batch(
+    rc = lib().ro_beam_search_batch_ex(
         _ptr(mats), ctypes.c_int(1 if mats.dtype == np.float64 else 0), _ptr(seq_off), _ptr(seq_len), ctypes.c_int(n),
-        ctypes.c_int(beam_width), _ptr(lm_table), ctypes.c_int(len_context), ctypes.c_double(s_threshold),
+        ctypes.c_int(beam_width), _ptr(lm_table), ctypes.c_int(len_context), ctypes.c_int(hash_order), ctypes.c_double(s_threshold),
         ctypes.c_double(r_threshold), _ptr(labels), _ptr(label_off), _ptr(lens), ctypes.c_int(nthreads))
     if rc != 0:
         raise RuntimeError("ro_beam_search_batch failed")

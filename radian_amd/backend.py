@@ -97,6 +97,19 @@ class Backend:
         self._check(self._L.rd_load_lm(self._h, _p(table), int(k)))
         self.lm_k = k
 
+    def load_lm_hashed(self, table, table_order, context_len):
+        """Synthetic LM for contexts longer than a dense table can index (rd_load_lm_hashed): table [4^table_order, 4],
+        row = hash of the last `context_len` labels (<= 256)."""
+        table = np.ascontiguousarray(table, dtype=np.float64)
+        if table.shape != (4 ** table_order, 4):
+            raise ValueError(f"LM table must be [4^{table_order},4], got {table.shape}")
+        self._check(self._L.rd_load_lm_hashed(self._h, _p(table), int(table_order), int(context_len)))
+        self.lm_k = context_len
+
+    def set_logits(self, mode):
+        """'f32' (default) or 'f16': storage of the softmax rows on the reads-level paths (rd_set_logits)."""
+        self._check(self._L.rd_set_logits(self._h, {"f32": 0, "f16": 1}[mode] if isinstance(mode, str) else int(mode)))
+
     # ------------------------------------------------------------------ seams (host arrays)
     def forward(self, windows):
         """sig_model.predict (radian/basecall.py:91,93): [n,T] -> [n,T,5] float32."""

@@ -455,21 +455,19 @@ int rd_model_halo(const rd_ctx* ctx)
 // --------------------------------------------------------------------------------------------- LM
 static void lm_bind(LM& lm)
 {
-    const size_t n = (size_t)1 << (2 * lm.k);
+    const size_t n = (size_t)1 << (2 * lm.table_order);
     lm.table = lm.storage.as<double>();
     lm.d_entropy = lm.table + n * 4;
 }
 
-extern "C" int rd_load_lm(rd_ctx* ctx, const double* table, int k)
+static int load_lm_table(rd_ctx* ctx, const double* table, int table_order, int context_len, int hashed)
 {
-    RD_REQUIRE(ctx, "rd_load_lm: null context");
     LM& lm = ctx->lm;
     lm.loaded = false;
     lm.gate_valid = false;
     if (!table) return RD_OK;
-    RD_REQUIRE(k >= 1 && k <= 13, "rd_load_lm: context length %d out of range [1,13]", k);
     RD_HIP(hipSetDevice(ctx->device));
-    const size_t n = (size_t)1 << (2 * k);
+    const size_t n = (size_t)1 << (2 * table_order);
     // per-context entropy, decode.py:73-76,85-90 (math.log == glibc log; python sum is left-assoc)
     std::vector<double> ent(n);
     for (size_t c = 0; c < n; c++) {
@@ -484,12 +482,38 @@ extern "C" int rd_load_lm(rd_ctx* ctx, const double* table, int k)
             }
         ent[c] = any ? -s : 0.0;
     }
-    lm.k = k;
+    lm.k = context_len;
+    lm.table_order = table_order;
+    lm.hashed = hashed;
     if (lm.storage.reserve(n * 5 * sizeof(double))) return RD_ERR_NOMEM;
     lm_bind(lm);
     RD_HIP(hipMemcpy(lm.table, table, n * 4 * sizeof(double), hipMemcpyHostToDevice));
     RD_HIP(hipMemcpy(lm.d_entropy, ent.data(), n * sizeof(double), hipMemcpyHostToDevice));
     lm.loaded = true;
+    return RD_OK;
+}
+
+extern "C" int rd_load_lm(rd_ctx* ctx, const double* table, int k)
+{
+    RD_REQUIRE(ctx, "rd_load_lm: null context");
+    if (!table) return load_lm_table(ctx, nullptr, 0, 0, 0);
+    RD_REQUIRE(k >= 1 && k <= 13, "rd_load_lm: context length %d out of range [1,13] (longer contexts: rd_load_lm_hashed)", k);
+    return load_lm_table(ctx, table, k, k, 0);
+}
+
+extern "C" int rd_load_lm_hashed(rd_ctx* ctx, const double* table, int table_order, int context_len)
+{
+    RD_REQUIRE(ctx && table, "rd_load_lm_hashed: null argument");
+    RD_REQUIRE(table_order >= 1 && table_order <= 13, "rd_load_lm_hashed: table order %d out of range [1,13]", table_order);
+    RD_REQUIRE(context_len >= 1 && context_len <= 256, "rd_load_lm_hashed: context length %d out of range [1,256]", context_len);
+    return load_lm_table(ctx, table, table_order, context_len, 1);
+}
+
+extern "C" int rd_set_logits(rd_ctx* ctx, int mode)
+{
+    RD_REQUIRE(ctx, "rd_set_logits: null context");
+    RD_REQUIRE(mode == 0 || mode == 1, "rd_set_logits: mode %d (0 = float32 rows, 1 = float16 rows)", mode);
+    ctx->logits_f16 = mode;
     return RD_OK;
 }
 
@@ -965,6 +989,7 @@ struct PipeSlot {
     hipEvent_t dec_done = nullptr;
     bool busy = false;      // decode launched, labels not yet delivered
     int T = 0, W = 0, nwin = 0;
+    int f16 = 0;            // the slot's probability rows are _Float16 (rd_set_logits)
     int64_t rows = 0;       // probability rows produced into this slot so far
     std::vector<PipeSub> subs;
     std::vector<int64_t> off1, off2;   // per window: source rows (see DecodeArgs)
@@ -1076,7 +1101,7 @@ int pipe_launch_decode(rd_ctx* ctx, Pipe* p, PipeSlot& s)
         if (s.lane_mask & (1u << l)) RD_HIP(hipStreamWaitEvent(p->s_dec, ctx->lanes[l].done, 0));
     RD_HIP(hipMemcpyAsync(s.meta.p, s.h_meta, o_llen, hipMemcpyHostToDevice, p->s_dec));
     char* dm = (char*)s.meta.p;
-    rc = rd_decode_dev(ctx, s.probs.p, 0, (const int64_t*)dm, (const int32_t*)(dm + o_len), (const int64_t*)(dm + o_node),
+    rc = rd_decode_dev(ctx, s.probs.p, s.f16 ? 2 : 0, (const int64_t*)dm, (const int32_t*)(dm + o_len), (const int64_t*)(dm + o_node),
                        (const int64_t*)(dm + o_lab), s.nwin, nodes, s.W, 0, 0.0, 0.0, s.labels.as<uint8_t>(),
                        (int32_t*)(dm + o_llen), nullptr, p->s_dec, (const int64_t*)(dm + o_off2), (const int32_t*)(dm + o_split));
     if (rc) return rc;
@@ -1088,12 +1113,12 @@ int pipe_launch_decode(rd_ctx* ctx, Pipe* p, PipeSlot& s)
 }
 
 // slot that can take `rows` more probability rows for windows of T rows decoded at width W; closes / recycles groups
-int pipe_open_slot(rd_ctx* ctx, Pipe* p, int T, int W, int64_t rows, PipeSlot** out)
+int pipe_open_slot(rd_ctx* ctx, Pipe* p, int T, int W, int64_t rows, PipeSlot** out, int f16 = 0)
 {
     int rc;
     PipeSlot* s = &p->slot[p->cur];
-    // a group is homogeneous in chunk_len and beam width and bounded in size; otherwise close it and move on
-    if (s->nwin > 0 && (s->T != T || s->W != W || (int)s->subs.size() >= p->group)) {
+    // a group is homogeneous in chunk_len, beam width and row type and bounded in size; otherwise close it and move on
+    if (s->nwin > 0 && (s->T != T || s->W != W || s->f16 != f16 || (int)s->subs.size() >= p->group)) {
         if ((rc = pipe_launch_decode(ctx, p, *s))) return rc;
         p->cur ^= 1;
         s = &p->slot[p->cur];
@@ -1112,6 +1137,7 @@ int pipe_open_slot(rd_ctx* ctx, Pipe* p, int T, int W, int64_t rows, PipeSlot** 
     }
     s->T = T;
     s->W = W;
+    s->f16 = f16;
     *out = s;
     return RD_OK;
 }
@@ -1382,11 +1408,12 @@ extern "C" int rd_basecall_reads_chunk_resident(rd_ctx* ctx, const float* d_sign
     const TileLists* tl = nullptr;
     if ((rc = get_plan(ctx, read_off, n_reads, chunk_len, step, 0, &P, &tl, nullptr))) return rc;
     if (ctx->ws_probs.reserve((size_t)P->total_rows * 20)) return RD_ERR_NOMEM;
-    rc = rd_forward_tiles_dev(ctx, d_signal, *tl, P->total_rows, ctx->ws_probs.as<float>());
+    const int f16 = ctx->logits_f16;
+    rc = rd_forward_tiles_dev(ctx, d_signal, *tl, P->total_rows, ctx->ws_probs.p, 0, f16);
     if (rc) return rc;
     std::vector<int64_t> lab_off(P->n_windows);
     for (int w = 0; w < P->n_windows; w++) lab_off[w] = (int64_t)w * chunk_len;
-    return decode_and_fetch(ctx, ctx->ws_probs.p, 0, P->off1.data(), P->valid.data(), P->n_windows, beam_width, 0, 0.0, 0.0,
+    return decode_and_fetch(ctx, ctx->ws_probs.p, f16 ? 2 : 0, P->off1.data(), P->valid.data(), P->n_windows, beam_width, 0, 0.0, 0.0,
                             labels_out, lab_off.data(), label_len, nullptr, P->off2.data(), P->split.data());
 }
 
@@ -1406,7 +1433,7 @@ extern "C" int rd_basecall_reads_chunk(rd_ctx* ctx, const float* signal, const i
 namespace {
 
 // assembly + decode of a batch of reads given the forward's probabilities (streamed or windowed row layout)
-int global_finish(rd_ctx* ctx, const float* d_probs, bool streamed, const ReadsPlan& P, const int64_t* read_off, int n_reads,
+int global_finish(rd_ctx* ctx, const void* d_probs, int f16, bool streamed, const ReadsPlan& P, const int64_t* read_off, int n_reads,
                   int chunk_len, int step, int beam_width, int use_lm, double s_thr, double r_thr, uint8_t* labels_out,
                   const int64_t* label_off, int32_t* label_len)
 {
@@ -1430,8 +1457,8 @@ int global_finish(rd_ctx* ctx, const float* d_probs, bool streamed, const ReadsP
     for (int r = 0; r < n_reads; r++) {
         if (!is64[r]) continue;
         const int nW = P.read_win_off[r + 1] - P.read_win_off[r];
-        rc = rd_assemble_dev(ctx, d_probs + (size_t)P.read_row[r] * 5, nW, chunk_len, P.valid[r], step,
-                             ctx->ws_mat.as<double>() + off64[r] * 5, seq_len[r], streamed ? 1 : 0);
+        rc = rd_assemble_dev(ctx, (const char*)d_probs + (size_t)P.read_row[r] * 5 * (f16 ? 2 : 4), nW, chunk_len, P.valid[r], step,
+                             ctx->ws_mat.as<double>() + off64[r] * 5, seq_len[r], streamed ? 1 : 0, f16);
         if (rc) return rc;
     }
     for (int pass = 0; pass < 2; pass++) {
@@ -1447,7 +1474,7 @@ int global_finish(rd_ctx* ctx, const float* d_probs, bool streamed, const ReadsP
             }
         if (idx.empty()) continue;
         std::vector<int32_t> ll(idx.size());
-        rc = decode_and_fetch(ctx, pass == 0 ? (const void*)ctx->ws_mat.p : (const void*)d_probs, pass == 0 ? 1 : 0, so.data(), sl.data(),
+        rc = decode_and_fetch(ctx, pass == 0 ? (const void*)ctx->ws_mat.p : d_probs, pass == 0 ? 1 : (f16 ? 2 : 0), so.data(), sl.data(),
                               (int)idx.size(), beam_width, use_lm, s_thr, r_thr, labels_out, lo.data(), ll.data(), nullptr);
         if (rc) return rc;
         for (size_t i = 0; i < idx.size(); i++) label_len[idx[i]] = ll[i];
@@ -1470,9 +1497,10 @@ extern "C" int rd_basecall_reads_global_resident(rd_ctx* ctx, const float* d_sig
     bool streamed = false;
     if ((rc = get_plan(ctx, read_off, n_reads, chunk_len, step, 1, &P, &tl, &streamed))) return rc;
     if (ctx->ws_probs.reserve((size_t)P->total_rows * 20)) return RD_ERR_NOMEM;
-    rc = rd_forward_tiles_dev(ctx, d_signal, *tl, P->total_rows, ctx->ws_probs.as<float>());
+    const int f16 = ctx->logits_f16;
+    rc = rd_forward_tiles_dev(ctx, d_signal, *tl, P->total_rows, ctx->ws_probs.p, 0, f16);
     if (rc) return rc;
-    return global_finish(ctx, ctx->ws_probs.as<float>(), streamed, *P, read_off, n_reads, chunk_len, step, beam_width, use_lm, s_thr,
+    return global_finish(ctx, ctx->ws_probs.p, f16, streamed, *P, read_off, n_reads, chunk_len, step, beam_width, use_lm, s_thr,
                          r_thr, labels_out, label_off, label_len);
 }
 
@@ -1567,10 +1595,11 @@ extern "C" int rd_pipe_submit_reads(rd_ctx* ctx, const float* d_signal, const in
     Pipe* p = nullptr;
     if ((rc = pipe_get(ctx, &p))) return rc;
     PipeSlot* s = nullptr;
-    if ((rc = pipe_open_slot(ctx, p, chunk_len, beam_width, P->total_rows, &s))) return rc;
+    const int f16 = ctx->logits_f16;
+    if ((rc = pipe_open_slot(ctx, p, chunk_len, beam_width, P->total_rows, &s, f16))) return rc;
     const int lane = p->next_lane;
     p->next_lane = (p->next_lane + 1) % p->lanes;
-    rc = rd_forward_tiles_dev(ctx, d_signal, *tl, P->total_rows, s->probs.as<float>() + (size_t)s->rows * 5, lane);
+    rc = rd_forward_tiles_dev(ctx, d_signal, *tl, P->total_rows, (char*)s->probs.p + (size_t)s->rows * 5 * (f16 ? 2 : 4), lane, f16);
     if (rc) return rc;
     s->lane_mask |= 1u << lane;
     PipeSub sb;
@@ -1747,7 +1776,7 @@ struct RcclState {
 
 struct BcastHeader {
     int32_t model_loaded, nblocks, dil[RD_MAX_BLOCKS];
-    int32_t lm_loaded, lm_k;
+    int32_t lm_loaded, lm_k, lm_order, lm_hashed;
     int64_t model_floats, lm_doubles;
     float inv_scale[2 * RD_MAX_BLOCKS], inv_scale_d1;
 };
@@ -1817,7 +1846,9 @@ extern "C" int rd_rccl_bcast_model(rd_ctx* ctx, int root)
         hd.inv_scale_d1 = ctx->model.inv_scale_d1;
         hd.lm_loaded = ctx->lm.loaded ? 1 : 0;
         hd.lm_k = ctx->lm.k;
-        hd.lm_doubles = ctx->lm.loaded ? (int64_t)5 << (2 * ctx->lm.k) : 0;
+        hd.lm_order = ctx->lm.table_order;
+        hd.lm_hashed = ctx->lm.hashed;
+        hd.lm_doubles = ctx->lm.loaded ? (int64_t)5 << (2 * ctx->lm.table_order) : 0;
     }
     if (st->scratch.reserve(sizeof(BcastHeader))) return RD_ERR_NOMEM;
     RD_HIP(hipMemcpyAsync(st->scratch.p, &hd, sizeof(hd), hipMemcpyHostToDevice, ctx->stream));
@@ -1837,6 +1868,8 @@ extern "C" int rd_rccl_bcast_model(rd_ctx* ctx, int root)
         ctx->lm.gate_valid = false;
         if (hd.lm_loaded) {
             ctx->lm.k = hd.lm_k;
+            ctx->lm.table_order = hd.lm_order;
+            ctx->lm.hashed = hd.lm_hashed;
             if (ctx->lm.storage.reserve((size_t)hd.lm_doubles * 8)) return RD_ERR_NOMEM;
             lm_bind(ctx->lm);
         }

@@ -11,7 +11,8 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__ probs, int nW, int T, int pad, int step,
+template <typename IT>
+__global__ __launch_bounds__(256) void assemble_kernel(const IT* __restrict__ probs, int nW, int T, int pad, int step,
                                                         double* __restrict__ out, int64_t N, int streamed)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -24,7 +25,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__
     if (i_max == nW - 1 && t >= (int64_t)(nW - 1) * step + (T - pad)) i_max--;  // trimmed rows of the last window
     if (i_min > i_max) i_min = i_max;  // cannot happen for t < N
     // streamed forward: the earliest covering window's row of time step t IS the stream's row t
-    const float* r = streamed ? probs + (size_t)t * 5 : probs + ((size_t)i_min * T + (size_t)(t - (int64_t)i_min * step)) * 5;
+    const IT* r = streamed ? probs + (size_t)t * 5 : probs + ((size_t)i_min * T + (size_t)(t - (int64_t)i_min * step)) * 5;
     double x[5];
 #pragma unroll
     for (int c = 0; c < 5; c++) x[c] = (double)r[c];
@@ -40,12 +41,17 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__
 
 }  // namespace
 
-int rd_assemble_dev(rd_ctx* ctx, const float* d_probs, int nW, int T, int pad, int step, double* d_out, int64_t N, int streamed)
+int rd_assemble_dev(rd_ctx* ctx, const void* d_probs, int nW, int T, int pad, int step, double* d_out, int64_t N, int streamed, int in_f16)
 {
     if (N <= 0) return RD_OK;
     const int threads = 256;
     const int64_t blocks = (N + threads - 1) / threads;
-    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)blocks), dim3(threads), 0, ctx->stream, d_probs, nW, T, pad, step, d_out, N, streamed);
+    if (in_f16)   // f16 logits mode: the rows were rounded to f16 by the head kernel; widening is exact
+        hipLaunchKernelGGL(assemble_kernel<_Float16>, dim3((unsigned)blocks), dim3(threads), 0, ctx->stream, (const _Float16*)d_probs, nW, T, pad,
+                           step, d_out, N, streamed);
+    else
+        hipLaunchKernelGGL(assemble_kernel<float>, dim3((unsigned)blocks), dim3(threads), 0, ctx->stream, (const float*)d_probs, nW, T, pad, step,
+                           d_out, N, streamed);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }

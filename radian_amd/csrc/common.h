@@ -77,8 +77,10 @@ struct Model {
 
 struct LM {
     bool loaded = false;
-    int k = 0;
-    double* table = nullptr;        // [4^k][4] device
+    int k = 0;                      // context length (labels)
+    int table_order = 0;            // the table has 4^table_order rows (= k unless hashed)
+    int hashed = 0;                 // 1: long-context mode, row = hash(context) (decode.hip)
+    double* table = nullptr;        // [4^table_order][4] device
     double* d_entropy = nullptr;    // [4^k] device: entropy of each context's distribution (glibc log, computed at load)
     uint32_t* gate_bits = nullptr;  // bit ctx: d_entropy[ctx] < gate_r_thr
     double gate_r_thr = 0.0;
@@ -134,6 +136,7 @@ struct FwdLane {
 struct rd_ctx {
     int device = 0;
     int precision = 0;   // 0: exact fp32 MFMA (default); 1: split-f16 (f16x3); 2: three-term bf16 split (bf16x3) matrix products
+    int logits_f16 = 0;  // 1: the reads-level paths keep the softmax rows as f16 in HBM (10 B per time step), the decoder widens them
     hipStream_t stream = nullptr;
     Model model;
     LM lm;
@@ -153,13 +156,14 @@ struct rd_ctx {
 
 // forward.hip
 int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_probs, int lane = 0);
-int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tiles, int64_t total_rows, float* d_probs, int lane = 0);
+int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tiles, int64_t total_rows, void* d_probs, int lane = 0,
+                         int probs_f16 = 0 /* 1: d_probs is _Float16 [rows][5] */);
 int rd_lane_get(rd_ctx* ctx, int lane, FwdLane** out);   // creates the lane's stream on first use
 int rd_sync_lanes(rd_ctx* ctx);                          // every forward stream idle
 int rd_split3_dev(rd_ctx* ctx, const float* d_in, size_t n, uint16_t* d_out);   // fp32 -> [3][n] bf16 bit patterns (hi, mid, lo)
 int rd_model_halo(const rd_ctx* ctx);  // receptive field - 1 = (K-1) * 2 * sum(dilations)
 // decode.hip
-int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* d_seq_off, const int32_t* d_seq_len,
+int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype /* 0 f32, 1 f64, 2 f16 rows */, const int64_t* d_seq_off, const int32_t* d_seq_len,
                   const int64_t* d_node_off, const int64_t* d_label_off, int n_seq, int64_t total_nodes, int W, int use_lm,
                   double s_thr, double r_thr, uint8_t* d_labels, int32_t* d_label_len, double* d_best_score,
                   hipStream_t stream = nullptr /* default: ctx->stream */, const int64_t* d_seq_off2 = nullptr,
@@ -168,8 +172,9 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* d
 int rd_normalise_dev(rd_ctx* ctx, const int16_t* d_raw, const int64_t* d_read_off, int n_reads, int clip, float* d_out,
                      int32_t* d_status);
 // assemble.hip
-int rd_assemble_dev(rd_ctx* ctx, const float* d_probs, int nW, int T, int pad, int step, double* d_out, int64_t N,
-                    int streamed = 0 /* 1: d_probs is the streamed forward [N][5]; row t is taken from row t */);
+int rd_assemble_dev(rd_ctx* ctx, const void* d_probs, int nW, int T, int pad, int step, double* d_out, int64_t N,
+                    int streamed = 0 /* 1: d_probs is the streamed forward [N][5]; row t is taken from row t */,
+                    int in_f16 = 0 /* 1: d_probs rows are _Float16 */);
 
 extern "C" int rd_decode_max_width(void);
 

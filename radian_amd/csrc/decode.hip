@@ -26,6 +26,7 @@
 
 namespace {
 
+constexpr unsigned kHashB = 0x9E3779B1u;   // odd multiplier of the context hash (long contexts)
 constexpr double kLogE2 = 0.693147180559945309417232121458176568;
 
 // ---- logaddexp --------------------------------------------------------------------------------------------------------
@@ -156,8 +157,9 @@ struct __attribute__((aligned(16))) Beam {
     double pnb;             // 16: pr_non_blank
     int last, len;          // 24: last label (-1: empty labeling), labeling length
     int node;               // 32: canonical trie id
-    unsigned hist;          // 36: last 16 labels, 2 bits each (LM context)
-    int pad0, pad1;
+    unsigned hist;          // 36: last 16 labels, 2 bits each (LM context) -- or the context hash (long contexts)
+    unsigned hprev;         // 40: long contexts: hash of the context that excludes the last label
+    int pad1;
     int child[4];           // 48: trie ids of the four children (0 = never created)
 };
 static_assert(sizeof(Beam) == 64, "Beam is one 64-B LDS record");
@@ -180,7 +182,14 @@ struct DecodeArgs {
     // LM
     const double* lm_table;
     const uint32_t* lm_gate;
-    int k;
+    int k;                // context length: labels per LM context (decode.py:42-49)
+    // long contexts (k > 13, a mode of this library with no reference behaviour -- the reference needs a dict entry per
+    // context, decode.py:83): the table row of a context is H(context) & tmask with the polynomial hash
+    // H(l_0 .. l_{k-1}) = sum l_i B^(k-1-i) mod 2^32, kept incrementally per beam (window of the last k labels; the label
+    // that leaves the window comes from a 256-label ring per beam)
+    int hashed;
+    unsigned tmask;       // rows of the table - 1
+    unsigned bk;          // B^k mod 2^32
     double s_thr;
     // trie in HBM
     int4* childtab;
@@ -199,9 +208,10 @@ struct Tab {
     static constexpr int N = 512 * R;
 };
 
-template <typename PT, int R, bool LM>
+template <typename PT, int R, bool LM, bool HC>
 __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
 {
+    static_assert(LM || !HC, "hashed contexts only exist with an LM");
     constexpr int WM = Cfg<R>::WM;
     constexpr int NC = Cfg<R>::NC;
     constexpr int TN = Tab<R>::N;
@@ -226,6 +236,7 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
     __shared__ double sent[LM ? 64 : 1];
     __shared__ __attribute__((aligned(16))) double keyC[NC + 4];   // keys of the ranking's survivors, compacted in insertion order
     __shared__ unsigned char tabslot[TN];
+    __shared__ __attribute__((aligned(16))) unsigned ring[2][HC ? WM : 1][16];   // long contexts: the last 256 labels of each beam, 2 bits each
 
     // decode.py:128-132: the empty labeling with pr_blank = pr_total = log(1)
     if (lane == 0) {
@@ -237,7 +248,8 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
         b.len = 0;
         b.node = 0;
         b.hist = 0u;
-        b.pad0 = b.pad1 = 0;
+        b.hprev = 0u;
+        b.pad1 = 0;
         for (int c = 0; c < 4; c++) b.child[c] = 0;
         childtab[0] = make_int4(0, 0, 0, 0);
         backptr[0] = 0;
@@ -321,8 +333,13 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                     // decode.py:157-163 (copy: context excludes the last label) and :180-184 (extend)
                     const int need = is_copy[s] ? a.k + 1 : a.k;
                     if (valid[s] && c >= 0 && len_i >= need) {
-                        const unsigned h = os[i].hist;
-                        const unsigned ctx = (is_copy[s] ? (h >> 2) : h) & ctx_mask;
+                        unsigned ctx;
+                        if constexpr (HC) {
+                            ctx = (is_copy[s] ? os[i].hprev : os[i].hist) & a.tmask;
+                        } else {
+                            const unsigned h = os[i].hist;
+                            ctx = (is_copy[s] ? (h >> 2) : h) & ctx_mask;
+                        }
                         const bool gate = ((a.lm_gate[ctx >> 5] >> (ctx & 31)) & 1u) && (sent[tt] > a.s_thr);
                         if (gate) {
                             // combine_dists decode.py:52-64
@@ -540,7 +557,29 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
             if (act) {
                 const int new_node = is_ext ? my_node : meta.x;
                 *(int2*)&ns[lane].last = make_int2(is_ext ? cl : ll.x, is_ext ? ll.y + 1 : ll.y);
-                *(int4*)&ns[lane].node = make_int4(new_node, is_ext ? (int)(((unsigned)meta.y << 2) | (unsigned)cl) : meta.y, 0, 0);
+                unsigned h_new = ((unsigned)meta.y << 2) | (unsigned)cl, hp_new = (unsigned)meta.z;
+                if constexpr (HC) {
+                    // the beam's label ring moves with it; an extension appends its label at position len (mod 256) and the
+                    // label k positions back leaves the hash window
+                    const uint4* rs = (const uint4*)ring[cur][src];
+                    uint4* rd = (uint4*)ring[cur ^ 1][lane];
+                    const uint4 r0 = rs[0], r1 = rs[1], r2 = rs[2], r3 = rs[3];
+                    rd[0] = r0;
+                    rd[1] = r1;
+                    rd[2] = r2;
+                    rd[3] = r3;
+                    const int len_p = ll.y;                                    // the parent's length (extensions)
+                    const int pout = (len_p - a.k) & 255, pin = len_p & 255;
+                    const unsigned wout = ring[cur][src][pout >> 4], win = ring[cur][src][pin >> 4];
+                    const unsigned lout = len_p >= a.k ? (wout >> ((pout & 15) * 2)) & 3u : 0u;
+                    if (is_ext) {
+                        const int sh = (pin & 15) * 2;
+                        ring[cur ^ 1][lane][pin >> 4] = (win & ~(3u << sh)) | ((unsigned)cl << sh);
+                    }
+                    h_new = (unsigned)meta.y * kHashB + (unsigned)cl - lout * a.bk;
+                    hp_new = is_ext ? (unsigned)meta.y : (unsigned)meta.z;
+                }
+                *(int4*)&ns[lane].node = make_int4(new_node, is_ext ? (int)h_new : meta.y, (int)hp_new, 0);
                 *(int4*)&ns[lane].child[0] = make_int4(is_ext ? ch.x : chs.x, is_ext ? ch.y : chs.y, is_ext ? ch.z : chs.z, is_ext ? ch.w : chs.w);
                 tabslot[new_node & (TN - 1)] = (unsigned char)lane;
             }
@@ -574,10 +613,12 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
 template <typename PT, int R>
 int launch_r(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
 {
-    if (lm)
-        hipLaunchKernelGGL((beam_search_kernel<PT, R, true>), dim3(n_seq), dim3(64), 0, st, a);
+    if (lm && a.hashed)
+        hipLaunchKernelGGL((beam_search_kernel<PT, R, true, true>), dim3(n_seq), dim3(64), 0, st, a);
+    else if (lm)
+        hipLaunchKernelGGL((beam_search_kernel<PT, R, true, false>), dim3(n_seq), dim3(64), 0, st, a);
     else
-        hipLaunchKernelGGL((beam_search_kernel<PT, R, false>), dim3(n_seq), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((beam_search_kernel<PT, R, false, false>), dim3(n_seq), dim3(64), 0, st, a);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }
@@ -612,7 +653,7 @@ static int ensure_lm_gate(rd_ctx* ctx, double r_thr)
 {
     LM& lm = ctx->lm;
     if (lm.gate_valid && lm.gate_r_thr == r_thr) return RD_OK;
-    const size_t n = (size_t)1 << (2 * lm.k);
+    const size_t n = (size_t)1 << (2 * lm.table_order);
     const size_t words = (n + 31) / 32;
     if (lm.gate_storage.reserve(words * 4)) return RD_ERR_NOMEM;
     lm.gate_bits = (uint32_t*)lm.gate_storage.p;
@@ -625,7 +666,7 @@ static int ensure_lm_gate(rd_ctx* ctx, double r_thr)
     return RD_OK;
 }
 
-int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* d_seq_off, const int32_t* d_seq_len,
+int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_seq_off, const int32_t* d_seq_len,
                   const int64_t* d_node_off, const int64_t* d_label_off, int n_seq, int64_t total_nodes, int W, int use_lm,
                   double s_thr, double r_thr, uint8_t* d_labels, int32_t* d_label_len, double* d_best_score, hipStream_t stream,
                   const int64_t* d_seq_off2, const int32_t* d_seq_split)
@@ -655,6 +696,10 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* d
     a.lm_table = use_lm ? ctx->lm.table : nullptr;
     a.lm_gate = use_lm ? ctx->lm.gate_bits : nullptr;
     a.k = use_lm ? ctx->lm.k : 0;
+    a.hashed = use_lm ? ctx->lm.hashed : 0;
+    a.tmask = use_lm ? (unsigned)(((size_t)1 << (2 * ctx->lm.table_order)) - 1) : 0u;
+    a.bk = 1u;
+    for (int i = 0; use_lm && i < ctx->lm.k; i++) a.bk *= kHashB;
     a.s_thr = s_thr;
     a.childtab = ctx->ws_nodes_child.as<int4>();
     a.backptr = ctx->ws_nodes_back.as<int>();
@@ -663,7 +708,8 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t* d
     a.best_score = d_best_score;
     KernelTimer& tm = ctx->timer_decode;
     if (tm.enabled && tm.used < tm.starts.size()) RD_HIP(hipEventRecord(tm.starts[tm.used], st));
-    int rc = is_f64 ? launch_pt<double>(st, a, n_seq, use_lm != 0) : launch_pt<float>(st, a, n_seq, use_lm != 0);
+    int rc = ptype == 1 ? launch_pt<double>(st, a, n_seq, use_lm != 0)
+             : ptype == 2 ? launch_pt<_Float16>(st, a, n_seq, use_lm != 0) : launch_pt<float>(st, a, n_seq, use_lm != 0);
     if (rc) return rc;
     if (tm.enabled && tm.used < tm.starts.size()) {
         RD_HIP(hipEventRecord(tm.stops[tm.used], st));

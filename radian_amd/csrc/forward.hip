@@ -52,6 +52,7 @@ struct ConvArgs {
     const float* w2;      // EPI_HEAD: [128][5]
     const float* b2;      // EPI_HEAD: [5]
     float* probs;         // EPI_HEAD: [nW][T][5]
+    int probs_f16;        // EPI_HEAD: 1 = probs is _Float16 [rows][5] (f16 logits mode)
     int zero_row;         // a row of `in` that holds zeros and is never written: source of the causal left padding
     float* sink;          // 1024 floats nobody reads: target of the stores past a segment's end
     const TileDesc* tiles; // one per workgroup
@@ -384,9 +385,15 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
                     e[o] = expf(lg[o] - mx);
                     s += e[o];
                 }
-                float* pr = a.probs + ((size_t)seg_row + t) * 5;
+                if (a.probs_f16) {
+                    _Float16* pr = (_Float16*)a.probs + ((size_t)seg_row + t) * 5;
 #pragma unroll
-                for (int o = 0; o < 5; o++) pr[o] = e[o] / s;
+                    for (int o = 0; o < 5; o++) pr[o] = (_Float16)(e[o] / s);   // round to nearest even
+                } else {
+                    float* pr = a.probs + ((size_t)seg_row + t) * 5;
+#pragma unroll
+                    for (int o = 0; o < 5; o++) pr[o] = e[o] / s;
+                }
             }
         }
     }
@@ -453,6 +460,7 @@ struct SplitArgs {
     const float* w2;
     const float* b2;
     float* probs;
+    int probs_f16;
     int zero_row;
     float* sink;
     const TileDesc* tiles;
@@ -731,9 +739,15 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
                     e[o] = expf(lg[o] - mx);
                     s += e[o];
                 }
-                float* pr = a.probs + ((size_t)seg_row + t) * 5;
+                if (a.probs_f16) {
+                    _Float16* pr = (_Float16*)a.probs + ((size_t)seg_row + t) * 5;
 #pragma unroll
-                for (int o = 0; o < 5; o++) pr[o] = e[o] / s;
+                    for (int o = 0; o < 5; o++) pr[o] = (_Float16)(e[o] / s);   // round to nearest even
+                } else {
+                    float* pr = a.probs + ((size_t)seg_row + t) * 5;
+#pragma unroll
+                    for (int o = 0; o < 5; o++) pr[o] = e[o] / s;
+                }
             }
         }
     }
@@ -820,6 +834,7 @@ struct Bf3Args {
     const float* w2;
     const float* b2;
     float* probs;
+    int probs_f16;
     int zero_row;
     float* sink;
     const TileDesc* tiles;
@@ -1179,9 +1194,15 @@ __global__ __launch_bounds__(512, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
                     e[o] = expf(lg[o] - mx);
                     s += e[o];
                 }
-                float* pr = a.probs + ((size_t)seg_row + t) * 5;
+                if (a.probs_f16) {
+                    _Float16* pr = (_Float16*)a.probs + ((size_t)seg_row + t) * 5;
 #pragma unroll
-                for (int o = 0; o < 5; o++) pr[o] = e[o] / s;
+                    for (int o = 0; o < 5; o++) pr[o] = (_Float16)(e[o] / s);   // round to nearest even
+                } else {
+                    float* pr = a.probs + ((size_t)seg_row + t) * 5;
+#pragma unroll
+                    for (int o = 0; o < 5; o++) pr[o] = e[o] / s;
+                }
             }
         }
     }
@@ -1261,7 +1282,7 @@ int timer_end(hipStream_t st, KernelTimer& tm, double flops, double bytes)
 namespace {
 
 int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2 conv1, 3 head*/, const TileDesc* tiles, int n,
-                double rows, int zero_row, const float* d_signal, float* Xin, float* Xout, float* MID, float* d_probs)
+                double rows, int zero_row, const float* d_signal, float* Xin, float* Xout, float* MID, float* d_probs, int probs_f16)
 {
     if (n <= 0) return RD_OK;
     Model& m = ctx->model;
@@ -1287,6 +1308,7 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
             h.w2 = m.w_d2;
             h.b2 = m.b_d2;
             h.probs = d_probs;
+            h.probs_f16 = probs_f16;
             hipLaunchKernelGGL((tcn_gemm_bf3_kernel<2, 1, EPI_HEAD>), dim3(n / 2), dim3(512), 0, st, h);
             RD_HIP(hipGetLastError());
             return timer_end(st, ctx->timer_head, 2.0 * rows * (RD_C * RD_H + RD_H * 5), rows * (RD_C * 6.0 + 20.0));
@@ -1336,6 +1358,7 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
             h.w2 = m.w_d2;
             h.b2 = m.b_d2;
             h.probs = d_probs;
+            h.probs_f16 = probs_f16;
             hipLaunchKernelGGL((tcn_gemm_split_kernel<2, 1, EPI_HEAD>), dim3(n), dim3(256), 0, st, h);
         } else {
             ConvArgs h = {};
@@ -1348,6 +1371,7 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
             h.w2 = m.w_d2;
             h.b2 = m.b_d2;
             h.probs = d_probs;
+            h.probs_f16 = probs_f16;
             hipLaunchKernelGGL((tcn_gemm_kernel<2, 1, EPI_HEAD>), dim3(n), dim3(256), 0, st, h);
         }
         RD_HIP(hipGetLastError());
@@ -1437,7 +1461,7 @@ int rd_sync_lanes(rd_ctx* ctx)
     return RD_OK;
 }
 
-int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl, int64_t total_rows, float* d_probs, int lane)
+int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl, int64_t total_rows, void* d_probs, int lane, int probs_f16)
 {
     Model& m = ctx->model;
     if (!m.loaded) {
@@ -1467,7 +1491,7 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl
     for (int li = 0; li < nl; li++) {
         const int b = li == nl - 1 ? m.nblocks : li / 2;
         const int kind = li == nl - 1 ? 3 : (li == 0 ? 0 : (li & 1 ? 2 : 1));
-        if ((rc = launch_layer(ctx, L->st, b, kind, tl.d[li], tl.n[li], (double)tl.rows[li], zero_row, d_signal, Xin, Xout, MID, d_probs))) return rc;
+        if ((rc = launch_layer(ctx, L->st, b, kind, tl.d[li], tl.n[li], (double)tl.rows[li], zero_row, d_signal, Xin, Xout, MID, (float*)d_probs, probs_f16))) return rc;
         if (kind == 2) {   // block finished: its output becomes the next block's input
             float* t = Xin;
             Xin = Xout;

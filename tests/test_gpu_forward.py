@@ -266,9 +266,12 @@ def test_bf16x3_split_reconstructs_fp32_exactly():
 
 
 def test_forward_bf16x3_accuracy(oracle):
-    """precision mode 2 (six bf16 MFMAs per product on exactly split operands): against the float64-ACCUMULATED oracle the
-    softmax error must not exceed the exact-fp32-MFMA mode's on any shape (both are float32-accumulation noise), and it must
-    stay inside the 1e-4 bound against the float32 oracle."""
+    """precision mode 2 (six bf16 MFMAs per product on exactly split operands): inside the 1e-4 bound against the float32
+    oracle, and against the float64-ACCUMULATED oracle of the same size as the exact-fp32-MFMA mode's error.  Both errors are
+    float32 accumulation-order noise: over the 500 random shapes of tests/fuzz_forward.py (seed 7) bf16x3's worst case
+    (8.1e-5) and mean (7.9e-6) are below the fp32 mode's (1.11e-4, 8.4e-6), but shape by shape either mode is the larger
+    one about half the time (235 / 500) -- so "never above the fp32 mode's error on any shape" does not hold, and this
+    mode is not the headline."""
     from radian_amd import Backend, weights
     rng = np.random.default_rng(10)
     shapes = [(1234, 1.0, (1, 2, 4, 8, 16, 32), 3, 1024), (77, 6.0, (1, 2, 4, 8, 16, 32), 3, 1024), (5, 3.0, (1, 2, 4), 3, 1024),
@@ -288,7 +291,7 @@ def test_forward_bf16x3_accuracy(oracle):
             e32, e3 = float(np.abs(p32 - exp).max()), float(np.abs(p3 - exp).max())
             print(f"seed {seed} gain {gain} dil {dil} {nW}x{T}: max|dp| vs f64-accumulated reference: fp32 MFMA {e32:.2e}, bf16x3 {e3:.2e}")
             assert e3 <= TOL and e32 <= TOL, (seed, e3, e32)
-            assert e3 <= max(e32, 2e-6), (seed, e3, e32)
+            assert e3 <= 3 * max(e32, 5e-6), (seed, e3, e32)     # same order as float32 summation-order noise
             assert np.abs(p3 - oracle.tcn_forward(w, x, dilations=dil)).max() <= TOL
             for Ts in (1, 100, 300):
                 xs = rng.normal(size=(2, Ts)).astype(np.float32)
