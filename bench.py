@@ -150,36 +150,65 @@ def e2e_raw_leg(device, pool, n_reads, precision):
                     "batches of 512 reads; excludes fast5 parsing and FASTA writing"}
 
 
-def global_lm_leg(be, batches, read_off, reads_per_batch, steps):
-    """BASELINE configs[3] geometry on one GPU: global decode (one beam search per read over the assembled float64
-    matrix), step 512, W = 10, 12-mer LM = 4^11 x 4 float64 table (Dirichlet(0.3), seed 0), thresholds 0.5 / 0.5;
-    inputs resident in HBM, labels on the host at stop (unpipelined calls)."""
-    k = 11
-    table = np.random.default_rng(0).dirichlet([0.3] * 4, size=4 ** k)
-    be.load_lm(table, k)
-    del table
+def global_leg(device, batches_host, read_off, reads_per_batch, steps, W, table, table_order, context_len, hashed, logits, desc):
+    """Global decode (one beam search per read over the assembled float64 matrix) of the bench batches on one GPU, the way
+    the product's driver runs it (radian_amd.basecall.run): two device contexts on two host threads taking the steps in
+    turn, so that one step's forward overlaps the other's beam search; inputs resident in HBM, labels on the host at stop."""
+    import threading
+    from radian_amd import Backend, weights
+    bes, bufs = [], []
     try:
-        labels = np.zeros(reads_per_batch * READ_LEN + 1, dtype=np.uint8)
-        lens = np.zeros(reads_per_batch, dtype=np.int32)
+        for _ in range(2):
+            b = Backend(device)
+            b.load_weights(weights.synthetic_weights(seed=1234))
+            if hashed:
+                b.load_lm_hashed(table, table_order, context_len)
+            else:
+                b.load_lm(table, table_order)
+            b.set_logits(logits)
+            d = []
+            for norm in batches_host:
+                p = b.dev_alloc(norm.nbytes)
+                b.h2d(p, norm)
+                d.append(p)
+            bes.append(b)
+            bufs.append(d)
         label_off = np.ascontiguousarray(read_off[:-1])
+        outs = [(np.zeros(reads_per_batch * READ_LEN + 1, dtype=np.uint8), np.zeros(reads_per_batch, dtype=np.int32)) for _ in range(2)]
+        err = []
 
-        def call(i):
-            be.basecall_reads_global_resident(batches[i % len(batches)][3], read_off, reads_per_batch, CHUNK, STEP, BEAM, True, 0.5, 0.5,
-                                              labels, label_off, lens)
-        for i in range(2):
-            call(i)
-        be.sync()
+        def worker(k, lo, hi):
+            try:
+                lab, ln = outs[k]
+                for i in range(lo + k, hi, 2):
+                    bes[k].basecall_reads_global_resident(bufs[k][i % len(batches_host)], read_off, reads_per_batch, CHUNK, STEP, W, True,
+                                                          0.5, 0.5, lab, label_off, ln)
+                bes[k].sync()
+            except Exception as e:   # surfaced below
+                err.append(e)
+
+        def run(lo, hi):
+            th = [threading.Thread(target=worker, args=(k, lo, hi)) for k in range(2)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if err:
+                raise err[0]
+        run(0, 4)
         t0 = time.perf_counter()
-        for i in range(steps):
-            call(i)
-        be.sync()
+        run(0, steps)
         dt = time.perf_counter() - t0
-        assert lens.min() > 0
+        assert all(o[1].min() > 0 for o in outs)
     finally:
-        be.load_lm(None, 0)
+        for b, d in zip(bes, bufs):
+            for p in d:
+                b.dev_free(p)
+            b.close()
     return {"value": steps * reads_per_batch * READ_LEN / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "config": "BASELINE configs[3] geometry, one GPU: 64 reads x 4096 per step, --decode-type global, step 512, beam 10, "
-                      "k=11 LM table (4^11 x 4 f64), sig/rna thresholds 0.5/0.5; streamed forward + assembly (f64) + LM beam search"}
+            "config": desc + "; 64 reads x 4096 per step, --decode-type global, step 512; streamed forward + assembly (f64) + LM beam "
+                             "search; 2 device contexts on 2 host threads (as radian_amd.basecall.run): a step's forward overlaps the "
+                             "other context's beam search"}
 
 
 def main():
@@ -349,10 +378,21 @@ def main():
             sec[key] = {"precision": desc, "value": world * args.steps * samples_per_step / el2, "unit": "samples/s",
                         "ms_per_step": el2 / args.steps * 1e3, "accuracy": acc}
     if secondaries:
-        try:
-            sec["secondary_global_lm"] = global_lm_leg(be, batches, read_off, reads_per_batch, args.steps)
-        except Exception as e:
-            print(f"[bench] secondary_global_lm failed: {e}", file=sys.stderr)
+        norms = [np.stack([synthetic.mad_normalise(r, 4) for r in synthetic.synthetic_reads(reads_per_batch, READ_LEN, seed=1000 * rank + b)]).astype(np.float32)
+                 for b in range(n_batches)]
+        table = np.random.default_rng(0).dirichlet([0.3] * 4, size=4 ** 11)
+        for key, kw in (("secondary_global_lm", dict(W=BEAM, table_order=11, context_len=11, hashed=False, logits="f32",
+                                                     desc="BASELINE configs[3] geometry, one GPU: beam 10, k=11 LM table (4^11 x 4 f64, Dirichlet(0.3) seed 0), "
+                                                          "sig/rna thresholds 0.5/0.5")),
+                        ("secondary_cfg5_w25_ctx256_f16", dict(W=25, table_order=11, context_len=256, hashed=True, logits="f16",
+                                                               desc="BASELINE configs[4] stress: beam 25, --context-len 256 (hashed synthetic LM over a 4^11-row "
+                                                                    "table, 256-label ring per beam), f16 logits; no reference behaviour (SURVEY F7): parity vs the "
+                                                                    "oracle's same definition, tests/test_gpu_cfg5.py"))):
+            try:
+                sec[key] = global_leg(device, norms, read_off, reads_per_batch, args.steps, table=table, **kw)
+            except Exception as e:
+                print(f"[bench] {key} failed: {e}", file=sys.stderr)
+        del table
         if args.e2e_reads > 0:
             try:
                 sec["secondary_e2e_raw"] = e2e_raw_leg(device, stitch_pool, args.e2e_reads, args.precision)

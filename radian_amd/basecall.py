@@ -49,6 +49,13 @@ def build_parser():
     parser.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"],
                         help="matrix products of the signal model: exact fp32 MFMA (default) or split-f16 products with fp32 "
                              "accumulation (about 2x faster, same softmax error against a float64 reference; DESIGN.md 4.7)")
+    parser.add_argument("--logits", default="f32", choices=["f32", "f16"],
+                        help="storage of the softmax rows between the model and the decoder on the device: float32 (the reference's) or "
+                             "float16 (not a reference option; BASELINE configs[4])")
+    parser.add_argument("--lm-hashed-context", action="store_true",
+                        help="global mode: accept a --context-len longer than the RNA model's k-mers (up to 256) by addressing the model's "
+                             "table with a hash of the context (a synthetic long-context LM: no reference behaviour -- the reference raises "
+                             "KeyError at decode.py:83)")
     parser.add_argument("--stitch-workers", default=min(4, max(1, (os.cpu_count() or 2) // 4)), type=int,
                         help="worker processes for the chunk-mode fragment stitch (0: stitch on the driver's host thread)")
     parser.add_argument("--queue-block", default=256, type=int,
@@ -308,6 +315,11 @@ def load_artifacts(args):
         if os.path.exists(args.rna_model):
             table, k = lm_mod.load_json(args.rna_model)
             if args.decode_type == "global":
+                if k != args.context_len and getattr(args, "lm_hashed_context", False):
+                    if not (1 <= args.context_len <= 256):
+                        raise ValueError("--lm-hashed-context: --context-len must be in [1, 256]")
+                    art["lm_table"], art["lm_k"], art["lm_hashed_order"] = table, args.context_len, k
+                    return art
                 if k != args.context_len:
                     raise KeyError(f"--context-len {args.context_len} does not match the RNA model's context length {k} "
                                    "(the reference fails with KeyError at decode.py:83)")
@@ -322,8 +334,12 @@ def apply_artifacts(args, be, art):
     be.load_weights(art["weights"], art["dilations"])
     be.set_precision(getattr(args, "precision", "fp32"))
     args._lm_loaded = False
+    be.set_logits(getattr(args, "logits", "f32"))
     if art["lm_table"] is not None:
-        be.load_lm(art["lm_table"], art["lm_k"])
+        if art.get("lm_hashed_order"):
+            be.load_lm_hashed(art["lm_table"], art["lm_hashed_order"], art["lm_k"])
+        else:
+            be.load_lm(art["lm_table"], art["lm_k"])
         args._lm_loaded = True
 
 

@@ -15,6 +15,9 @@ class OracleBackend:
     def set_precision(self, mode):
         pass   # the checker computes in float32 either way
 
+    def set_logits(self, mode):
+        assert mode in ("f32", 0)
+
     def load_weights(self, flat, dilations=(1, 2, 4, 8, 16, 32)):
         self.w = np.asarray(flat, dtype=np.float32)
         self.dil = tuple(dilations)
