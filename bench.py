@@ -200,12 +200,46 @@ def global_leg(device, batches_host, read_off, reads_per_batch, steps, W, table,
         run(0, steps)
         dt = time.perf_counter() - t0
         assert all(o[1].min() > 0 for o in outs)
+        # the same job in calls of 512 reads (8 bench batches side by side): 512 beam-search waves per call instead of 64 --
+        # the per-read serial chain (4096 time steps) is then a small part of a call
+        big = np.concatenate(batches_host * 2)[: 8 * reads_per_batch]
+        nb = big.shape[0]
+        off_b = np.arange(nb + 1, dtype=np.int64) * READ_LEN
+        lab_b, len_b = np.zeros(nb * READ_LEN + 1, dtype=np.uint8), np.zeros(nb, dtype=np.int32)
+        dbig = [b.dev_alloc(big.nbytes) for b in bes]
+        for b, p in zip(bes, dbig):
+            b.h2d(p, big)
+
+        def worker_big(k, n):
+            try:
+                for _ in range(n):
+                    bes[k].basecall_reads_global_resident(dbig[k], off_b, nb, CHUNK, STEP, W, True, 0.5, 0.5, lab_b if k == 0 else lab_b.copy(),
+                                                          np.ascontiguousarray(off_b[:-1]), len_b if k == 0 else len_b.copy())
+                bes[k].sync()
+            except Exception as e:
+                err.append(e)
+
+        def run_big(n):
+            th = [threading.Thread(target=worker_big, args=(k, n)) for k in range(2)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if err:
+                raise err[0]
+        run_big(1)
+        t0 = time.perf_counter()
+        run_big(2)
+        dt_big = time.perf_counter() - t0
+        for b, p in zip(bes, dbig):
+            b.dev_free(p)
     finally:
         for b, d in zip(bes, bufs):
             for p in d:
                 b.dev_free(p)
             b.close()
     return {"value": steps * reads_per_batch * READ_LEN / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "value_calls_of_512_reads": 4 * nb * READ_LEN / dt_big,
             "config": desc + "; 64 reads x 4096 per step, --decode-type global, step 512; streamed forward + assembly (f64) + LM beam "
                              "search; 2 device contexts on 2 host threads (as radian_amd.basecall.run): a step's forward overlaps the "
                              "other context's beam search"}

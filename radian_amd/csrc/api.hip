@@ -98,8 +98,16 @@ extern "C" int rd_create(int device_id, rd_ctx** out)
     rd_ctx* ctx = new rd_ctx();
     ctx->device = device_id;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        int lo = 0, hi = 0;
+        e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->stream_hi, hipStreamNonBlocking, hi);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_chain, hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
         rd_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        if (ctx->stream_hi) (void)hipStreamDestroy(ctx->stream_hi);
         delete ctx;
         return RD_ERR_HIP;
     }
@@ -147,6 +155,11 @@ extern "C" int rd_destroy(rd_ctx* ctx)
                       &ctx->lm.storage, &ctx->lm.gate_storage};
     for (DevBuf* b : bufs) b->release();
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->stream_hi) {
+        (void)hipStreamSynchronize(ctx->stream_hi);
+        (void)hipStreamDestroy(ctx->stream_hi);
+    }
+    if (ctx->ev_chain) (void)hipEventDestroy(ctx->ev_chain);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RD_OK;
@@ -598,15 +611,20 @@ int decode_and_fetch(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t
     if (rc) return rc;
     if (ctx->ws_labels.reserve((size_t)sm.total_labels + 16)) return RD_ERR_NOMEM;
     uint8_t* d_labels = ctx->ws_labels.as<uint8_t>();
+    // everything queued on the context's stream so far (forward, assembly, metadata) precedes the beam search, which runs on
+    // the high-priority stream: with another context's forward filling the chip, its few waves are dispatched first
+    hipStream_t ds = ctx->stream_hi;
+    RD_HIP(hipEventRecord(ctx->ev_chain, ctx->stream));
+    RD_HIP(hipStreamWaitEvent(ds, ctx->ev_chain, 0));
     rc = rd_decode_dev(ctx, d_probs, is_f64, sm.d_seq_off, sm.d_seq_len, sm.d_node_off, sm.d_label_off, n_seq, sm.total_nodes, W,
-                       use_lm, s_thr, r_thr, d_labels, sm.d_label_len, best_score ? sm.d_score : nullptr, nullptr, sm.d_seq_off2,
+                       use_lm, s_thr, r_thr, d_labels, sm.d_label_len, best_score ? sm.d_score : nullptr, ds, sm.d_seq_off2,
                        sm.d_split);
     if (rc) return rc;
     std::vector<uint8_t> hl((size_t)sm.total_labels + 16);
-    RD_HIP(hipMemcpyAsync(hl.data(), d_labels, (size_t)sm.total_labels, hipMemcpyDeviceToHost, ctx->stream));
-    RD_HIP(hipMemcpyAsync(label_len, sm.d_label_len, (size_t)n_seq * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (best_score) RD_HIP(hipMemcpyAsync(best_score, sm.d_score, (size_t)n_seq * 8, hipMemcpyDeviceToHost, ctx->stream));
-    RD_HIP(hipStreamSynchronize(ctx->stream));
+    RD_HIP(hipMemcpyAsync(hl.data(), d_labels, (size_t)sm.total_labels, hipMemcpyDeviceToHost, ds));
+    RD_HIP(hipMemcpyAsync(label_len, sm.d_label_len, (size_t)n_seq * 4, hipMemcpyDeviceToHost, ds));
+    if (best_score) RD_HIP(hipMemcpyAsync(best_score, sm.d_score, (size_t)n_seq * 8, hipMemcpyDeviceToHost, ds));
+    RD_HIP(hipStreamSynchronize(ds));
     for (int i = 0; i < n_seq; i++) {
         if (label_len[i] < 0 || label_len[i] > seq_len[i]) {
             rd_set_error("decode: sequence %d produced an impossible label length %d (rows %d)", i, label_len[i], seq_len[i]);

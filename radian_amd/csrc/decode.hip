@@ -649,7 +649,7 @@ extern "C" int rd_decode_max_width(void) { return Cfg<4>::WM; }
 
 // Per-context gate bits: bit = (entropy(lm[ctx]) < r_threshold)   decode.py:85-93.
 // The entropies were computed once at rd_load_lm (glibc log, like the reference's math.log) and live in HBM.
-static int ensure_lm_gate(rd_ctx* ctx, double r_thr)
+static int ensure_lm_gate(rd_ctx* ctx, double r_thr, hipStream_t st)
 {
     LM& lm = ctx->lm;
     if (lm.gate_valid && lm.gate_r_thr == r_thr) return RD_OK;
@@ -659,7 +659,7 @@ static int ensure_lm_gate(rd_ctx* ctx, double r_thr)
     lm.gate_bits = (uint32_t*)lm.gate_storage.p;
     const int threads = 256;
     const int blocks = (int)((words + threads - 1) / threads);
-    hipLaunchKernelGGL(lm_gate_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, lm.d_entropy, n, r_thr, lm.gate_bits);
+    hipLaunchKernelGGL(lm_gate_kernel, dim3(blocks), dim3(threads), 0, st, lm.d_entropy, n, r_thr, lm.gate_bits);
     RD_HIP(hipGetLastError());
     lm.gate_valid = true;
     lm.gate_r_thr = r_thr;
@@ -679,7 +679,7 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_
             rd_set_error("decode with use_lm=1 but no LM table loaded (rd_load_lm)");
             return RD_ERR_STATE;
         }
-        int rc = ensure_lm_gate(ctx, r_thr);
+        int rc = ensure_lm_gate(ctx, r_thr, st);
         if (rc) return rc;
     }
     if (ctx->ws_nodes_child.reserve((size_t)total_nodes * sizeof(int4))) return RD_ERR_NOMEM;
