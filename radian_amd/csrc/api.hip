@@ -927,6 +927,11 @@ int plan_reads_chunk(const Model& m, const int64_t* read_off, int n_reads, int c
     P.per_layer = true;
     int64_t row = 0;
     P.read_win_off.assign(1, 0);
+    // A layer's tile list holds the streams of ALL reads first, then the heads: workgroups are dispatched in list order as
+    // slots free up, so the full 128-row stream tiles fill the rounds and the short head tiles (few rows, waves without rows
+    // skip their MFMAs) make up the last, partial round -- longest-processing-time-first.  (Tiles of one launch are
+    // independent: a head reads its later rows from the layer's INPUT tensor.)
+    std::vector<TileDesc> heads[RD_MAX_LAYERS];
     for (int r = 0; r < n_reads; r++) {
         const int64_t N = read_off[r + 1] - read_off[r];
         RD_REQUIRE(N >= 1, "read %d is empty", r);
@@ -946,7 +951,7 @@ int plan_reads_chunk(const Model& m, const int64_t* read_off, int n_reads, int c
                 for (int li = 0; li < P.n_layers; li++) {
                     const int len = lh[li].h_out < valid ? lh[li].h_out : valid;   // rows of this head the layer must produce
                     if (len > 0)
-                        add_segment(P.tiles[li], P.rows[li], row, read_off[r] + (int64_t)i * step, len, valid, alt, lh[li].h_in, lh[li].h_res);
+                        add_segment(heads[li], P.rows[li], row, read_off[r] + (int64_t)i * step, len, valid, alt, lh[li].h_in, lh[li].h_res);
                 }
                 row += h;
             }
@@ -958,6 +963,7 @@ int plan_reads_chunk(const Model& m, const int64_t* read_off, int n_reads, int c
         P.n_windows += g.nW;
         P.read_win_off.push_back(P.n_windows);
     }
+    for (int li = 0; li < P.n_layers; li++) P.tiles[li].insert(P.tiles[li].end(), heads[li].begin(), heads[li].end());
     P.total_rows = row;
     return RD_OK;
 }

@@ -151,7 +151,10 @@ __device__ __forceinline__ void wave_sync()
 // decode.py:16-17
 __device__ __forceinline__ double safe_log(double x) { return x == 0.0 ? -INFINITY : log(x); }
 
-// One kept labeling, 64 B in LDS: a candidate lane fetches its parent with three 16-B reads.
+// One kept labeling, 64 B in LDS: a candidate lane fetches its parent with three 16-B reads.  (The 64-B stride makes the
+// 4-B / 8-B reads of one field of beams i and i + 2 / i + 4 share banks -- 27 % of the kernel's LDS cycles are conflict
+// cycles -- but padding the record to 80 B bought nothing at 512 sequences and cost residency at W = 25: the kernel is
+// bound by instruction issue and dependent-operation latency, not by the LDS.)
 struct __attribute__((aligned(16))) Beam {
     double ptot, pb;        //  0: pr_total, pr_blank          (log)
     double pnb;             // 16: pr_non_blank

@@ -273,7 +273,10 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
         // (store-issue bound, ~10 % of the kernel).  Instead each wave transposes its tile through a private LDS patch,
         // 32 rows x 64 channels at a time, and leaves with 16-B-per-lane accesses: 4 x 256-B row segments per
         // instruction, 32 store (and 32 residual load) instructions per lane instead of 128.
-        constexpr int TSTR = 68;                       // patch row stride in floats (64 + 4: conflict-free, 16-B aligned)
+        // patch row stride in floats.  64 = one 256-B bank row per patch row: a ds_read_b128 lane group (16 lanes: two quarter-rows of
+        // one patch row + one half-row of the next) then covers 64 distinct banks.  (Round 1's 68 put the second row's quarter on
+        // the first row's banks: 1.2-1.5 M conflict cycles per launch.)
+        constexpr int TSTR = 64;
         float* ts = smem + wave * (32 * TSTR);
         float4* sink4 = (float4*)a.sink + threadIdx.x;
         const int rrow = lane >> 4;                    // 0..3: row inside a 4-row store group
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
     __syncthreads();
 
     if constexpr (EPI != EPI_HEAD) {
-        constexpr int TSTR = 68;
+        constexpr int TSTR = 64;   // see the fp32 kernel
         float* ts = smem + wave * (32 * TSTR);
         f16x4* sinkh = (f16x4*)a.sink + 2 * threadIdx.x;
         const int rrow = lane >> 4;
@@ -857,7 +860,7 @@ __global__ __launch_bounds__(512, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
     constexpr int STAGE_BYTES = (BM3 + BN) * RB;             // 48 KiB (conv) / 36 KiB (head)
     constexpr int NSTAGE = 3;
     constexpr int HEAD_FLOATS = BM3 * (RD_H + 1) + RD_H * 5 + 8;
-    constexpr int EPI_FLOATS = 8 * 32 * 68;
+    constexpr int EPI_FLOATS = 8 * 32 * 64;
     constexpr int STG_FLOATS = NSTAGE * STAGE_BYTES / 4;
     constexpr int SMEM_FLOATS = (EPI == EPI_HEAD && HEAD_FLOATS > STG_FLOATS) ? HEAD_FLOATS : (STG_FLOATS > EPI_FLOATS ? STG_FLOATS : EPI_FLOATS);
 
@@ -1063,7 +1066,7 @@ __global__ __launch_bounds__(512, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
 #endif
 
     if constexpr (EPI != EPI_HEAD) {
-        constexpr int TSTR = 68;
+        constexpr int TSTR = 64;   // see the fp32 kernel
         float* ts = smem + wave * (32 * TSTR);
         bf16x4* sinkh = (bf16x4*)a.sink + (threadIdx.x & 255);   // past-the-end rows store here (nobody reads it)
         const int rrow = lane >> 4;
