@@ -46,9 +46,10 @@ def build_parser():
     parser.add_argument("--gpus", default=1, type=int, help="shard reads over this many GPUs (one process each)")
     parser.add_argument("--device-contexts", default=2, type=int,
                         help="independent device contexts (streams) per GPU: batch i+1's forward overlaps batch i's beam search")
-    parser.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"],
-                        help="matrix products of the signal model: exact fp32 MFMA (default) or split-f16 products with fp32 "
-                             "accumulation (about 2x faster, same softmax error against a float64 reference; DESIGN.md 4.7)")
+    parser.add_argument("--precision", default="fp32", choices=["fp32", "f16x3", "bf16x3"],
+                        help="matrix products of the signal model: exact fp32 MFMA (default); split-f16 products (22-bit operands, fp32 "
+                             "accumulation, about 2x faster; DESIGN.md 4.7); three-term bf16 split (every fp32 operand exact, six bf16 "
+                             "MFMAs per product, about 1.4x faster; DESIGN.md 4.9)")
     parser.add_argument("--logits", default="f32", choices=["f32", "f16"],
                         help="storage of the softmax rows between the model and the decoder on the device: float32 (the reference's) or "
                              "float16 (not a reference option; BASELINE configs[4])")

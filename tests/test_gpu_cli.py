@@ -110,3 +110,36 @@ def test_cli_worker_path_with_rccl_single_rank(tmp_path, golden_dir):
     launch.run_multi_gpu(args, argv_b)
     assert _read_fasta(str(a_dir)) == _read_fasta(str(b_dir))
     assert len(_read_fasta(str(b_dir))) == 5
+
+
+def test_cli_cfg5_flags_f16_logits_and_hashed_long_context(tmp_path, golden_dir, oracle):
+    """the configs[4] flags end to end through the CLI: --logits f16 --lm-hashed-context --context-len 40 --beam-width 25 (global),
+    against the oracle's long-context decode of the f16-rounded GPU rows; and both precision flags reach the device."""
+    from radian_amd import Backend, basecall, weights, lm
+    from radian_amd.preprocess import mad_normalise, get_windows
+    ids, sig, in_dir, lm_path = _make_inputs(tmp_path, golden_dir)
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    basecall.main([in_dir, str(out_dir), "--sig-model", "synthetic:1234", "--sig-config", "none", "--rna-model", lm_path, "--step-size", "512",
+                   "--context-len", "40", "--lm-hashed-context", "--logits", "f16", "--beam-width", "25", "--sig-threshold", "0.0",
+                   "--rna-threshold", "5.0"])
+    got = _read_fasta(str(out_dir))
+    table, k = lm.load_json(lm_path)
+    be = Backend(0)
+    be.load_weights(weights.synthetic_weights(seed=1234))
+    exp = []
+    for r in ids:
+        win, pad = get_windows(mad_normalise(sig[r], 4), 1024, 512)
+        probs = be.forward(win.astype(np.float32)).astype(np.float16).astype(np.float32)
+        mat = oracle.assemble_matrices(probs, pad, 512)
+        lab = oracle.beam_search_batch(mat, [0], [mat.shape[0]], 25, table, 0.0, 5.0, 40, hash_order=k)[0]
+        exp.append((r, "".join("ACGT"[c] for c in lab)[::-1]))
+    be.close()
+    assert got == exp
+    with pytest.raises(KeyError):   # without the flag a context length that is not the model's stays the reference's KeyError
+        basecall.main([in_dir, str(out_dir), "--sig-model", "synthetic:1234", "--sig-config", "none", "--rna-model", lm_path, "--context-len", "40"])
+    out2 = tmp_path / "out2"
+    out2.mkdir()
+    basecall.main([in_dir, str(out2), "--decode-type", "chunk", "--beam-width", "3", "--step-size", "512", "--sig-model", "synthetic:7",
+                   "--sig-config", "none", "--rna-model", "None", "--precision", "bf16x3"])
+    assert len(_read_fasta(str(out2))) == 5
