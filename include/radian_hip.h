@@ -215,6 +215,9 @@ int rd_timer_enable(rd_ctx* ctx, int which, int max_launches); /* 0 disables */
 int rd_timer_read(rd_ctx* ctx, int which, double* total_ms, int* launches, double* flops, double* bytes);
 
 /* ---- multi-GPU start-up: one RCCL broadcast of weights + LM table over xGMI ------------------- */
+/* librccl can be loaded in this process (dlopen + symbol lookup; creates nothing).  Ranks other than the one that draws the
+ * unique id call this before the collective ncclCommInitRank, so that a rank without a usable librccl is known to everyone first. */
+int rd_rccl_probe(void);
 int rd_rccl_unique_id(uint8_t id_out[128]);                       /* rank 0, then shared out of band */
 int rd_rccl_init(rd_ctx* ctx, int rank, int nranks, const uint8_t id[128]);
 int rd_rccl_bcast_model(rd_ctx* ctx, int root);                   /* weights (+ LM when loaded on root) */

@@ -58,6 +58,7 @@ SIGNATURES = {
     "rd_pipe_flush": (c_i, [c_vp]),
     "rd_timer_enable": (c_i, [c_vp, c_i, c_i]),
     "rd_timer_read": (c_i, [c_vp, c_i, c_dp, ctypes.POINTER(c_i), c_dp, c_dp]),
+    "rd_rccl_probe": (c_i, []),
     "rd_rccl_unique_id": (c_i, [c_vp]),
     "rd_rccl_init": (c_i, [c_vp, c_i, c_i, c_vp]),
     "rd_rccl_bcast_model": (c_i, [c_vp, c_i]),

@@ -347,6 +347,10 @@ class Backend:
         return {"total_ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
 
     # ------------------------------------------------------------------ multi-GPU start-up
+    def rccl_probe(self):
+        """librccl loads in this process (no communicator, no bootstrap thread)."""
+        self._check(self._L.rd_rccl_probe())
+
     def rccl_unique_id(self):
         buf = (ctypes.c_uint8 * 128)()
         self._check(self._L.rd_rccl_unique_id(ctypes.cast(buf, ctypes.c_void_p)))

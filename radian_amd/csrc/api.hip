@@ -1807,6 +1807,8 @@ struct BcastHeader {
 
 }  // namespace
 
+extern "C" int rd_rccl_probe(void) { return rccl_load(); }
+
 extern "C" int rd_rccl_unique_id(uint8_t id_out[128])
 {
     RD_REQUIRE(id_out, "rd_rccl_unique_id: null argument");

@@ -179,7 +179,10 @@ def connect(be, rank, world, uid_file, allow_file_fallback=True, timeout=120.0, 
     rdv = Rendezvous(uid_file + ".rdv", rank, world, timeout)
     uid, mine = None, "ok"
     try:
-        uid = be.rccl_unique_id()          # dlopen(librccl) + ncclGetUniqueId: a purely local test on every rank
+        if rank == 0 or not hasattr(be, "rccl_probe"):
+            uid = be.rccl_unique_id()      # dlopen(librccl) + ncclGetUniqueId (starts the bootstrap root: rank 0 only)
+        else:
+            be.rccl_probe()                # dlopen(librccl) + symbols: a purely local test
     except Exception as e:
         mine = f"fail: {e}"
     if rank == 0 and uid is not None:
