@@ -388,6 +388,61 @@ def main():
 
     samples_per_step = reads_per_batch * READ_LEN  # input samples basecalled per step per GPU
     value = world * args.steps * samples_per_step / elapsed
+    # ---- roofline of the dominant kernel (dilated conv on fp32 MFMA), HIP events on the launch stream
+    roof = None
+    if rank == 0:
+        n_prof = 4
+        for i in range(2):   # the pass follows the timed region directly (same clock / thermal state), after two unrecorded steps
+            step(i)
+        be.timer_enable(RD_TIMER_CONV, 11 * n_prof)
+        be.timer_enable(RD_TIMER_DECODE, n_prof)
+        be.timer_enable(RD_TIMER_HEAD, n_prof)
+        for i in range(n_prof):
+            step(i)
+        be.sync()
+        tc = be.timer_read(RD_TIMER_CONV)
+        td = be.timer_read(RD_TIMER_DECODE)
+        th = be.timer_read(RD_TIMER_HEAD)
+        be.timer_enable(RD_TIMER_CONV, 0)
+        be.timer_enable(RD_TIMER_DECODE, 0)
+        be.timer_enable(RD_TIMER_HEAD, 0)
+        # algorithmic FLOPs of the timed launches as accounted by the library: 393 216 per evaluated time step; the
+        # streamed forward evaluates fewer rows in the early layers (a head only holds the rows its layer changes)
+        flop_per_launch = tc["flops"] / max(1, tc["launches"])
+        avg_s = tc["total_ms"] / max(1, tc["launches"]) * 1e-3
+        achieved = flop_per_launch / avg_s / 1e12
+        peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "f16x3": F16_MFMA_PEAK_TFLOPS / 3.0, "bf16x3": F16_MFMA_PEAK_TFLOPS / 6.0}[args.precision]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        tsrc = None
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get("conv_hbm_bytes_per_launch")
+                tsrc = f"profiles/traffic.json ({tj.get('source', 'offline rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE')}); not measured in this run"
+            except Exception:
+                traffic = None
+        conv_flops_per_step = tc["flops"] / n_prof   # the same batches and geometry as every step of the timed region
+        roof = {
+            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "frac": achieved / peak, "traffic": traffic, "traffic_source": tsrc,
+            "kernel": {"fp32": "tcn_gemm_kernel<4,3,*> (dilated causal conv 256->256, k=3, v_mfma_f32_32x32x2_f32)",
+                       "f16x3": "tcn_gemm_split_kernel<4,3,*> (same conv, 3 x v_mfma_f32_32x32x16_f16 per fp32 product; peak = 2516/3 TFLOP/s)",
+                       "bf16x3": "tcn_gemm_bf3_kernel<4,3,*> (same conv, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product; peak = 2516/6 TFLOP/s)"}[args.precision],
+            "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_s * 1e3, "launches_timed": tc["launches"],
+            # the fraction that refers to the TIMED REGION: all conv FLOPs the region issued / its wall time / the peak
+            # (includes the head, the C_in=1 layer, beam search tails and launch gaps as lost time)
+            "pipeline_frac": conv_flops_per_step * args.steps / elapsed / 1e12 / peak,
+            "pipeline_conv_tflops": conv_flops_per_step * args.steps / elapsed / 1e12,
+            "conv_ms_per_step": tc["total_ms"] / n_prof, "decode_ms_per_step": td["total_ms"] / n_prof,
+            "head_ms_per_step": th["total_ms"] / n_prof,
+            "timing": "frac/achieved: HIP events around every launch of a forward + beam search run on ONE stream after the timed "
+                      "region (launches back to back: the kernel's own duration; = profiles/*_kernel_stats.csv, taken with --lanes 1). "
+                      "In the timed region the launches of consecutive batches overlap on two lanes, so a launch's bracketed "
+                      "duration there also counts the time it shares the chip (profiles/*_kernel_stats_default_2lanes.csv); "
+                      "pipeline_frac is the timed region's own figure",
+            "decode_timesteps_per_s": float(sum(b[1].sum() for b in batches[:n_prof])) / max(1e-9, td["total_ms"] * 1e-3),
+        }
     # secondaries, reported beside the headline (one GPU, fp32 headline only): the same job in the other matrix-product
     # modes; configs[3]'s global + LM geometry; the raw-reads end-to-end driver loop
     sec = {}
@@ -438,60 +493,8 @@ def main():
     # probability rows produced per step: every window row (windowed) or every time step once + 7 window heads (streamed)
     rows_streamed = BATCH_WINDOWS * CHUNK if args.windowed else reads_per_batch * (READ_LEN + 7 * halo)
 
-    # ---- roofline of the dominant kernel (dilated conv on fp32 MFMA), HIP events on the launch stream
-    roof = None
     cpu = None
     if rank == 0:
-        n_prof = 2
-        be.timer_enable(RD_TIMER_CONV, 11 * n_prof)
-        be.timer_enable(RD_TIMER_DECODE, n_prof)
-        be.timer_enable(RD_TIMER_HEAD, n_prof)
-        for i in range(n_prof):
-            step(i)
-        be.sync()
-        tc = be.timer_read(RD_TIMER_CONV)
-        td = be.timer_read(RD_TIMER_DECODE)
-        th = be.timer_read(RD_TIMER_HEAD)
-        be.timer_enable(RD_TIMER_CONV, 0)
-        be.timer_enable(RD_TIMER_DECODE, 0)
-        be.timer_enable(RD_TIMER_HEAD, 0)
-        # algorithmic FLOPs of the timed launches as accounted by the library: 393 216 per evaluated time step; the
-        # streamed forward evaluates fewer rows in the early layers (a head only holds the rows its layer changes)
-        flop_per_launch = tc["flops"] / max(1, tc["launches"])
-        avg_s = tc["total_ms"] / max(1, tc["launches"]) * 1e-3
-        achieved = flop_per_launch / avg_s / 1e12
-        peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "f16x3": F16_MFMA_PEAK_TFLOPS / 3.0, "bf16x3": F16_MFMA_PEAK_TFLOPS / 6.0}[args.precision]
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        tsrc = None
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get("conv_hbm_bytes_per_launch")
-                tsrc = f"profiles/traffic.json ({tj.get('source', 'offline rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE')}); not measured in this run"
-            except Exception:
-                traffic = None
-        conv_flops_per_step = tc["flops"] / n_prof   # the same batches and geometry as every step of the timed region
-        roof = {
-            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "traffic": traffic, "traffic_source": tsrc,
-            "kernel": {"fp32": "tcn_gemm_kernel<4,3,*> (dilated causal conv 256->256, k=3, v_mfma_f32_32x32x2_f32)",
-                       "f16x3": "tcn_gemm_split_kernel<4,3,*> (same conv, 3 x v_mfma_f32_32x32x16_f16 per fp32 product; peak = 2516/3 TFLOP/s)",
-                       "bf16x3": "tcn_gemm_bf3_kernel<4,3,*> (same conv, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product; peak = 2516/6 TFLOP/s)"}[args.precision],
-            "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_s * 1e3, "launches_timed": tc["launches"],
-            # the fraction that refers to the TIMED REGION: all conv FLOPs the region issued / its wall time / the peak
-            # (includes the head, the C_in=1 layer, beam search tails and launch gaps as lost time)
-            "pipeline_frac": conv_flops_per_step * args.steps / elapsed / 1e12 / peak,
-            "pipeline_conv_tflops": conv_flops_per_step * args.steps / elapsed / 1e12,
-            "conv_ms_per_step": tc["total_ms"] / n_prof, "decode_ms_per_step": td["total_ms"] / n_prof,
-            "head_ms_per_step": th["total_ms"] / n_prof,
-            "timing": "frac/achieved: HIP events around every launch of a forward + beam search run on ONE stream after the timed "
-                      "region (launches back to back: the kernel's own duration; = profiles/*_kernel_stats.csv, taken with --lanes 1). "
-                      "In the timed region the launches of consecutive batches overlap on two lanes, so a launch's bracketed "
-                      "duration there also counts the time it shares the chip (profiles/*_kernel_stats_default_2lanes.csv); "
-                      "pipeline_frac is the timed region's own figure",
-            "decode_timesteps_per_s": float(sum(b[1].sum() for b in batches[:n_prof])) / max(1e-9, td["total_ms"] * 1e-3),
-        }
         if world == 1 and not args.no_cpu_baseline:
             cores = effective_cores()
             nr = args.cpu_reads or max(2, min(reads_per_batch, 4 * cores))   # ~10-20 s of CPU work, all usable cores busy

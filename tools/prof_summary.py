@@ -45,7 +45,7 @@ for k in ["conv_relu", "conv_res_ident", "conv_res_match"]:
     derived[k] = {"avg_ns_trace": dur.get(k), "cycles_per_xcd": cyc, "mfma_busy_cycles_per_simd": mf, "mfma_util": mf / cyc,
                   "eff_clock_ghz": cyc / dur[k] if k in dur else None,
                   "hbm_bytes": (2 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024}
-json.dump({"round": tag, "command": "tools/prof.sh (rocprofv3 --pmc <group>, one pass per counter group; python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --lanes 1; durations from the --kernel-trace pass of the same command)",
+json.dump({"round": tag, "command": "tools/prof.sh (rocprofv3 --pmc <group>, one pass per counter group; python3 bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-secondary --lanes 1; durations from the --kernel-trace pass of the same command)",
            "units": {"FETCH_SIZE": "KiB; gfx950 tallies 16-B-per-lane loads (incl. LDS-DMA) at half their bytes -> doubled in hbm_bytes",
                      "WRITE_SIZE": "KiB", "SQ_*": "quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES (cycles summed over SIMDs)",
                      "GRBM_GUI_ACTIVE": "cycles summed over 8 XCDs"},
