@@ -401,6 +401,47 @@ def gen_seq_assembly():
     print("seq_assembly:", len(cases), "cases")
 
 
+def gen_seq_assembly_random():
+    """Round 2: 160 random fragment lists through the reference's simple_assembly (incl. lists on which it raises
+    IndexError: its vote matrix grows by 1000 columns at most once per fragment).  Compact form: shape, consensus string
+    and a SHA-256 of the int64 vote matrix instead of the matrix."""
+    import hashlib
+    rng = np.random.default_rng(20260101)
+    cases = []
+
+    def rand_seq(n, alphabet=BASES):
+        return "".join(alphabet[i] for i in rng.integers(0, len(alphabet), size=n))
+
+    for ci in range(160):
+        kind = ci % 8
+        n = int(rng.integers(0, 8))
+        base = rand_seq(int(rng.integers(0, 900)))
+        frags, pos = [], 0
+        for _ in range(n):
+            if kind == 0 or not base:
+                f = rand_seq(int(rng.choice([0, 3, 40, 260, 450])), "ACGTacgt" if kind == 0 else BASES)
+            else:
+                pos = min(len(base), pos + int(rng.integers(0, 130)))
+                f = base[pos: pos + int(rng.integers(0, 430))]
+                if f and rng.random() < 0.5:
+                    i = int(rng.integers(0, len(f)))
+                    f = f[:i] + BASES[int(rng.integers(0, 4))] + f[i + 1:]
+            frags.append(f)
+        if kind == 7:   # provoke the fixed growth step
+            frags = [rand_seq(int(rng.integers(950, 1100)))] if ci % 16 == 7 else ["A" * int(rng.integers(900, 1000)), "C", "C" + rand_seq(int(rng.integers(900, 1200)))]
+        try:
+            cons = ref_seq.simple_assembly(frags)
+        except IndexError:
+            cases.append({"fragments": frags, "error": "IndexError"})
+            continue
+        seq = "" if cons.shape[1] == 0 else ref_seq.index2base(np.argmax(cons, axis=0))
+        cases.append({"fragments": frags, "consensus_shape": list(cons.shape), "seq": seq,
+                      "consensus_sha256": hashlib.sha256(np.ascontiguousarray(cons, dtype=np.int64).tobytes()).hexdigest()})
+    with open(os.path.join(HERE, "seq_assembly_random_cases.json"), "w") as f:
+        json.dump({"source": "radian/sequence_assembly.py:19-48,90-97 + basecall.py:122-123 (random lists, round 2)", "cases": cases}, f, indent=0)
+    print("seq_assembly_random:", len(cases), "cases,", sum("error" in c for c in cases), "IndexError")
+
+
 # ----------------------------------------------------------------------------------------------
 # 6. raw signals of the reference's sample fast5 (data fixture)
 # ----------------------------------------------------------------------------------------------
@@ -467,11 +508,16 @@ def gen_pipeline():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:       # regenerate single fixture sets: make_golden.py gen_seq_assembly_random ...
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     gen_beam_nolm()
     gen_beam_lm()
     gen_assemble()
     gen_preprocess()
     gen_seq_assembly()
+    gen_seq_assembly_random()
     gen_fast5_signals()
     gen_pipeline()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE))

@@ -42,6 +42,24 @@ def test_product_stitch_matches_golden(golden_dir):
         assert S.consensus_sequence(c["fragments"]) == c["seq"]
 
 
+def test_product_stitch_matches_reference_random_cases(golden_dir):
+    """160 random fragment lists generated through the reference's own simple_assembly (make_golden.py
+    gen_seq_assembly_random): vote matrix by SHA-256, consensus string, and the lists on which the reference raises"""
+    import hashlib
+    from radian_amd import sequence_assembly as S
+    g = json.load(open(os.path.join(golden_dir, "seq_assembly_random_cases.json")))
+    assert len(g["cases"]) == 160 and sum("error" in c for c in g["cases"]) >= 8
+    for i, c in enumerate(g["cases"]):
+        if "error" in c:
+            with pytest.raises(IndexError):
+                S.simple_assembly(c["fragments"])
+            continue
+        cons = S.simple_assembly(c["fragments"])
+        assert list(cons.shape) == c["consensus_shape"], i
+        assert hashlib.sha256(np.ascontiguousarray(cons, dtype=np.int64).tobytes()).hexdigest() == c["consensus_sha256"], i
+        assert S.consensus_sequence(c["fragments"]) == c["seq"], i
+
+
 def test_product_stitch_matches_oracle_hypothesis(oracle):
     """random fragment lists (overlapping, unrelated, empty, lower case, >= 200 characters = difflib autojunk, more than
     1000 columns = the reference's matrix growth) against the oracle's statement-level restatement of

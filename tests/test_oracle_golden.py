@@ -136,6 +136,20 @@ def test_seq_assembly(oracle, golden_dir):
         assert oracle.chunk_consensus(c["fragments"]) == c["seq"]
 
 
+def test_seq_assembly_random_cases(oracle, golden_dir):
+    import hashlib
+    g = _load(golden_dir, "seq_assembly_random_cases.json")
+    for i, c in enumerate(g["cases"]):
+        if "error" in c:
+            with pytest.raises(IndexError):
+                oracle.simple_assembly(c["fragments"])
+            continue
+        cons = oracle.simple_assembly(c["fragments"])
+        assert list(cons.shape) == c["consensus_shape"], i
+        assert hashlib.sha256(np.ascontiguousarray(cons, dtype=np.int64).tobytes()).hexdigest() == c["consensus_sha256"], i
+        assert oracle.chunk_consensus(c["fragments"]) == c["seq"], i
+
+
 # ------------------------------------------------------------------------------ decode side of basecall.py
 def test_pipeline_decode_side(oracle, golden_dir):
     g = _load(golden_dir, "pipeline_cases.json")
