@@ -96,6 +96,10 @@ int rd_load_lm_hashed(rd_ctx* ctx, const double* table, int table_order, int con
  * (10 B per time step; rounded to nearest by the head kernel, widened exactly by the decoder / assembly).  Not a
  * reference option (BASELINE configs[4] "fp16 logits"): labels equal the oracle's on the same f16-rounded rows. */
 int rd_set_logits(rd_ctx* ctx, int mode);
+/* Launch shape of the beam search for beam widths above 12 (no effect on results; no reference counterpart): 0 = chosen
+ * per launch (default: several waves per sequence while the launch leaves SIMDs idle, else two candidates per lane),
+ * 1 = always several waves per sequence, 2 = always two candidates per lane.  For tests and measurements. */
+int rd_set_decode_form(rd_ctx* ctx, int form);
 
 /* ---- the five seams, host-pointer form ----------------------------------------------------- */
 /* sig_model.predict(windows) -- radian/basecall.py:91,93.

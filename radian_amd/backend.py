@@ -110,6 +110,10 @@ class Backend:
         """'f32' (default) or 'f16': storage of the softmax rows on the reads-level paths (rd_set_logits)."""
         self._check(self._L.rd_set_logits(self._h, {"f32": 0, "f16": 1}[mode] if isinstance(mode, str) else int(mode)))
 
+    def set_decode_form(self, form):
+        """'auto' (default), 'waves' or 'lanes': launch shape of the beam search for widths above 12 (rd_set_decode_form)."""
+        self._check(self._L.rd_set_decode_form(self._h, {"auto": 0, "waves": 1, "lanes": 2}[form] if isinstance(form, str) else int(form)))
+
     # ------------------------------------------------------------------ seams (host arrays)
     def forward(self, windows):
         """sig_model.predict (radian/basecall.py:91,93): [n,T] -> [n,T,5] float32."""

@@ -97,6 +97,7 @@ extern "C" int rd_create(int device_id, rd_ctx** out)
     }
     rd_ctx* ctx = new rd_ctx();
     ctx->device = device_id;
+    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) {
         int lo = 0, hi = 0;
@@ -527,6 +528,14 @@ extern "C" int rd_set_logits(rd_ctx* ctx, int mode)
     RD_REQUIRE(ctx, "rd_set_logits: null context");
     RD_REQUIRE(mode == 0 || mode == 1, "rd_set_logits: mode %d (0 = float32 rows, 1 = float16 rows)", mode);
     ctx->logits_f16 = mode;
+    return RD_OK;
+}
+
+extern "C" int rd_set_decode_form(rd_ctx* ctx, int form)
+{
+    RD_REQUIRE(ctx, "rd_set_decode_form: null context");
+    RD_REQUIRE(form >= 0 && form <= 2, "rd_set_decode_form: form %d (0 = per launch, 1 = waves per sequence, 2 = candidates per lane)", form);
+    ctx->decode_form = form;
     return RD_OK;
 }
 

@@ -167,10 +167,10 @@ struct __attribute__((aligned(16))) Beam {
 };
 static_assert(sizeof(Beam) == 64, "Beam is one 64-B LDS record");
 
-template <int R>
+template <int R, int NW>
 struct Cfg {
-    static constexpr int NC = 64 * R;       // candidate capacity
-    static constexpr int WM = (64 * R) / 5; // max beam width
+    static constexpr int NC = 64 * R * NW;  // candidate capacity
+    static constexpr int WM = NC / 5;       // max beam width
 };
 
 struct DecodeArgs {
@@ -203,22 +203,49 @@ struct DecodeArgs {
     double* best_score;
 };
 
-// node id -> beam slot, one byte per entry, indexed by the low bits of the id.  Entries are never cleared: a hit is
-// verified against the live node array, so a stale byte is harmless.  Two kept beams whose ids collide in the table are
-// detected when the table is filled (once per step) and that step falls back to comparing against every beam.
-template <int R>
-struct Tab {
-    static constexpr int N = 512 * R;
-};
+// Hand-off between the waves of a sequence's workgroup.  One wave: see wave_sync.  Several waves: the LDS operations of
+// this wave have completed (lgkmcnt) and every wave has arrived -- again without vmcnt(0), so the trie stores stay in flight.
+// Every branch that contains a hand-off is taken by all waves or by none (its condition is computed from LDS data that
+// all waves read after the same hand-off).
+template <int NW>
+__device__ __forceinline__ void seq_sync()
+{
+    if constexpr (NW == 1) {
+        wave_sync();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
 
-template <typename PT, int R, bool LM, bool HC>
-__global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
+// node id -> beam slot: a table indexed by the low bits of the id; an entry is the rest of the id << 8 | the slot of the kept
+// beam that carries it.  Every kept beam enters itself every step (its slot changes), a labeling that is not kept
+// removes its entry, so a matching id is a kept labeling and one LDS round trip answers "is this extension already kept?".
+// Two kept beams whose ids collide in the table are detected (each beam checks that it finds itself) and that step falls
+// back to comparing against every beam.
+//
+// Candidate q = 5*i + k of a step lives in slot s of thread tid with q = s * (64 NW) + tid: NW waves of one workgroup
+// share a sequence (W <= 12: one wave; W <= 25: two; W <= 51: four), each with R slots per lane (R = 1 in the product;
+// R > 1 is the single-wave form of round 2's first half, kept for A/B builds).
+template <typename PT, int R, int NW, bool LM, bool HC>
+__global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
 {
     static_assert(LM || !HC, "hashed contexts only exist with an LM");
-    constexpr int WM = Cfg<R>::WM;
-    constexpr int NC = Cfg<R>::NC;
-    constexpr int TN = Tab<R>::N;
-    const int lane = threadIdx.x;
+    constexpr int WM = Cfg<R, NW>::WM;
+    constexpr int TPB = 64 * NW;
+    constexpr int NS = R * NW;          // key segments: one per (slot, wave), in insertion order
+    // keys per pass of the ranking loop (all their LDS reads are in flight together): 16 shortens a lone wave's step (one
+    // round trip for <= 16 survivors); with R slots per lane the 32 key registers would cost residency, which is what the
+    // R > 1 form is for (many sequences)
+    constexpr int KG = R == 1 ? 16 : 4;
+    constexpr int SEG = 64 + KG;        // doubles per segment: 64 keys + the padding of the last group
+    constexpr int LOG_TN = R * NW <= 2 ? 9 : 10;
+    constexpr int TN = 1 << LOG_TN;     // (LDS per sequence bounds the resident waves: 2 KiB / 4 KiB)
+    static_assert(WM < 64, "the kept beams fit the lanes of one wave");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
     const int seq = blockIdx.x;
     const int T = a.seq_len[seq];
     const PT* __restrict__ probs = (const PT*)a.probs;
@@ -231,18 +258,30 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
     const unsigned ctx_mask = LM ? ((a.k >= 16) ? 0xffffffffu : ((1u << (2 * a.k)) - 1u)) : 0u;
 
     __shared__ Beam st[2][WM];
-    __shared__ double cpy_pnb[WM], cpy_pb[WM], mb_v[WM], mP[WM], mQ[WM];
+    // per-beam scratch of the merge phases (5 x WM doubles) and the ranking's key segments.  One wave: the keys overlay the
+    // scratch (they are written after its last read in program order, and LDS operations of a wave execute in order); the
+    // footprint decides how many sequences stay resident per CU.
+    constexpr int SCR = 5 * WM, KEYS = NS * SEG;
+    __shared__ __attribute__((aligned(16))) double dbuf[NW == 1 ? (SCR > KEYS ? SCR : KEYS) : SCR + KEYS + (SCR & 1)];
+    double* const cpy_pnb = dbuf;
+    double* const cpy_pb = dbuf + WM;
+    double* const mb_v = dbuf + 2 * WM;
+    double* const mP = dbuf + 3 * WM;
+    double* const mQ = dbuf + 4 * WM;
+    double* const keyC = NW == 1 ? dbuf : dbuf + SCR + (SCR & 1);   // 16-B aligned: keys of the ranking's survivors, compacted per segment
     __shared__ int mb_q[WM];
-    __shared__ int d_copy[WM], d_par[WM], d_c[WM], rk_owner[WM], newslot[WM];
+    __shared__ int d_sel[WM], newslot[WM];   // d_sel: who fills new slot r = (copied beam or 0xff) | parent beam << 8 | (1 + label) << 16
+    __shared__ unsigned claims[WM];
     __shared__ double lp[64][5];
     __shared__ double praw[LM ? 64 : 1][5];
     __shared__ double sent[LM ? 64 : 1];
-    __shared__ __attribute__((aligned(16))) double keyC[NC + 4];   // keys of the ranking's survivors, compacted in insertion order
-    __shared__ unsigned char tabslot[TN];
+    __shared__ int seg_s[NS], seg_v[NS], mflag[NW];
+    __shared__ unsigned tab[TN];
     __shared__ __attribute__((aligned(16))) unsigned ring[2][HC ? WM : 1][16];   // long contexts: the last 256 labels of each beam, 2 bits each
 
+    for (int i = tid; i < TN; i += TPB) tab[i] = i == 0 ? 0u : 0xffffffffu;    // (the empty labeling: id 0 in slot 0)
     // decode.py:128-132: the empty labeling with pr_blank = pr_total = log(1)
-    if (lane == 0) {
+    if (tid == 0) {
         Beam& b = st[0][0];
         b.ptot = 0.0;
         b.pb = 0.0;
@@ -256,18 +295,17 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
         for (int c = 0; c < 4; c++) b.child[c] = 0;
         childtab[0] = make_int4(0, 0, 0, 0);
         backptr[0] = 0;
-        tabslot[0] = 0;
     }
-    int nb = 1;              // beams currently kept (wave-uniform)
-    int next_id = 1;         // next free trie node id (wave-uniform)
+    int nb = 1;              // beams currently kept (workgroup-uniform)
+    int next_id = 1;         // next free trie node id (wave 0)
     int cur = 0;
-    wave_sync();
+    seq_sync<NW>();
 
     for (int t0 = 0; t0 < T; t0 += 64) {
         // ---- per-tile prepass: one lane per time step computes the 5 log-probabilities (decode.py:165,168,193,195
         //      take math.log of mat[t][c]) and, with an LM, the entropy of the renormalised base distribution
         //      (decode.py:135-138).
-        {
+        if (NW == 1 || wv == 0) {
             const int t = t0 + lane;
             if (t < T) {
                 double p[5];
@@ -298,7 +336,7 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                 }
             }
         }
-        wave_sync();
+        seq_sync<NW>();
 
         const int tend = (T - t0) < 64 ? (T - t0) : 64;
         for (int tt = 0; tt < tend; tt++) {
@@ -307,33 +345,64 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
             const int ncand = 5 * nb;
 
             // ---------------- Phase A: candidate scores; which extension equals which kept labeling? -------------
-            // Written without divergent branches: every lane issues the same LDS reads (clamped indices) and selects.
+            // A time step is a chain of LDS round trips; the reads are written unconditionally (clamped indices, results
+            // selected afterwards, no && / || over loads) so that each phase issues ONE batch of independent reads and
+            // waits once -- as conditional reads hipcc emits a wait and a branch per read.
             bool valid[R], is_copy[R];
             int bi[R], kk[R], pj[R], dcopy[R], xch[R];
             double c_ptot[R], c_pnb[R], c_pb[R];
+            // batch 1: the parent records, log p(blank), the weakest kept beam (ranking threshold), this lane's kept beam
             const double lp_blank = lp[tt][4];
-            // the node -> slot table resolves every kept beam iff each beam finds itself in it
-            const int myn = st[cur][lane < nb ? lane : 0].node;
-            const bool tab_ok = !__any(lane < nb && tabslot[myn & (TN - 1)] != (unsigned char)lane);
+            const double ptot_last = os[nb - 1].ptot;
+            const int myn = os[lane < nb ? lane : 0].node;
+            double2 pp[R];
+            double pnb_i[R];
+            int2 ll[R];
+            int chx[R];
 #pragma unroll
             for (int s = 0; s < R; s++) {
-                const int q = s * 64 + lane;
+                const int q = s * TPB + tid;
                 valid[s] = q < ncand;
                 const int i = valid[s] ? q / 5 : 0;
                 const int k = q - 5 * (q / 5);
                 bi[s] = i;
                 kk[s] = k;
                 is_copy[s] = k == 0;
-                const double2 pp = *(const double2*)&os[i].ptot;               // pr_total, pr_blank
-                const double pnb_i = os[i].pnb;
-                const int2 ll = *(const int2*)&os[i].last;                     // last, len
-                const int last_i = ll.x, len_i = ll.y;
-                const int chx = os[i].child[(k - 1) & 3];
-                const int c = is_copy[s] ? last_i : k - 1;  // label whose probability this candidate consumes
-                double lpc = lp[tt][c < 0 ? 0 : c];
-                lpc = c < 0 ? -INFINITY : lpc;
+                pp[s] = *(const double2*)&os[i].ptot;               // pr_total, pr_blank
+                pnb_i[s] = os[i].pnb;
+                ll[s] = *(const int2*)&os[i].last;                   // last, len
+                // (all four child ids from the record's base address and a select: as a 4-B read at a computed address hipcc
+                // issues it after the wait for the reads above -- one more round trip)
+                int4 c4 = *(const int4*)&os[i].child[0];
+                asm("" : "+v"(c4.x), "+v"(c4.y), "+v"(c4.z), "+v"(c4.w));   // (opaque: or the select below becomes four conditional reads)
+                const int ci = (k - 1) & 3;
+                const int c_lo = (ci & 1) ? c4.y : c4.x, c_hi = (ci & 1) ? c4.w : c4.z;
+                chx[s] = (ci & 2) ? c_hi : c_lo;
+            }
+            if (tid < W) claims[tid] = 0u;
+            // batch 2: log p(label), the id-table probe of the extension's child id, and every kept beam looks itself up: the
+            // table resolves all kept beams iff each finds itself (every wave checks all beams)
+            const unsigned my_e = tab[myn & (TN - 1)];
+            double lpc[R];
+            unsigned p_e[R];
+#pragma unroll
+            for (int s = 0; s < R; s++) {
+                const int c = is_copy[s] ? ll[s].x : kk[s] - 1;     // label whose probability this candidate consumes
+                lpc[s] = lp[tt][c < 0 ? 0 : c];
+                lpc[s] = c < 0 ? -INFINITY : lpc[s];
+                const int x = (valid[s] & !is_copy[s]) ? chx[s] : 0;
+                xch[s] = x;
+                p_e[s] = tab[x & (TN - 1)];
+            }
+            const bool tab_ok = !__any((lane < nb) & (my_e != ((((unsigned)myn >> LOG_TN) << 8) | (unsigned)lane)));
+#pragma unroll
+            for (int s = 0; s < R; s++) {
+                const int i = bi[s], k = kk[s];
+                const int last_i = ll[s].x;
                 if constexpr (LM) {
                     // decode.py:157-163 (copy: context excludes the last label) and :180-184 (extend)
+                    const int len_i = ll[s].y;
+                    const int c = is_copy[s] ? last_i : k - 1;
                     const int need = is_copy[s] ? a.k + 1 : a.k;
                     if (valid[s] && c >= 0 && len_i >= need) {
                         unsigned ctx;
@@ -359,31 +428,26 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                                 const double sb = praw[tt][c] / bp;
                                 val = ((r + sb) / 2.0) * bp;
                             }
-                            lpc = safe_log(val);
+                            lpc[s] = safe_log(val);
                         }
                     }
                 }
                 // COPY decode.py:150-175 / EXTEND decode.py:186-201
-                const double pnb_c = (last_i >= 0) ? pnb_i + lpc : -INFINITY;
-                const double pb_c = pp.x + lp_blank;
-                const double v = ((last_i == k - 1) ? pp.y : pp.x) + lpc;
+                const double pnb_c = (last_i >= 0) ? pnb_i[s] + lpc[s] : -INFINITY;
+                const double pb_c = pp[s].x + lp_blank;
+                const double v = ((last_i == k - 1) ? pp[s].y : pp[s].x) + lpc[s];
                 c_pnb[s] = is_copy[s] ? pnb_c : v;
                 c_pb[s] = is_copy[s] ? pb_c : -INFINITY;
                 c_ptot[s] = is_copy[s] ? 0.0 : v;            // copies: lae(pb_c, pnb_c) below
                 dcopy[s] = is_copy[s] ? i : -1;
-                if (valid[s] && is_copy[s]) {
+                if (valid[s] & is_copy[s]) {
                     cpy_pnb[i] = pnb_c;
                     cpy_pb[i] = pb_c;
                     mb_q[i] = -1;
                     newslot[i] = -1;
                 }
-                // the labeling "beam i + label" is already kept iff its trie id is some kept beam's id
-                const int x = (valid[s] && !is_copy[s]) ? chx : 0;
-                xch[s] = x;
-                int sl = tabslot[x & (TN - 1)];
-                sl = sl < WM ? sl : WM - 1;
-                const int nd = os[sl].node;
-                pj[s] = (tab_ok && x != 0 && sl < nb && nd == x) ? sl : -1;
+                // the labeling "beam i + label" is already kept iff its trie id is in the id table
+                pj[s] = (tab_ok & (xch[s] != 0) & ((p_e[s] >> 8) == ((unsigned)xch[s] >> LOG_TN))) ? (int)(p_e[s] & 0xffu) : -1;
             }
             if (!tab_ok) {   // two kept beams share a table entry (rare): compare against every beam
                 for (int j = 0; j < nb; j++) {
@@ -393,11 +457,23 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                         if (xch[s] != 0 && nj == xch[s]) pj[s] = j;
                 }
             }
-            wave_sync();
+            // does any extension of the step merge into a kept labeling?  (workgroup-uniform: the branch below holds hand-offs)
+            bool any_merge = false;
+#pragma unroll
+            for (int s = 0; s < R; s++) any_merge |= __any(pj[s] >= 0);
+            if constexpr (NW > 1) {
+                if (lane == 0) mflag[wv] = any_merge ? 1 : 0;
+            }
+            seq_sync<NW>();
+            if constexpr (NW > 1) {
+                int m = 0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) m |= mflag[w];
+                any_merge = __builtin_amdgcn_readfirstlane(m) != 0;
+            }
 
             // ---------------- lae pass 1: copies: pr_total = logaddexp(pr_blank, pr_non_blank) (decode.py:174-175);
             //                  merging extensions: pr_non_blank of the merged entry = logaddexp(copy.pnb, v) (decode.py:199)
-            bool any_merge = false;
 #pragma unroll
             for (int s = 0; s < R; s++) {
                 const bool mext = pj[s] >= 0;
@@ -407,43 +483,39 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                 const double r = lae(x, y);
                 c_ptot[s] = is_copy[s] ? r : c_ptot[s];
                 if (mext) {
-                    mb_q[pj[s]] = s * 64 + lane;
+                    mb_q[pj[s]] = s * TPB + tid;
                     mb_v[pj[s]] = c_ptot[s];
                     mQ[pj[s]] = r;
                 }
-                any_merge |= __any(mext);
             }
             if (any_merge) {
-                wave_sync();
+                seq_sync<NW>();
                 // ---------- lae pass 2: pr_total of the merged entry = logaddexp(copy.total, v) (decode.py:200-201), by the copy's lane
 #pragma unroll
                 for (int s = 0; s < R; s++) {
                     const int qe = mb_q[bi[s]];
                     const double mv = mb_v[bi[s]];
-                    const bool m = valid[s] && is_copy[s] && qe >= 0;
+                    const bool m = valid[s] & is_copy[s] & (qe >= 0);
                     const double r = lae(c_ptot[s], m ? mv : -INFINITY);
                     if (m) mP[bi[s]] = r;
                 }
-                wave_sync();
+                seq_sync<NW>();
                 // the merged entry lives in whichever of the two candidates was inserted first (dict order); the other is gone
 #pragma unroll
                 for (int s = 0; s < R; s++) {
-                    const int q = s * 64 + lane;
+                    const int q = s * TPB + tid;
                     const int j = is_copy[s] ? bi[s] : (pj[s] >= 0 ? pj[s] : 0);      // the copy's beam
                     const int qe = mb_q[j];
                     const double P = mP[j], Q = mQ[j], cb = cpy_pb[j];
-                    const bool merged = valid[s] && (is_copy[s] ? qe >= 0 : pj[s] >= 0);
+                    const bool merged = valid[s] & (is_copy[s] ? qe >= 0 : pj[s] >= 0);
                     const int qother = is_copy[s] ? qe : 5 * j;
-                    const bool keep = q < qother;
-                    if (merged) {
-                        c_ptot[s] = keep ? P : c_ptot[s];
-                        c_pnb[s] = keep ? Q : c_pnb[s];
-                        if (!is_copy[s]) {
-                            c_pb[s] = keep ? cb : c_pb[s];
-                            dcopy[s] = keep ? j : dcopy[s];
-                        }
-                        valid[s] = keep;
-                    }
+                    const bool mk = merged & (q < qother);                           // merged and inserted first: holds the entry
+                    const bool mke = mk & !is_copy[s];
+                    c_ptot[s] = mk ? P : c_ptot[s];
+                    c_pnb[s] = mk ? Q : c_pnb[s];
+                    c_pb[s] = mke ? cb : c_pb[s];
+                    dcopy[s] = mke ? j : dcopy[s];
+                    valid[s] = valid[s] & (!merged | mk);
                 }
             }
 
@@ -451,41 +523,66 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
             // Only candidates that can reach the top W are ranked.  Every kept labeling survives this step as an entry
             // (its copy, merged or not) whose pr_total >= pr_total_old + log p(blank) >= tau := the weakest kept beam's
             // pr_total + log p(blank): with W beams kept there are W entries >= tau, so an entry below tau is not among
-            // the best W.  The survivors' keys are compacted into LDS in insertion order and each survivor counts the
-            // keys ahead of it (16-B LDS broadcasts, two keys per read).
-            int nvalid = 0, S = 0;
+            // the best W.  The survivors' keys are compacted into LDS in insertion order -- one segment per (slot, wave),
+            // segments in order -- and each survivor counts the keys ahead of it (16-B LDS broadcasts, two keys per read).
             double key[R];
             bool surv[R];
-            int cidx[R];
-            const double tau = (nb == W) ? os[nb - 1].ptot + lp_blank : -INFINITY;
+            int lidx[R], scnt[R], vcnt[R];
+            const double tau = (nb == W) ? ptot_last + lp_blank : -INFINITY;
 #pragma unroll
             for (int s = 0; s < R; s++) {
                 key[s] = valid[s] ? c_ptot[s] : __builtin_nan("");
                 surv[s] = valid[s] && key[s] >= tau;
                 const unsigned long long mv = __ballot(valid[s]), ms = __ballot(surv[s]);
-                nvalid += __popcll(mv);
-                cidx[s] = S + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ms >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ms, 0u));
-                S += __popcll(ms);
+                vcnt[s] = __popcll(mv);
+                scnt[s] = __popcll(ms);
+                lidx[s] = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ms >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ms, 0u));
+                double* kseg = keyC + (s * NW + wv) * SEG;
+                if (lane < KG) kseg[scnt[s] + lane] = -INFINITY;  // padding of the last group
+                if (surv[s]) kseg[lidx[s]] = key[s];
+                if constexpr (NW > 1) {
+                    if (lane == 0) {
+                        seg_s[s * NW + wv] = scnt[s];
+                        seg_v[s * NW + wv] = vcnt[s];
+                    }
+                }
             }
-            if (lane < 4) keyC[S + lane] = -INFINITY;   // padding of the last group of four
+            seq_sync<NW>();
+            int segn[NS];     // survivors per segment (scalars)
+            int nvalid = 0;
 #pragma unroll
-            for (int s = 0; s < R; s++)
-                if (surv[s]) keyC[cidx[s]] = key[s];
-            wave_sync();
+            for (int g = 0; g < NS; g++) {
+                if constexpr (NW > 1) {
+                    segn[g] = __builtin_amdgcn_readfirstlane(seg_s[g]);
+                    nvalid += __builtin_amdgcn_readfirstlane(seg_v[g]);
+                } else {
+                    segn[g] = scnt[g];
+                    nvalid += vcnt[g];
+                }
+            }
             int rank[R];
 #pragma unroll
             for (int s = 0; s < R; s++) rank[s] = 0;
-            for (int j = 0; j < S; j += 4) {
-                const double2 ka = *(const double2*)&keyC[j], kb = *(const double2*)&keyC[j + 2];
 #pragma unroll
-                for (int s = 0; s < R; s++) rank[s] = count4_gt(rank[s], ka.x, ka.y, kb.x, kb.y, key[s]);
+            for (int g = 0; g < NS; g++) {
+                const double* kseg = keyC + g * SEG;
+                for (int j = 0; j < segn[g]; j += KG) {
+                    double2 kq[KG / 2];
+#pragma unroll
+                    for (int u = 0; u < KG / 2; u++) kq[u] = *(const double2*)&kseg[j + 2 * u];
+#pragma unroll
+                    for (int u = 0; u < KG / 4; u++)
+#pragma unroll
+                        for (int s = 0; s < R; s++)
+                            rank[s] = count4_gt(rank[s], kq[2 * u].x, kq[2 * u].y, kq[2 * u + 1].x, kq[2 * u + 1].y, key[s]);
+                }
             }
             const int nb_new = nvalid < W ? nvalid : W;
 
             // ---------------- Phase E: the kept candidates move to their new beam slot ------------------------
-            // The count above is of strictly greater keys: equal keys get the same count, so two candidates claiming one
-            // slot below W means a tie that matters; only then is the count redone with the insertion-order rule (exact 0
-            // probabilities make such ties; softmax rows do not) and the slots are written again.
+            // The count above is of strictly greater keys: equal keys get the same count, so a slot below nb_new that is
+            // not claimed exactly once means a tie that matters; only then is the count redone with the insertion-order
+            // rule (exact 0 probabilities make such ties; softmax rows do not) and the slots are written again.
             auto scatter = [&]() {
 #pragma unroll
                 for (int s = 0; s < R; s++) {
@@ -493,112 +590,131 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
                         const int r = rank[s];
                         *(double2*)&ns[r].ptot = make_double2(c_ptot[s], c_pb[s]);
                         ns[r].pnb = c_pnb[s];
-                        d_copy[r] = dcopy[s];
-                        d_par[r] = bi[s];
-                        d_c[r] = kk[s] - 1;
-                        rk_owner[r] = s * 64 + lane;
+                        d_sel[r] = (dcopy[s] & 0xff) | (bi[s] << 8) | (kk[s] << 16);
+                        atomicAdd(&claims[r], 1u);
                         if (dcopy[s] >= 0) newslot[dcopy[s]] = r;
                     }
                 }
             };
             scatter();
-            wave_sync();
-            bool tie = false;
-#pragma unroll
-            for (int s = 0; s < R; s++) tie |= surv[s] && rank[s] < W && rk_owner[rank[s]] != s * 64 + lane;
-            if (__any(tie)) {
+            seq_sync<NW>();
+            // one batch: the claim counts, Phase F's input, and what an old beam needs to know to leave the id table
+            const unsigned n_claims = claims[lane < nb_new ? lane : 0];
+            int sel = d_sel[lane < nb_new ? lane : 0];
+            int my_newslot = newslot[lane < nb ? lane : 0];
+            unsigned my_tn2 = tab[myn & (TN - 1)];
+            asm volatile("" : "+v"(sel), "+v"(my_newslot), "+v"(my_tn2));   // (all four requested before the tie branch)
+            if (__any((lane < nb_new) & (n_claims != 1u))) {      // (every wave looks at all slots: workgroup-uniform)
 #pragma unroll
                 for (int s = 0; s < R; s++) rank[s] = 0;
-                for (int j = 0; j < S; j++) {
-                    const double kv = keyC[j];
 #pragma unroll
-                    for (int s = 0; s < R; s++) rank[s] += ((kv > key[s]) || (kv == key[s] && j < cidx[s])) ? 1 : 0;
+                for (int g = 0; g < NS; g++) {
+                    const double* kseg = keyC + g * SEG;
+                    for (int j = 0; j < segn[g]; j++) {
+                        const double kv = kseg[j];
+#pragma unroll
+                        for (int s = 0; s < R; s++) {
+                            // insertion order = (segment, index in segment); this candidate's segment is s * NW + wv
+                            const bool before = g < s * NW + wv || (g == s * NW + wv && j < lidx[s]);
+                            rank[s] += ((kv > key[s]) || (kv == key[s] && before)) ? 1 : 0;
+                        }
+                    }
                 }
-                if (lane < nb) newslot[lane] = -1;      // the first attempt may have placed a labeling that is not kept after all
+                if (tid < nb) newslot[tid] = -1;      // the first attempt may have placed a labeling that is not kept after all
+                if constexpr (NW > 1) seq_sync<NW>();
                 scatter();
-                wave_sync();
+                seq_sync<NW>();
+                sel = d_sel[lane < nb_new ? lane : 0];
+                my_newslot = newslot[lane < nb ? lane : 0];
             }
 
-            // ---------------- Phase F: the new beam set: trie ids, labeling state ------------------------------
+            // ---------------- Phase F: the new beam set: trie ids, labeling state (wave 0) ----------------------
             // Lane r < nb_new builds beam r.  A copy takes its record from the old beam; an extension takes its parent's,
             // appends its label and gets its canonical id: the parent's child id if that child was ever created (its own
             // child ids then come back from the HBM trie), else a fresh id.  A fresh id is also patched into the parent's
             // NEW record when the parent is kept (newslot), so that child ids stay canonical.
-            const bool act = lane < nb_new;
-            const int j = act ? d_copy[lane] : 0;
-            const int par = act ? d_par[lane] : 0;
-            const int cl = act ? d_c[lane] : 0;
-            const bool is_ext = act && j < 0;
-            const int src = is_ext ? par : j;
-            const int4 meta = *(const int4*)&os[src].node;       // node, hist, pad, pad
-            const int2 ll = *(const int2*)&os[src].last;         // last, len
-            const int4 chs = *(const int4*)&os[src].child[0];
-            const int nid_old = os[src].child[cl & 3];           // (extensions: cl = the appended label)
-            const bool fresh = is_ext && nid_old == 0;
-            const bool reload = is_ext && nid_old != 0;
-            const unsigned long long fmask = __ballot(fresh);
-            const int my_node = fresh ? next_id + __popcll(fmask & ((1ull << lane) - 1ull)) : nid_old;
-            if (fresh) {
-                backptr[my_node] = (meta.x << 2) | cl;
-                ((int*)&childtab[meta.x])[cl] = my_node;
-                childtab[my_node] = make_int4(0, 0, 0, 0);
-            }
-            next_id += __popcll(fmask);
-            int4 ch = make_int4(0, 0, 0, 0);
-            if (__any(reload)) {
-                // a labeling that left the beam earlier and re-enters: fetch its child ids from the HBM trie
-                // (written by this same wave; drain our stores, read past the L1)
-                __builtin_amdgcn_s_waitcnt(0);
-                if (reload) {
-                    const int* cp = (const int*)&childtab[my_node];
-                    ch.x = __hip_atomic_load(cp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ch.y = __hip_atomic_load(cp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ch.z = __hip_atomic_load(cp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ch.w = __hip_atomic_load(cp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            if (act) {
-                const int new_node = is_ext ? my_node : meta.x;
-                *(int2*)&ns[lane].last = make_int2(is_ext ? cl : ll.x, is_ext ? ll.y + 1 : ll.y);
-                unsigned h_new = ((unsigned)meta.y << 2) | (unsigned)cl, hp_new = (unsigned)meta.z;
-                if constexpr (HC) {
-                    // the beam's label ring moves with it; an extension appends its label at position len (mod 256) and the
-                    // label k positions back leaves the hash window
-                    const uint4* rs = (const uint4*)ring[cur][src];
-                    uint4* rd = (uint4*)ring[cur ^ 1][lane];
-                    const uint4 r0 = rs[0], r1 = rs[1], r2 = rs[2], r3 = rs[3];
-                    rd[0] = r0;
-                    rd[1] = r1;
-                    rd[2] = r2;
-                    rd[3] = r3;
-                    const int len_p = ll.y;                                    // the parent's length (extensions)
-                    const int pout = (len_p - a.k) & 255, pin = len_p & 255;
-                    const unsigned wout = ring[cur][src][pout >> 4], win = ring[cur][src][pin >> 4];
-                    const unsigned lout = len_p >= a.k ? (wout >> ((pout & 15) * 2)) & 3u : 0u;
-                    if (is_ext) {
-                        const int sh = (pin & 15) * 2;
-                        ring[cur ^ 1][lane][pin >> 4] = (win & ~(3u << sh)) | ((unsigned)cl << sh);
-                    }
-                    h_new = (unsigned)meta.y * kHashB + (unsigned)cl - lout * a.bk;
-                    hp_new = is_ext ? (unsigned)meta.y : (unsigned)meta.z;
-                }
-                *(int4*)&ns[lane].node = make_int4(new_node, is_ext ? (int)h_new : meta.y, (int)hp_new, 0);
-                *(int4*)&ns[lane].child[0] = make_int4(is_ext ? ch.x : chs.x, is_ext ? ch.y : chs.y, is_ext ? ch.z : chs.z, is_ext ? ch.w : chs.w);
-                tabslot[new_node & (TN - 1)] = (unsigned char)lane;
-            }
-            if (fresh) {   // (after the record writes above in program order: LDS operations of a wave execute in order)
+            if (NW == 1 || wv == 0) {
+                const bool act = lane < nb_new;
+                const int j = act ? (sel & 0xff) : 0;                // copied beam (0xff: none)
+                const int par = act ? (sel >> 8) & 0xff : 0;
+                const int cl = act ? (sel >> 16) - 1 : 0;
+                const bool is_ext = act && j == 0xff;
+                const int src = is_ext ? par : j;
+                // one batch: the source record and the parent's new slot (for the patch at the end)
+                const int4 meta = *(const int4*)&os[src].node;       // node, hist, pad, pad
+                const int2 sl2 = *(const int2*)&os[src].last;        // last, len
+                const int4 chs = *(const int4*)&os[src].child[0];
+                const int nid_old = os[src].child[cl & 3];           // (extensions: cl = the appended label)
                 const int ps = newslot[par];
-                if (ps >= 0) ns[ps].child[cl] = my_node;
+                // a labeling that is not kept leaves the id table (before the new beams enter theirs: in-order LDS)
+                if ((lane < nb) & (my_newslot < 0) & ((my_tn2 >> 8) == ((unsigned)myn >> LOG_TN))) tab[myn & (TN - 1)] = 0xffffffffu;
+                const bool fresh = is_ext && nid_old == 0;
+                const bool reload = is_ext && nid_old != 0;
+                const unsigned long long fmask = __ballot(fresh);
+                const int my_node = fresh ? next_id + __popcll(fmask & ((1ull << lane) - 1ull)) : nid_old;
+                if (fresh) {
+                    backptr[my_node] = (meta.x << 2) | cl;
+                    ((int*)&childtab[meta.x])[cl] = my_node;
+                    childtab[my_node] = make_int4(0, 0, 0, 0);
+                }
+                next_id += __popcll(fmask);
+                int4 ch = make_int4(0, 0, 0, 0);
+                if (__any(reload)) {
+                    // a labeling that left the beam earlier and re-enters: fetch its child ids from the HBM trie
+                    // (written by this same wave; drain our stores, read past the L1)
+                    __builtin_amdgcn_s_waitcnt(0);
+                    if (reload) {
+                        const int* cp = (const int*)&childtab[my_node];
+                        ch.x = __hip_atomic_load(cp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ch.y = __hip_atomic_load(cp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ch.z = __hip_atomic_load(cp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ch.w = __hip_atomic_load(cp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    // the loads have landed before the block ends: no load is pending at the loop's back edge, so hipcc puts
+                    // no vmcnt wait (which would also wait for the trie STORES of the step) into the next step
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ch.x), "+v"(ch.y), "+v"(ch.z), "+v"(ch.w));
+                }
+                if (act) {
+                    const int new_node = is_ext ? my_node : meta.x;
+                    *(int2*)&ns[lane].last = make_int2(is_ext ? cl : sl2.x, is_ext ? sl2.y + 1 : sl2.y);
+                    unsigned h_new = ((unsigned)meta.y << 2) | (unsigned)cl, hp_new = (unsigned)meta.z;
+                    if constexpr (HC) {
+                        // the beam's label ring moves with it; an extension appends its label at position len (mod 256) and the
+                        // label k positions back leaves the hash window
+                        const uint4* rs = (const uint4*)ring[cur][src];
+                        uint4* rd = (uint4*)ring[cur ^ 1][lane];
+                        const uint4 r0 = rs[0], r1 = rs[1], r2 = rs[2], r3 = rs[3];
+                        rd[0] = r0;
+                        rd[1] = r1;
+                        rd[2] = r2;
+                        rd[3] = r3;
+                        const int len_p = sl2.y;                                   // the parent's length (extensions)
+                        const int pout = (len_p - a.k) & 255, pin = len_p & 255;
+                        const unsigned wout = ring[cur][src][pout >> 4], win = ring[cur][src][pin >> 4];
+                        const unsigned lout = len_p >= a.k ? (wout >> ((pout & 15) * 2)) & 3u : 0u;
+                        if (is_ext) {
+                            const int sh = (pin & 15) * 2;
+                            ring[cur ^ 1][lane][pin >> 4] = (win & ~(3u << sh)) | ((unsigned)cl << sh);
+                        }
+                        h_new = (unsigned)meta.y * kHashB + (unsigned)cl - lout * a.bk;
+                        hp_new = is_ext ? (unsigned)meta.y : (unsigned)meta.z;
+                    }
+                    *(int4*)&ns[lane].node = make_int4(new_node, is_ext ? (int)h_new : meta.y, (int)hp_new, 0);
+                    *(int4*)&ns[lane].child[0] = make_int4(is_ext ? ch.x : chs.x, is_ext ? ch.y : chs.y, is_ext ? ch.z : chs.z, is_ext ? ch.w : chs.w);
+                    tab[new_node & (TN - 1)] = (((unsigned)new_node >> LOG_TN) << 8) | (unsigned)lane;
+                }
+                // (after the record writes above in program order: LDS operations of a wave execute in order)
+                if (fresh && ps >= 0) ns[ps].child[cl] = my_node;
             }
             nb = nb_new;
             cur ^= 1;
-            wave_sync();
+            seq_sync<NW>();
         }
     }
 
     // ---------------- traceback of the best labeling (slot 0 = rank 0; decode.py:207-210) --------------------
-    __builtin_amdgcn_s_waitcnt(0);
-    if (lane == 0) {
+    if (tid == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
         const Beam& fs = st[cur][0];
         int n = fs.node;
         const int len = fs.len;
@@ -613,25 +729,36 @@ __global__ __launch_bounds__(64) void beam_search_kernel(DecodeArgs a)
     }
 }
 
-template <typename PT, int R>
+// Launch shape.  W <= 12: one wave per sequence.  Wider beams have two forms: several waves per sequence (two for W <= 25,
+// four for W <= 51; one candidate per lane) -- the shortest time step, for launches that leave SIMDs idle (global decode of
+// a batch of reads) -- and fewer waves with two candidates per lane, which issues fewer instructions per sequence and keeps
+// more sequences resident: the form for launches of thousands of sequences (chunk decode of a group of batches).
+// (rd_set_decode_form pins one form, for tests and measurements.)
+constexpr int kMaxW = Cfg<1, 4>::WM;
+static_assert(Cfg<2, 2>::WM == kMaxW, "both forms cover the same widths");
+
+template <typename PT, int R, int NW>
 int launch_r(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
 {
     if (lm && a.hashed)
-        hipLaunchKernelGGL((beam_search_kernel<PT, R, true, true>), dim3(n_seq), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((beam_search_kernel<PT, R, NW, true, true>), dim3(n_seq), dim3(64 * NW), 0, st, a);
     else if (lm)
-        hipLaunchKernelGGL((beam_search_kernel<PT, R, true, false>), dim3(n_seq), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((beam_search_kernel<PT, R, NW, true, false>), dim3(n_seq), dim3(64 * NW), 0, st, a);
     else
-        hipLaunchKernelGGL((beam_search_kernel<PT, R, false, false>), dim3(n_seq), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((beam_search_kernel<PT, R, NW, false, false>), dim3(n_seq), dim3(64 * NW), 0, st, a);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }
 
 template <typename PT>
-int launch_pt(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
+int launch_pt(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm, int n_simd, int form)
 {
-    if (a.W <= Cfg<1>::WM) return launch_r<PT, 1>(st, a, n_seq, lm);
-    if (a.W <= Cfg<2>::WM) return launch_r<PT, 2>(st, a, n_seq, lm);
-    return launch_r<PT, 4>(st, a, n_seq, lm);
+    if (a.W <= Cfg<1, 1>::WM) return launch_r<PT, 1, 1>(st, a, n_seq, lm);
+    // wide form while every wave still gets a SIMD of its own
+    const bool mid = a.W <= Cfg<1, 2>::WM;
+    const bool wide = form == 1 || (form == 0 && (long long)n_seq * (mid ? 2 : 4) <= n_simd);
+    if (mid) return wide ? launch_r<PT, 1, 2>(st, a, n_seq, lm) : launch_r<PT, 2, 1>(st, a, n_seq, lm);
+    return wide ? launch_r<PT, 1, 4>(st, a, n_seq, lm) : launch_r<PT, 2, 2>(st, a, n_seq, lm);
 }
 
 __global__ void lm_gate_kernel(const double* __restrict__ entropy, size_t n, double r_thr, uint32_t* __restrict__ bits)
@@ -648,7 +775,7 @@ __global__ void lm_gate_kernel(const double* __restrict__ entropy, size_t n, dou
 
 }  // namespace
 
-extern "C" int rd_decode_max_width(void) { return Cfg<4>::WM; }
+extern "C" int rd_decode_max_width(void) { return kMaxW; }
 
 // Per-context gate bits: bit = (entropy(lm[ctx]) < r_threshold)   decode.py:85-93.
 // The entropies were computed once at rd_load_lm (glibc log, like the reference's math.log) and live in HBM.
@@ -675,7 +802,7 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_
                   const int64_t* d_seq_off2, const int32_t* d_seq_split)
 {
     hipStream_t st = stream ? stream : ctx->stream;
-    RD_REQUIRE(W >= 1 && W <= Cfg<4>::WM, "beam_width %d out of range [1,%d]", W, Cfg<4>::WM);
+    RD_REQUIRE(W >= 1 && W <= kMaxW, "beam_width %d out of range [1,%d]", W, kMaxW);
     if (n_seq == 0) return RD_OK;
     if (use_lm) {
         if (!ctx->lm.loaded) {
@@ -711,8 +838,8 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_
     a.best_score = d_best_score;
     KernelTimer& tm = ctx->timer_decode;
     if (tm.enabled && tm.used < tm.starts.size()) RD_HIP(hipEventRecord(tm.starts[tm.used], st));
-    int rc = ptype == 1 ? launch_pt<double>(st, a, n_seq, use_lm != 0)
-             : ptype == 2 ? launch_pt<_Float16>(st, a, n_seq, use_lm != 0) : launch_pt<float>(st, a, n_seq, use_lm != 0);
+    int rc = ptype == 1 ? launch_pt<double>(st, a, n_seq, use_lm != 0, 4 * ctx->n_cu, ctx->decode_form)
+             : ptype == 2 ? launch_pt<_Float16>(st, a, n_seq, use_lm != 0, 4 * ctx->n_cu, ctx->decode_form) : launch_pt<float>(st, a, n_seq, use_lm != 0, 4 * ctx->n_cu, ctx->decode_form);
     if (rc) return rc;
     if (tm.enabled && tm.used < tm.starts.size()) {
         RD_HIP(hipEventRecord(tm.stops[tm.used], st));

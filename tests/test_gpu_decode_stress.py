@@ -74,6 +74,34 @@ def test_random_batches_match_oracle(be, oracle, kind):
                 assert best_gap <= 8 * np.finfo(np.float64).eps, (W, i, first, best_gap)
 
 
+@pytest.mark.parametrize("form", ["waves", "lanes"])
+def test_wide_beams_both_launch_forms_match_oracle(be, oracle, form):
+    """beam widths above 12 have two launch shapes (several waves per sequence / two candidates per lane, DESIGN.md 4.4);
+    the library picks by launch size, here each is pinned: every sequence label for label, with and without an LM,
+    f32 and f64 rows, widths on both sides of the 25 / 26 and 51 boundaries"""
+    rng = np.random.default_rng(11)
+    be.set_decode_form(form)
+    try:
+        for kind, dtype in (("flat", np.float32), ("blocky", np.float64), ("peaky", np.float32)):
+            mats, off, lens = _mats(rng, 160, 300, kind, dtype)
+            for W in (13, 20, 25, 26, 40, 51):
+                got = be.decode_batch(mats, off, lens, W)
+                exp = oracle.beam_search_batch(mats, off, lens, W)
+                bad = [i for i in range(len(lens)) if not np.array_equal(got[i], exp[i])]
+                assert not bad, (form, kind, W, bad[:5], len(bad))
+        table = rng.dirichlet([0.2] * 4, size=4 ** 3)
+        be.load_lm(table, 3)
+        mats, off, lens = _mats(rng, 120, 250, "flat", np.float64)
+        for W, s_thr, r_thr in ((13, 0.5, 0.5), (25, 0.0, 2.0), (30, 0.8, 0.9), (51, 0.5, 0.5)):
+            got = be.decode_batch(mats, off, lens, W, use_lm=True, s_threshold=s_thr, r_threshold=r_thr)
+            exp = oracle.beam_search_batch(mats, off, lens, W, table, s_thr, r_thr, 3)
+            bad = [i for i in range(len(lens)) if not np.array_equal(got[i], exp[i])]
+            assert not bad, (form, W, bad[:5], len(bad))
+    finally:
+        be.load_lm(None, 0)
+        be.set_decode_form("auto")
+
+
 def test_random_batches_with_lm_match_oracle(be, oracle):
     rng = np.random.default_rng(77)
     for k in (1, 2, 4):
