@@ -1,13 +1,13 @@
-// decode.hip -- CTC prefix beam search with the k-mer RNA-LM gate, one wavefront per sequence.
+// decode.hip -- CTC prefix beam search with the k-mer RNA-LM gate, one workgroup of 1-4 wavefronts per sequence.
 //
 // Replaces radian/decode.py:100-212 (beam_search) and :42-96 (LM gate) of the reference.
 //
-// Mapping to gfx950: a sequence is a T-long serial dependency chain, so each sequence gets ONE
-// 64-lane wave (workgroup = 1 wave; many waves per CU hide each other's latency).  Within a time
-// step the 5*W candidate entries (for each kept beam: its copy + 4 extensions, decode.py:150-201)
-// are spread over lanes: candidate q = 5*i + k lives in slot q/64 of lane q%64 (R slots per lane:
-// R=1 for W<=12, R=2 for W<=25, R=4 for W<=51).  Candidate order q is exactly the reference's dict
-// insertion order, which is what Python's stable sort falls back to on ties (decode.py:38).
+// Mapping to gfx950: a sequence is a T-long serial dependency chain, so each sequence gets ONE small
+// workgroup (a single 64-lane wave for W <= 12; many workgroups per CU hide each other's latency).
+// Within a time step the 5*W candidate entries (for each kept beam: its copy + 4 extensions,
+// decode.py:150-201) are spread over threads: candidate q = 5*i + k lives in slot q / (64 NW) of thread
+// q % (64 NW) (NW waves, R slots per lane; see launch_pt for the shapes).  Candidate order q is exactly
+// the reference's dict insertion order, which is what Python's stable sort falls back to on ties (decode.py:38).
 //
 // Exact labeling identity (the dict keyed by tuples, decode.py:171-201) is kept with a per-sequence
 // trie whose node ids are canonical: every kept beam carries the ids of its four children
@@ -17,9 +17,9 @@
 // child[c][i] == node[j]; the two probabilities are then combined with logaddexp exactly as the
 // reference does.  Back-pointers (parent<<2 | label) in HBM give the final labeling by traceback.
 //
-// Scores are float64 log-probabilities; log / log1p / exp are ROCm's double-precision device
-// functions (<= 1 ulp from glibc), so scores agree with the reference to a few ulp and the emitted
-// labeling is identical unless two beams tie within that distance.
+// Scores are float64 log-probabilities; log is ROCm's double-precision device function, logaddexp runs on
+// range-specific exp / log1p routines (below; all <= 1 ulp from glibc's), so scores agree with the reference
+// to a few ulp and the emitted labeling is identical unless two beams tie within that distance.
 #include "common.h"
 
 #include <math.h>
@@ -353,6 +353,9 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
             double c_ptot[R], c_pnb[R], c_pb[R];
             // batch 1: the parent records, log p(blank), the weakest kept beam (ranking threshold), this lane's kept beam
             const double lp_blank = lp[tt][4];
+            // the signal side of the LM gate (decode.py:91) is a property of the time step: closed, no candidate looks at the LM
+            bool s_open = false;
+            if constexpr (LM) s_open = __builtin_amdgcn_readfirstlane((int)(sent[tt] > a.s_thr)) != 0;
             const double ptot_last = os[nb - 1].ptot;
             const int myn = os[lane < nb ? lane : 0].node;
             double2 pp[R];
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
                     const int len_i = ll[s].y;
                     const int c = is_copy[s] ? last_i : k - 1;
                     const int need = is_copy[s] ? a.k + 1 : a.k;
-                    if (valid[s] && c >= 0 && len_i >= need) {
+                    if (s_open && valid[s] && c >= 0 && len_i >= need) {
                         unsigned ctx;
                         if constexpr (HC) {
                             ctx = (is_copy[s] ? os[i].hprev : os[i].hist) & a.tmask;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
                             const unsigned h = os[i].hist;
                             ctx = (is_copy[s] ? (h >> 2) : h) & ctx_mask;
                         }
-                        const bool gate = ((a.lm_gate[ctx >> 5] >> (ctx & 31)) & 1u) && (sent[tt] > a.s_thr);
+                        const bool gate = (a.lm_gate[ctx >> 5] >> (ctx & 31)) & 1u;
                         if (gate) {
                             // combine_dists decode.py:52-64
                             const double r = a.lm_table[(size_t)ctx * 4 + c];

@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd $R
 for LIBTAG in new old; do
   if [ $LIBTAG = old ]; then export RADIAN_HIP_LIB=$R/tools/variants/libradian_hip_r1decode.so; else unset RADIAN_HIP_LIB; fi
-  for CFG in "512 10 0" "512 10 1" "4096 10 0" "512 25 1"; do
+  for CFG in "512 10 0" "512 10 1" "4096 10 0" "512 25 1" "4096 25 1"; do
     NAME=${LIBTAG}_$(echo $CFG | tr ' ' '_')
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$NAME -- python3 tools/decode_prof_run.py $CFG > $OUT/trace_$NAME.log 2>&1
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_$NAME -- python3 tools/decode_prof_run.py $CFG > $OUT/pmc_$NAME.log 2>&1
