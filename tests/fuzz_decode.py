@@ -25,6 +25,8 @@ for r in range(rounds):
     mats, off, lens = _mats(rng, 800, 400, kind, dtype)
     W = int(rng.choice([1, 2, 5, 6, 10, 12, 13, 25, 26, 40]))
     s_thr, r_thr = float(rng.choice([0.0, 0.5, 0.8])), float(rng.choice([0.5, 0.9, 2.0]))
+    form = str(rng.choice(["auto", "waves", "lanes"]))     # launch shape for W > 12 (rd_set_decode_form)
+    be.set_decode_form(form)
     if use_lm:
         got = be.decode_batch(mats, off, lens, W, use_lm=True, s_threshold=s_thr, r_threshold=r_thr)
         exp = oracle.beam_search_batch(mats, off, lens, W, table, s_thr, r_thr, k)
@@ -34,6 +36,6 @@ for r in range(rounds):
     bad = [i for i in range(len(lens)) if not np.array_equal(got[i], exp[i])]
     total += len(lens)
     bad_total += len(bad)
-    print(f"round {r}: {kind} {dtype.__name__} W={W} lm={'k=%d' % k if use_lm else 'no'}: {len(bad)} of {len(lens)} differ ({time.time() - t0:.0f}s)", flush=True)
+    print(f"round {r}: {kind} {dtype.__name__} W={W} {form} lm={'k=%d' % k if use_lm else 'no'}: {len(bad)} of {len(lens)} differ ({time.time() - t0:.0f}s)", flush=True)
 print(f"done: {bad_total} of {total} sequences differ")
 sys.exit(1 if bad_total else 0)
