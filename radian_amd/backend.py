@@ -114,6 +114,10 @@ class Backend:
         """'auto' (default), 'waves' or 'lanes': launch shape of the beam search for widths above 12 (rd_set_decode_form)."""
         self._check(self._L.rd_set_decode_form(self._h, {"auto": 0, "waves": 1, "lanes": 2}[form] if isinstance(form, str) else int(form)))
 
+    def set_decode_math(self, mode):
+        """'fast' (default) or 'glibc': arithmetic of the beam search's log / logaddexp (rd_set_decode_math)."""
+        self._check(self._L.rd_set_decode_math(self._h, {"fast": 0, "glibc": 1}[mode] if isinstance(mode, str) else int(mode)))
+
     # ------------------------------------------------------------------ seams (host arrays)
     def forward(self, windows):
         """sig_model.predict (radian/basecall.py:91,93): [n,T] -> [n,T,5] float32."""

@@ -539,6 +539,14 @@ extern "C" int rd_set_decode_form(rd_ctx* ctx, int form)
     return RD_OK;
 }
 
+extern "C" int rd_set_decode_math(rd_ctx* ctx, int mode)
+{
+    RD_REQUIRE(ctx, "rd_set_decode_math: null context");
+    RD_REQUIRE(mode == 0 || mode == 1, "rd_set_decode_math: mode %d (0 = library routines, 1 = glibc's operation sequence)", mode);
+    ctx->decode_math = mode;
+    return RD_OK;
+}
+
 // --------------------------------------------------------------------------------------------- helpers
 namespace {
 

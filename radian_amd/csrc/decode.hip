@@ -21,10 +21,16 @@
 // range-specific exp / log1p routines (below; all <= 1 ulp from glibc's), so scores agree with the reference
 // to a few ulp and the emitted labeling is identical unless two beams tie within that distance.
 #include "common.h"
+#include "glibc_math.h"
+#include "glibc_tables.h"
 
 #include <math.h>
 
 namespace {
+
+// the "glibc" arithmetic mode's tables (glibc_math.h): exp's is copied into LDS per sequence, log's is read in place
+__device__ const uint64_t g_gm_exp_tab[256] = RD_GLIBC_EXP_TAB;
+__device__ const uint64_t g_gm_log_tab[256] = RD_GLIBC_LOG_TAB;
 
 constexpr unsigned kHashB = 0x9E3779B1u;   // odd multiplier of the context hash (long contexts)
 constexpr double kLogE2 = 0.693147180559945309417232121458176568;
@@ -137,6 +143,15 @@ __device__ __forceinline__ double lae(double x, double y)
     return x == y ? x + kLogE2 : r;    // (also the -inf / -inf case: lo - hi would be NaN)
 }
 
+// numpy npy_logaddexp on glibc 2.35's exp / log1p, operation for operation (glibc_math.h): bit-identical to the reference's
+// scores on an x86-64 FMA host.  T = the exp table in LDS.
+__device__ __forceinline__ double lae_gx(double x, double y, const uint64_t* T)
+{
+    const double hi = fmax(x, y), lo = fmin(x, y);
+    const double r = hi + gm_log1p(gm_exp(lo - hi, T));      // (lo - hi = -|x - y| exactly, as npy_logaddexp's tmp / -tmp)
+    return x == y ? x + kLogE2 : r;
+}
+
 // The workgroup IS one wave (launch bounds 64), so LDS hand-offs between lanes need no s_barrier and -- the point -- no
 // s_waitcnt vmcnt(0): __syncthreads() would also wait for the acknowledgement of the trie stores to HBM of every time
 // step (~1-2 us each on a loaded chip).  LDS operations of one wave execute in order; the fences keep the compiler from
@@ -149,7 +164,14 @@ __device__ __forceinline__ void wave_sync()
 }
 
 // decode.py:16-17
-__device__ __forceinline__ double safe_log(double x) { return x == 0.0 ? -INFINITY : log(x); }
+template <bool GX>
+__device__ __forceinline__ double log_m(double x)
+{
+    if constexpr (GX) return gm_log(x, g_gm_log_tab);
+    else return log(x);
+}
+template <bool GX>
+__device__ __forceinline__ double safe_log(double x) { return x == 0.0 ? -INFINITY : log_m<GX>(x); }
 
 // One kept labeling, 64 B in LDS: a candidate lane fetches its parent with three 16-B reads.  (The 64-B stride makes the
 // 4-B / 8-B reads of one field of beams i and i + 2 / i + 4 share banks -- 27 % of the kernel's LDS cycles are conflict
@@ -182,6 +204,7 @@ struct DecodeArgs {
     const int64_t* node_off;
     const int64_t* label_off;
     int W;
+    int glibc_math;       // rd_set_decode_math: 1 = log / exp / log1p as glibc 2.35 evaluates them (glibc_math.h)
     // LM
     const double* lm_table;
     const uint32_t* lm_gate;
@@ -228,7 +251,7 @@ __device__ __forceinline__ void seq_sync()
 // Candidate q = 5*i + k of a step lives in slot s of thread tid with q = s * (64 NW) + tid: NW waves of one workgroup
 // share a sequence (W <= 12: one wave; W <= 25: two; W <= 51: four), each with R slots per lane (R = 1 in the product;
 // R > 1 is the single-wave form of round 2's first half, kept for A/B builds).
-template <typename PT, int R, int NW, bool LM, bool HC>
+template <typename PT, int R, int NW, bool LM, bool HC, bool GX>
 __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
 {
     static_assert(LM || !HC, "hashed contexts only exist with an LM");
@@ -277,6 +300,9 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
     __shared__ double sent[LM ? 64 : 1];
     __shared__ int seg_s[NS], seg_v[NS], mflag[NW];
     __shared__ unsigned tab[TN];
+    __shared__ uint64_t gx_exp[GX ? 256 : 1];     // glibc arithmetic mode: exp's table
+    if constexpr (GX)
+        for (int i = tid; i < 256; i += TPB) gx_exp[i] = g_gm_exp_tab[i];
     __shared__ __attribute__((aligned(16))) unsigned ring[2][HC ? WM : 1][16];   // long contexts: the last 256 labels of each beam, 2 bits each
 
     for (int i = tid; i < TN; i += TPB) tab[i] = i == 0 ? 0u : 0xffffffffu;    // (the empty labeling: id 0 in slot 0)
@@ -312,7 +338,7 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
 #pragma unroll
                 for (int c = 0; c < 5; c++) p[c] = (double)probs[((t < split ? row_a : row_b) + t) * 5 + c];
 #pragma unroll
-                for (int c = 0; c < 5; c++) lp[lane][c] = safe_log(p[c]);
+                for (int c = 0; c < 5; c++) lp[lane][c] = safe_log<GX>(p[c]);
                 if constexpr (LM) {
 #pragma unroll
                     for (int c = 0; c < 5; c++) praw[lane][c] = p[c];
@@ -327,7 +353,7 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
                         else if constexpr (sizeof(PT) == 4) n = (double)((float)p[c] / (float)s);
                         else n = p[c] / s;
                         if (n > 0) {
-                            double v = n * log(n);
+                            double v = n * log_m<GX>(n);
                             ent = any ? ent + v : v;
                             any = true;
                         }
@@ -431,7 +457,7 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
                                 const double sb = praw[tt][c] / bp;
                                 val = ((r + sb) / 2.0) * bp;
                             }
-                            lpc[s] = safe_log(val);
+                            lpc[s] = safe_log<GX>(val);
                         }
                     }
                 }
@@ -483,7 +509,7 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
                 const double cp = cpy_pnb[mext ? pj[s] : 0];
                 const double x = mext ? cp : c_pb[s];
                 const double y = mext ? c_ptot[s] : c_pnb[s];
-                const double r = lae(x, y);
+                const double r = GX ? lae_gx(x, y, gx_exp) : lae(x, y);
                 c_ptot[s] = is_copy[s] ? r : c_ptot[s];
                 if (mext) {
                     mb_q[pj[s]] = s * TPB + tid;
@@ -499,7 +525,7 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
                     const int qe = mb_q[bi[s]];
                     const double mv = mb_v[bi[s]];
                     const bool m = valid[s] & is_copy[s] & (qe >= 0);
-                    const double r = lae(c_ptot[s], m ? mv : -INFINITY);
+                    const double r = GX ? lae_gx(c_ptot[s], m ? mv : -INFINITY, gx_exp) : lae(c_ptot[s], m ? mv : -INFINITY);
                     if (m) mP[bi[s]] = r;
                 }
                 seq_sync<NW>();
@@ -740,17 +766,23 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
 constexpr int kMaxW = Cfg<1, 4>::WM;
 static_assert(Cfg<2, 2>::WM == kMaxW, "both forms cover the same widths");
 
+template <typename PT, int R, int NW, bool GX>
+int launch_g(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
+{
+    if (lm && a.hashed)
+        hipLaunchKernelGGL((beam_search_kernel<PT, R, NW, true, true, GX>), dim3(n_seq), dim3(64 * NW), 0, st, a);
+    else if (lm)
+        hipLaunchKernelGGL((beam_search_kernel<PT, R, NW, true, false, GX>), dim3(n_seq), dim3(64 * NW), 0, st, a);
+    else
+        hipLaunchKernelGGL((beam_search_kernel<PT, R, NW, false, false, GX>), dim3(n_seq), dim3(64 * NW), 0, st, a);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
 template <typename PT, int R, int NW>
 int launch_r(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
 {
-    if (lm && a.hashed)
-        hipLaunchKernelGGL((beam_search_kernel<PT, R, NW, true, true>), dim3(n_seq), dim3(64 * NW), 0, st, a);
-    else if (lm)
-        hipLaunchKernelGGL((beam_search_kernel<PT, R, NW, true, false>), dim3(n_seq), dim3(64 * NW), 0, st, a);
-    else
-        hipLaunchKernelGGL((beam_search_kernel<PT, R, NW, false, false>), dim3(n_seq), dim3(64 * NW), 0, st, a);
-    RD_HIP(hipGetLastError());
-    return RD_OK;
+    return a.glibc_math ? launch_g<PT, R, NW, true>(st, a, n_seq, lm) : launch_g<PT, R, NW, false>(st, a, n_seq, lm);
 }
 
 template <typename PT>
@@ -826,6 +858,7 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_
     a.node_off = d_node_off;
     a.label_off = d_label_off;
     a.W = W;
+    a.glibc_math = ctx->decode_math;
     a.lm_table = use_lm ? ctx->lm.table : nullptr;
     a.lm_gate = use_lm ? ctx->lm.gate_bits : nullptr;
     a.k = use_lm ? ctx->lm.k : 0;

@@ -108,6 +108,7 @@ def worker(scratch, argv):
     comm.bcast_artifacts(be, lambda b: apply_artifacts(args, b, load_artifacts(args)))
     be.set_precision(args.precision)   # context state, not part of the broadcast images
     be.set_logits(args.logits)
+    be.set_decode_math(args.decode_math)
     args._lm_loaded = (args.rna_model != "None" and args.decode_type == "global" and os.path.exists(args.rna_model))
     with open(os.path.join(scratch, "files.json")) as f:
         sources = [fast5.Fast5Source(p) for p in json.load(f)]

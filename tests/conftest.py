@@ -25,3 +25,31 @@ def oracle():
     from oracle import oracle as orc
     orc.build()
     return orc
+
+
+def glibc_math_check_binary(force=False):
+    """tests/build/glibc_math_check: radian_amd/csrc/glibc_math.h compiled for the host, compared with the running libm
+    (tests/glibc_math_check.c).  Built with gcc when missing; None when it cannot be built."""
+    import shutil
+    import subprocess
+    out = os.path.join(ROOT, "tests", "build", "glibc_math_check")
+    src = os.path.join(ROOT, "tests", "glibc_math_check.c")
+    deps = [src, os.path.join(ROOT, "radian_amd", "csrc", "glibc_math.h"), os.path.join(ROOT, "radian_amd", "csrc", "glibc_tables.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    if shutil.which("gcc") is None:
+        return out if os.path.exists(out) else None
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-o", out, src, "-lm"])
+    return out
+
+
+@pytest.fixture(scope="session")
+def host_libm_is_glibc235_fma():
+    """True when this host's exp / log / log1p are bit-identical to glibc_math.h (glibc 2.35, x86-64 FMA + AVX2 variant) on a
+    million arguments each: then the oracle's scores are what the beam search's "glibc" arithmetic mode reproduces."""
+    import subprocess
+    exe = glibc_math_check_binary()
+    if exe is None:
+        return False
+    return subprocess.run([exe, "1"], capture_output=True).returncode == 0

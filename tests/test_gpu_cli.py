@@ -143,3 +143,12 @@ def test_cli_cfg5_flags_f16_logits_and_hashed_long_context(tmp_path, golden_dir,
     basecall.main([in_dir, str(out2), "--decode-type", "chunk", "--beam-width", "3", "--step-size", "512", "--sig-model", "synthetic:7",
                    "--sig-config", "none", "--rna-model", "None", "--precision", "bf16x3"])
     assert len(_read_fasta(str(out2))) == 5
+    # --decode-math glibc reaches the device; on softmax rows it gives the labelings the default arithmetic gives
+    outs = []
+    for math in ("glibc", "fast"):
+        o = tmp_path / ("out_" + math)
+        o.mkdir()
+        basecall.main([in_dir, str(o), "--decode-type", "chunk", "--beam-width", "6", "--step-size", "512", "--sig-model", "synthetic:1234",
+                       "--sig-config", "none", "--rna-model", "None", "--decode-math", math])
+        outs.append(_read_fasta(str(o)))
+    assert len(outs[0]) == 5 and outs[0] == outs[1]

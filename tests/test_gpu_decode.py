@@ -51,6 +51,43 @@ def test_golden_nolm(be, golden_dir):
     assert not bad, bad
 
 
+def test_golden_scores_bit_exact_in_glibc_mode(be, golden_dir):
+    """rd_set_decode_math(1): log / exp / log1p evaluated as glibc 2.35's x86-64 FMA build does (csrc/glibc_math.h) -- the libm
+    the golden vectors were generated on.  The winner's pr_total then equals the REFERENCE's own float64 bit for bit, on every
+    no-LM golden case (136 matrices incl. exact 0 / 1 probabilities and duplicated rows), and every labeling is the reference's."""
+    g = json.load(open(os.path.join(golden_dir, "beam_nolm_cases.json")))
+    mats = np.load(os.path.join(golden_dir, "beam_nolm_mats.npz"))
+    be.set_decode_math("glibc")
+    try:
+        n_scores = 0
+        for c in g["cases"]:
+            mat = mats[c["mat"]]
+            (lab,), sc = be.decode_batch(mat.reshape(-1, 5), [0], [mat.shape[0]], c["W"], with_scores=True)
+            assert s_of(lab) == c["seq"], (c["mat"], c["W"])
+            if "final" in c:
+                exp = fdec(c["final"][0]["pr_total"])
+                assert sc[0] == exp or (np.isnan(exp) and np.isnan(sc[0])), (c["mat"], c["W"], float(sc[0]).hex(), c["final"][0]["pr_total"])
+                n_scores += 1
+        assert n_scores >= 50
+        gl = json.load(open(os.path.join(golden_dir, "beam_lm_cases.json")))
+        ml = np.load(os.path.join(golden_dir, "beam_lm_mats.npz"))
+        cur = None
+        for c in gl["cases"]:
+            if cur != c["lm"]:
+                be.load_lm(ml[c["lm"]], c["k"])
+                cur = c["lm"]
+            mat = ml[c["mat"]]
+            (lab,), sc = be.decode_batch(mat.reshape(-1, 5), [0], [mat.shape[0]], c["W"], use_lm=True, s_threshold=fdec(c["s_thr"]),
+                                         r_threshold=fdec(c["r_thr"]), with_scores=True)
+            assert s_of(lab) == c["seq"], (c["mat"], c["k"], c["W"])
+            if "final" in c and c["final"]:
+                exp = fdec(c["final"][0]["pr_total"])
+                assert sc[0] == exp or (np.isnan(exp) and np.isnan(sc[0])), (c["mat"], c["k"], c["W"], float(sc[0]).hex(), c["final"][0]["pr_total"])
+    finally:
+        be.load_lm(None, 0)
+        be.set_decode_math("fast")
+
+
 def test_golden_lm(be, golden_dir):
     g = json.load(open(os.path.join(golden_dir, "beam_lm_cases.json")))
     mats = np.load(os.path.join(golden_dir, "beam_lm_mats.npz"))

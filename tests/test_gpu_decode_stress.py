@@ -74,6 +74,39 @@ def test_random_batches_match_oracle(be, oracle, kind):
                 assert best_gap <= 8 * np.finfo(np.float64).eps, (W, i, first, best_gap)
 
 
+def test_exact_ties_reproduce_in_glibc_mode(be, oracle, host_libm_is_glibc235_fma):
+    """the regime the default arithmetic cannot promise (see "quant" above): labelings that are equiprobable in exact arithmetic
+    are ordered by the last-ulp rounding of the host's libm.  rd_set_decode_math(1) evaluates log / exp / log1p operation for
+    operation as glibc 2.35's x86-64 FMA build does, so on such a host (checked: the restated routines agree with the running
+    libm bit for bit) EVERY sequence is identical, in both launch forms, with and without an LM."""
+    if not host_libm_is_glibc235_fma:
+        pytest.skip("this host's libm is not the build csrc/glibc_math.h restates (tests/glibc_math_check.c differs or cannot run)")
+    rng = np.random.default_rng(hash("quant") % 1000)
+    be.set_decode_math("glibc")
+    try:
+        for dtype in (np.float32, np.float64):
+            mats, off, lens = _mats(rng, 600, 300, "quant", dtype)
+            for W, form in ((1, "auto"), (2, "auto"), (3, "auto"), (6, "auto"), (10, "auto"), (25, "waves"), (25, "lanes"), (40, "waves"), (40, "lanes")):
+                be.set_decode_form(form)
+                got = be.decode_batch(mats, off, lens, W)
+                exp = oracle.beam_search_batch(mats, off, lens, W)
+                bad = [i for i in range(len(lens)) if not np.array_equal(got[i], exp[i])]
+                assert not bad, (dtype.__name__, W, form, bad[:5], len(bad))
+        be.set_decode_form("auto")
+        table = rng.dirichlet([0.2] * 4, size=4 ** 2)
+        be.load_lm(table, 2)
+        mats, off, lens = _mats(rng, 300, 250, "quant", np.float64)
+        for W, s_thr, r_thr in ((2, 0.5, 0.5), (6, 0.0, 2.0), (10, 0.8, 0.9), (25, 0.5, 2.0)):
+            got = be.decode_batch(mats, off, lens, W, use_lm=True, s_threshold=s_thr, r_threshold=r_thr)
+            exp = oracle.beam_search_batch(mats, off, lens, W, table, s_thr, r_thr, 2)
+            bad = [i for i in range(len(lens)) if not np.array_equal(got[i], exp[i])]
+            assert not bad, (W, bad[:5], len(bad))
+    finally:
+        be.load_lm(None, 0)
+        be.set_decode_form("auto")
+        be.set_decode_math("fast")
+
+
 @pytest.mark.parametrize("form", ["waves", "lanes"])
 def test_wide_beams_both_launch_forms_match_oracle(be, oracle, form):
     """beam widths above 12 have two launch shapes (several waves per sequence / two candidates per lane, DESIGN.md 4.4);

@@ -29,8 +29,10 @@ for name, scale in (("bench weights (saturated rows)", 1.0), ("soft head x0.05",
         valid = np.ascontiguousarray(valid_w, dtype=np.int32)
         labels = np.zeros((n, T), np.uint8)
         lens = np.zeros(n, np.int32)
-        for W, form in ((1, "auto"), (6, "auto"), (10, "auto"), (25, "waves"), (25, "lanes"), (25, "auto")):
+        for W, form, math in ((1, "auto", "fast"), (6, "auto", "fast"), (10, "auto", "fast"), (10, "auto", "glibc"), (25, "waves", "fast"),
+                              (25, "lanes", "fast"), (25, "auto", "fast"), (25, "auto", "glibc")):
             be.set_decode_form(form)
+            be.set_decode_math(math)
             be.decode_resident(d_p, n, T, valid, W, labels, lens)
             be.timer_enable(RD_TIMER_DECODE, 8)
             t0 = time.perf_counter()
@@ -40,7 +42,7 @@ for name, scale in (("bench weights (saturated rows)", 1.0), ("soft head x0.05",
             t = be.timer_read(RD_TIMER_DECODE)
             be.timer_enable(RD_TIMER_DECODE, 0)
             ms = t["total_ms"] / max(1, t["launches"])
-            print(f"n={n} T={T} W={W} ({form}): kernel {ms:.3f} ms ({valid.sum() / ms / 1e3:.1f} M timesteps/s, {ms * 1e3 / T:.2f} us per time step), "
+            print(f"n={n} T={T} W={W} ({form}, {math}): kernel {ms:.3f} ms ({valid.sum() / ms / 1e3:.1f} M timesteps/s, {ms * 1e3 / T:.2f} us per time step), "
                   f"call {wall * 1e3:.2f} ms, mean len {lens.mean():.0f}")
         be.dev_free(d_w)
         be.dev_free(d_p)
