@@ -406,6 +406,17 @@ def main():
         be.timer_enable(RD_TIMER_CONV, 0)
         be.timer_enable(RD_TIMER_DECODE, 0)
         be.timer_enable(RD_TIMER_HEAD, 0)
+        # the same single-stream steps with the beam search's glibc arithmetic (rd_set_decode_math 1: scores bit-identical to the
+        # reference's on a glibc 2.35 x86-64 host); the timed region runs the default arithmetic
+        be.set_decode_math("glibc")
+        step(0)
+        be.timer_enable(RD_TIMER_DECODE, n_prof)
+        for i in range(n_prof):
+            step(i)
+        be.sync()
+        tdg = be.timer_read(RD_TIMER_DECODE)
+        be.timer_enable(RD_TIMER_DECODE, 0)
+        be.set_decode_math("fast")
         # algorithmic FLOPs of the timed launches as accounted by the library: 393 216 per evaluated time step; the
         # streamed forward evaluates fewer rows in the early layers (a head only holds the rows its layer changes)
         flop_per_launch = tc["flops"] / max(1, tc["launches"])
@@ -442,6 +453,7 @@ def main():
                       "duration there also counts the time it shares the chip (profiles/*_kernel_stats_default_2lanes.csv); "
                       "pipeline_frac is the timed region's own figure",
             "decode_timesteps_per_s": float(sum(b[1].sum() for b in batches[:n_prof])) / max(1e-9, td["total_ms"] * 1e-3),
+            "decode_timesteps_per_s_glibc_math": float(sum(b[1].sum() for b in batches[:n_prof])) / max(1e-9, tdg["total_ms"] * 1e-3),
         }
     # secondaries, reported beside the headline (one GPU, fp32 headline only): the same job in the other matrix-product
     # modes; configs[3]'s global + LM geometry; the raw-reads end-to-end driver loop

@@ -104,8 +104,8 @@ int rd_set_decode_form(rd_ctx* ctx, int form);
  * libm): 0 = this library's routines (default; <= 1 ulp from glibc's, so scores agree to a few ulp and labelings are
  * identical unless two labelings tie within that distance), 1 = the operation sequence of glibc 2.35's x86-64 FMA build
  * (exp, log, log1p restated in csrc/glibc_math.h): scores and labelings bit-identical to the reference's on such a host,
- * including labelings that are equiprobable in exact arithmetic; the beam search takes 13 % (peaked rows) to 65 %
- * (flat rows) longer. */
+ * including labelings that are equiprobable in exact arithmetic; the beam search takes 10 % (peaked rows, thousands of
+ * sequences) to 35 % (flat rows, few sequences) longer. */
 int rd_set_decode_math(rd_ctx* ctx, int mode);
 
 /* ---- the five seams, host-pointer form ----------------------------------------------------- */

@@ -56,7 +56,7 @@ def build_parser():
     parser.add_argument("--decode-math", default="fast", choices=["fast", "glibc"],
                         help="arithmetic of the beam search's log / logaddexp: this library's routines (default; within an ulp of libm's, "
                              "labelings identical unless two labelings tie within a few ulp) or glibc 2.35's operation sequence (scores bit-"
-                             "identical to the reference's on an x86-64 FMA host, including exactly tied labelings; 15-60 %% slower beam search)")
+                             "identical to the reference's on an x86-64 FMA host, including exactly tied labelings; 10-35 %% slower beam search)")
     parser.add_argument("--lm-hashed-context", action="store_true",
                         help="global mode: accept a --context-len longer than the RNA model's k-mers (up to 256) by addressing the model's "
                              "table with a hash of the context (a synthetic long-context LM: no reference behaviour -- the reference raises "

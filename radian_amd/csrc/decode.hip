@@ -148,7 +148,7 @@ __device__ __forceinline__ double lae(double x, double y)
 __device__ __forceinline__ double lae_gx(double x, double y, const uint64_t* T)
 {
     const double hi = fmax(x, y), lo = fmin(x, y);
-    const double r = hi + gm_log1p(gm_exp(lo - hi, T));      // (lo - hi = -|x - y| exactly, as npy_logaddexp's tmp / -tmp)
+    const double r = hi + gm_log1p_unit(gm_exp(lo - hi, T));      // (lo - hi = -|x - y| exactly, as npy_logaddexp's tmp / -tmp)
     return x == y ? x + kLogE2 : r;
 }
 

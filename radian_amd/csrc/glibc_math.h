@@ -71,16 +71,9 @@ GM_FN double gm_exp(double x, const uint64_t* T)
                  NegLn2loN = -0x1.cf79abc9e3b3ap-47, C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3,
                  C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
     const uint64_t ix = gm_bits(x);
-    uint32_t abstop = (uint32_t)(ix >> 52) & 0x7ffu;
-    if (abstop - 0x3c9u >= 0x3fu) {                    // |x| < 2^-54 or |x| >= 512 or NaN
-        if (abstop - 0x3c9u >= 0x80000000u) return 1.0 + x;   // tiny: exp(x) = 1 + x to within rounding
-        if (abstop >= 0x409u) {                        // |x| >= 1024
-            if (ix == 0xfff0000000000000ull) return 0.0;
-            if (abstop >= 0x7ffu) return 1.0 + x;      // NaN, +inf
-            return (ix >> 63) ? 0x1p-767 * 0x1p-767 : 0x1p769 * 0x1p769;   // underflow -> 0, overflow -> inf
-        }
-        abstop = 0;                                    // 512 <= |x| < 1024: the result may be subnormal / huge
-    }
+    const uint32_t abstop = (uint32_t)(ix >> 52) & 0x7ffu;
+    // the main path, evaluated for every argument (one straight instruction stream on a SIMD machine; the range cases below
+    // replace its result, and the 512 <= |x| < 1024 case continues from its intermediate values exactly as e_exp.c does)
     double kd = gm_fma(InvLn2N, x, Shift);             // z + Shift, fused
     const uint64_t ki = gm_bits(kd);
     kd = kd - Shift;
@@ -97,9 +90,17 @@ GM_FN double gm_exp(double x, const uint64_t* T)
     double tmp = gm_fma(p23, r2, tr);
     const double r4 = r2 * r2;
     tmp = gm_fma(r4, p45, tmp);
-    if (abstop == 0) return gm_exp_special(tmp, sbits, ki);
     const double scale = gm_dbl(sbits);
-    return gm_fma(scale, tmp, scale);
+    double res = gm_fma(scale, tmp, scale);
+    if (abstop - 0x3c9u >= 0x3fu) {                    // |x| < 2^-54 or |x| >= 512 or NaN
+        if (abstop - 0x3c9u >= 0x80000000u) res = 1.0 + x;   // tiny: exp(x) = 1 + x to within rounding
+        else if (abstop >= 0x409u) {                   // |x| >= 1024
+            if (ix == 0xfff0000000000000ull) res = 0.0;
+            else if (abstop >= 0x7ffu) res = 1.0 + x;  // NaN, +inf
+            else res = (ix >> 63) ? 0x1p-767 * 0x1p-767 : 0x1p769 * 0x1p769;   // underflow -> 0, overflow -> inf
+        } else res = gm_exp_special(tmp, sbits, ki);   // 512 <= |x| < 1024: the result may be subnormal / huge
+    }
+    return res;
 }
 
 // ---------------------------------------------------------------------------------------------------------------- log
@@ -244,6 +245,61 @@ GM_FN double gm_log1p(double x)
     const double t = s * (hfsq + R);
     if (k == 0) return f - (hfsq - t);
     return kd * ln2_hi - ((hfsq - (t + (kd * ln2_lo + c))) - f);
+}
+
+// log1p on [0, 1] (and NaN): the same operations as gm_log1p for such arguments, arranged for a SIMD machine -- the
+// 1 + x >= sqrt(2) reduction is the only divergent block, the rest is one instruction stream with selects.  (The decoder's
+// argument is exp of a non-positive number.)
+GM_FN double gm_log1p_unit(double t)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
+                 Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
+                 Lp7 = 1.479819860511658591e-01;
+    const uint32_t hx = (uint32_t)(gm_bits(t) >> 32);
+    int k = 0;
+    int32_t hu = 1;
+    double f = t, c = 0.0;
+    if (hx >= 0x3FDA827Au && hx < 0x7ff00000u) {              // 0.41422 <= t (<= 1): u = 1 + t in [sqrt 2, 2]
+        double u = 1.0 + t;
+        hu = (int32_t)(gm_bits(u) >> 32);
+        k = (hu >> 20) - 1023;                                  // 0, or 1 for u = 2
+        c = (k > 0) ? 1.0 - (u - t) : t - (u - 1.0);
+        c = c / u;
+        hu &= 0x000fffff;
+        if (hu < 0x6a09e) {
+            u = gm_dbl((gm_bits(u) & 0xffffffffull) | ((uint64_t)(uint32_t)(hu | 0x3ff00000) << 32));
+        } else {
+            k += 1;
+            u = gm_dbl((gm_bits(u) & 0xffffffffull) | ((uint64_t)(uint32_t)(hu | 0x3fe00000) << 32));
+            hu = (0x00100000 - hu) >> 2;
+        }
+        f = u - 1.0;
+    }
+    const double hfsq = (0.5 * f) * f;
+    const double kd = (double)k;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double R1 = z * Lp1;
+    const double z2 = z * z;
+    const double R2 = Lp2 + z * Lp3;
+    const double z4 = z2 * z2;
+    const double R3 = Lp4 + z * Lp5;
+    const double z6 = z4 * z2;
+    const double R4 = Lp6 + z * Lp7;
+    const double R = ((R1 + z2 * R2) + z4 * R3) + z6 * R4;
+    const double tt = s * (hfsq + R);
+    const double kl = kd * ln2_lo + c, kh = kd * ln2_hi;
+    double res = (k == 0) ? f - (hfsq - tt) : kh - ((hfsq - (tt + kl)) - f);
+    if (hu == 0) {                                              // |f| < 2^-20 (t within 2^-19 of 1)
+        if (f == 0.0) res = (k == 0) ? 0.0 : kl + kh;
+        else {
+            const double Rs = (1.0 - 0.66666666666666666 * f) * hfsq;
+            res = (k == 0) ? f - Rs : kh - ((Rs - kl) - f);
+        }
+    }
+    if (hx < 0x3e200000u) res = (hx < 0x3c900000u) ? t : t - (t * t) * 0.5;   // t < 2^-29 (< 2^-54: t)
+    return res;
 }
 
 #if defined(__clang__)

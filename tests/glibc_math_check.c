@@ -36,6 +36,10 @@ static void ck_log1p(double x)
 {
     const double a = gm_log1p(x), b = log1p(x);
     if (gm_bits(a) != gm_bits(b) && !(a != a && b != b) && bad_log1p++ < 5) printf("log1p(%a): %a vs libm %a\n", x, a, b);
+    if ((x >= 0.0 && x <= 1.0) || x != x) {   /* the SIMD arrangement for [0, 1] */
+        const double u = gm_log1p_unit(x);
+        if (gm_bits(u) != gm_bits(b) && !(u != u && b != b) && bad_log1p++ < 5) printf("log1p_unit(%a): %a vs libm %a\n", x, u, b);
+    }
 }
 
 int main(int argc, char** argv)
@@ -44,7 +48,7 @@ int main(int argc, char** argv)
     const double edges[] = {0.0, -0.0, 1.0, -1.0, 0.5, 2.0, 0x1p-54, -0x1p-54, 0x1p-55, 0x1p-29, 0x1p-30, 0.41421356237309503, 0.4142135623730951,
                             -0.2928932188134524, -0.29289321881345254, 0x1p-1022, 0x1p-1074, 0x1.fffffffffffffp-1023, 1e-300, 1e300, 511.9, 512.0,
                             -511.9, -512.0, -708.3, -708.4, -744.9, -745.13, -745.14, -746.0, -1023.9, -1024.0, -1e5, 709.7, 709.8, 1024.0,
-                            1.0 - 0x1p-4, 1.0 + 0x1.09p-4, 0x1.fffffffffffffp-1, 0x1.0000000000001p+0, 0.9375, 1.0647, INFINITY, -INFINITY, NAN};
+                            1.0 - 0x1p-4, 1.0 + 0x1.09p-4, 1.0 - 0x1p-19, 1.0 - 0x1p-20, 1.0 - 0x1p-21, 1.0 - 0x1p-30, 0x1.fffffffffffffp-1, 0x1.0000000000001p+0, 0.9375, 1.0647, INFINITY, -INFINITY, NAN};
     for (size_t i = 0; i < sizeof edges / sizeof *edges; i++) {
         ck_exp(edges[i]);
         ck_exp(nextafter(edges[i], 0.0));
@@ -72,12 +76,13 @@ int main(int argc, char** argv)
         ck_log1p(unif());
         ck_log1p(ldexp(unif(), -(int)(rnd() % 80)));
         ck_log1p(0.41 + 0.01 * unif());
+        ck_log1p(1.0 - ldexp(unif(), -(int)(rnd() % 40)));
         ck_log1p(-unif() * 0.999);
         ck_log1p(ldexp(unif(), (int)(rnd() % 70)));
         /* the composition numpy's logaddexp evaluates: hi + log1p(exp(lo - hi)) */
         {
             const double hi = -unif() * 50.0, lo = hi - unif() * 60.0;
-            const double a = hi + gm_log1p(gm_exp(lo - hi, TE)), b = hi + log1p(exp(lo - hi));
+            const double a = hi + gm_log1p_unit(gm_exp(lo - hi, TE)), b = hi + log1p(exp(lo - hi));
             if (gm_bits(a) != gm_bits(b)) bad_lae++;
         }
     }
