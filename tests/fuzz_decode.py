@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Beam search, GPU vs the C oracle, over many random batches (the generator of tests/test_gpu_decode_stress.py): counts the
-sequences whose labeling differs.  usage: fuzz_decode.py [rounds] [seed]"""
+sequences whose labeling differs.  usage: fuzz_decode.py [rounds] [seed] [max rows per sequence = 400] [sequences per round = 800]"""
 import os, sys, time
 import numpy as np
 R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +12,8 @@ from test_gpu_decode_stress import _mats
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+tmax = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+nseq = int(sys.argv[4]) if len(sys.argv) > 4 else 800
 be = Backend(0)
 t0 = time.time()
 total = bad_total = 0
@@ -22,11 +24,13 @@ for r in range(rounds):
     k = int(rng.integers(1, 6))
     table = rng.dirichlet([0.2] * 4, size=4 ** k) if use_lm else None
     be.load_lm(table, k if use_lm else 0)
-    mats, off, lens = _mats(rng, 800, 400, kind, dtype)
-    W = int(rng.choice([1, 2, 5, 6, 10, 12, 13, 25, 26, 40]))
+    mats, off, lens = _mats(rng, nseq, tmax, kind, dtype)
+    W = int(rng.choice([1, 2, 5, 6, 10, 12, 13, 25, 26, 40, 51]))
     s_thr, r_thr = float(rng.choice([0.0, 0.5, 0.8])), float(rng.choice([0.5, 0.9, 2.0]))
     form = str(rng.choice(["auto", "waves", "lanes"]))     # launch shape for W > 12 (rd_set_decode_form)
     be.set_decode_form(form)
+    math = str(rng.choice(["fast", "glibc"]))              # arithmetic of log / logaddexp (rd_set_decode_math)
+    be.set_decode_math(math)
     if use_lm:
         got = be.decode_batch(mats, off, lens, W, use_lm=True, s_threshold=s_thr, r_threshold=r_thr)
         exp = oracle.beam_search_batch(mats, off, lens, W, table, s_thr, r_thr, k)
@@ -36,6 +40,6 @@ for r in range(rounds):
     bad = [i for i in range(len(lens)) if not np.array_equal(got[i], exp[i])]
     total += len(lens)
     bad_total += len(bad)
-    print(f"round {r}: {kind} {dtype.__name__} W={W} {form} lm={'k=%d' % k if use_lm else 'no'}: {len(bad)} of {len(lens)} differ ({time.time() - t0:.0f}s)", flush=True)
+    print(f"round {r}: {kind} {dtype.__name__} W={W} {form} {math} lm={'k=%d' % k if use_lm else 'no'}: {len(bad)} of {len(lens)} differ ({time.time() - t0:.0f}s)", flush=True)
 print(f"done: {bad_total} of {total} sequences differ")
 sys.exit(1 if bad_total else 0)
