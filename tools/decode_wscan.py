@@ -1,0 +1,28 @@
+"""Beam search alone, 512 windows x 1024 rows: us per time step against the beam width, both launch shapes."""
+import os, sys, time
+import numpy as np
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, R)
+from radian_amd import Backend, weights, synthetic
+from radian_amd.backend import RD_TIMER_DECODE
+T = 1024
+be = Backend(0)
+be.load_weights(weights.synthetic_weights(seed=1234))
+n = 512
+reads = synthetic.synthetic_reads(n // 8, 4096, seed=5)
+win, valid_w = synthetic.reads_to_windows(reads, T, 512)[:2]
+win = np.ascontiguousarray(win, dtype=np.float32)
+d_w = be.dev_alloc(win.nbytes); be.h2d(d_w, win)
+d_p = be.dev_alloc(n * T * 5 * 4)
+be.forward_resident(d_w, n, T, d_p)
+valid = np.ascontiguousarray(valid_w, dtype=np.int32)
+labels = np.zeros((n, T), np.uint8); lens = np.zeros(n, np.int32)
+for W, form in ((10,"auto"),(12,"auto"),(13,"waves"),(13,"lanes"),(20,"waves"),(25,"waves"),(26,"waves"),(40,"waves"),(51,"waves"),(51,"lanes")):
+    be.set_decode_form(form)
+    be.decode_resident(d_p, n, T, valid, W, labels, lens)
+    be.timer_enable(RD_TIMER_DECODE, 8)
+    for _ in range(3):
+        be.decode_resident(d_p, n, T, valid, W, labels, lens)
+    t = be.timer_read(RD_TIMER_DECODE); be.timer_enable(RD_TIMER_DECODE, 0)
+    ms = t["total_ms"] / max(1, t["launches"])
+    print(f"W={W} {form}: {ms*1e3/T:.2f} us/step")
