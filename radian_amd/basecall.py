@@ -65,8 +65,10 @@ def build_parser():
                         help="worker processes for the chunk-mode fragment stitch (0: stitch on the driver's host thread)")
     parser.add_argument("--queue-block", default=256, type=int,
                         help="--gpus N: reads per claim of the per-node work queue (0: static round-robin by read index)")
-    parser.add_argument("--gpu-batch-windows", default=4096, type=int,
-                        help="device batch size across reads, in windows (chunk mode) or chunk_len-row units (global mode)")
+    parser.add_argument("--gpu-batch-windows", default=None, type=int,
+                        help="device batch size across reads, in windows (chunk mode) or chunk_len-row units (global mode).  Default: 4096; "
+                             "in global mode a batch that holds long reads grows (up to 16384) until its forward covers the longest read's "
+                             "beam search, which is one serial chain per read")
     return parser
 
 
@@ -267,6 +269,19 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
             while len(finishing) > 2:
                 finishing.pop(0).result()               # re-raises host-side errors
 
+    # Global mode: a read's beam search is a serial chain of one time step per sample (~1.7 us at beam <= 12) that
+    # only overlaps the OTHER context's forward (~29 M rows/s): a batch should hold ~128 forward rows per chain step of its longest
+    # read (measured: 768 reads x 100 k samples, 19 M samples/s at 4096, 25 M at 16384; tools/cli_long.py).
+    longest = 0
+    chain_rows = 128 if args.beam_width <= 12 else 200 if args.beam_width <= 25 else 300
+
+    def batch_limit(longest_read):
+        if args.gpu_batch_windows is not None:
+            return args.gpu_batch_windows
+        if args.decode_type != "global":
+            return 4096
+        return max(4096, min(16384, longest_read * chain_rows // args.chunk_len))
+
     def flush():
         nonlocal batch, batch_idx, n_win, n_submitted
         if not batch:
@@ -296,11 +311,13 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
                 nw = (0 if n < args.chunk_len else (n - args.chunk_len) // args.step_size + 1) + 1   # windows decoded
             else:
                 nw = -(-n // args.chunk_len)   # global: the device evaluates N rows and decodes one sequence per read
-            if batch and n_win + nw > args.gpu_batch_windows:
+            if batch and n_win + nw > batch_limit(max(longest, n)):
                 flush()
+                longest = 0
             batch.append((read.read_id, raw))
             batch_idx.append(idx)
             n_win += nw
+            longest = max(longest, n)
         flush()
         drain()
     finally:
