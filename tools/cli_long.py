@@ -2,7 +2,7 @@
 """End-to-end CLI timing on LONG reads (GPU box): n reads x L samples in one multi-read fast5 -> FASTA, global decode at the
 reference's defaults (step 128, beam 6, no LM), for several --gpu-batch-windows.  A read's beam search is one serial chain
 (L steps x ~1.7 us), so a device batch must hold enough rows for its forward to cover the longest chain.
-usage: cli_long.py [n_reads=96] [L=100000] [batch windows ...]"""
+usage: cli_long.py [n_reads=96] [L=100000] [batch windows | auto [:device contexts] ...]"""
 import os, sys, tempfile, time
 import numpy as np
 R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,7 +20,9 @@ def main():
     fast5.write_multi_fast5(os.path.join(d, "in", "r.fast5"), {f"{i:08d}-0000": reads[i] for i in range(n_reads)})
     for sz in sizes:
         out = tempfile.mkdtemp(prefix="out_" + sz + "_", dir=d)
-        extra = [] if sz == "auto" else ["--gpu-batch-windows", sz]
+        extra = [] if sz.startswith("auto") else ["--gpu-batch-windows", sz.split(":")[0]]
+        if ":" in sz:                      # "<size>:<device contexts>"
+            extra += ["--device-contexts", sz.split(":")[1]]
         t0 = time.time()
         so = sys.stdout
         sys.stdout = open(os.devnull, "w")
