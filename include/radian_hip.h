@@ -101,11 +101,11 @@ int rd_set_logits(rd_ctx* ctx, int mode);
  * 1 = always several waves per sequence, 2 = always two candidates per lane.  For tests and measurements. */
 int rd_set_decode_form(rd_ctx* ctx, int form);
 /* Arithmetic of the beam search's log / logaddexp (decode.py:16-17,172-201 call math.log and np.logaddexp, i.e. the host's
- * libm): 0 = this library's routines (default; <= 1 ulp from glibc's, so scores agree to a few ulp and labelings are
- * identical unless two labelings tie within that distance), 1 = the operation sequence of glibc 2.35's x86-64 FMA build
- * (exp, log, log1p restated in csrc/glibc_math.h): scores and labelings bit-identical to the reference's on such a host,
- * including labelings that are equiprobable in exact arithmetic; the beam search takes 10 % (peaked rows, thousands of
- * sequences) to 35 % (flat rows, few sequences) longer. */
+ * libm): 1 (default) = the operation sequence of glibc 2.35's x86-64 FMA build (exp, log, log1p restated in
+ * csrc/glibc_math.h): scores and labelings bit-identical to the reference's on such a host, including labelings that are
+ * equiprobable in exact arithmetic; 0 = this library's faster routines (<= 1 ulp from glibc's, so scores agree to a few ulp
+ * and labelings are identical unless two labelings tie within that distance; the beam search runs 10 % (peaked rows,
+ * thousands of sequences) to 35 % (flat rows, few sequences) faster). */
 int rd_set_decode_math(rd_ctx* ctx, int mode);
 
 /* ---- the five seams, host-pointer form ----------------------------------------------------- */

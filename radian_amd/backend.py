@@ -115,7 +115,8 @@ class Backend:
         self._check(self._L.rd_set_decode_form(self._h, {"auto": 0, "waves": 1, "lanes": 2}[form] if isinstance(form, str) else int(form)))
 
     def set_decode_math(self, mode):
-        """'fast' (default) or 'glibc': arithmetic of the beam search's log / logaddexp (rd_set_decode_math)."""
+        """'glibc' (default: scores bit-identical to the reference's) or 'fast': arithmetic of the beam search's log / logaddexp
+        (rd_set_decode_math)."""
         self._check(self._L.rd_set_decode_math(self._h, {"fast": 0, "glibc": 1}[mode] if isinstance(mode, str) else int(mode)))
 
     # ------------------------------------------------------------------ seams (host arrays)

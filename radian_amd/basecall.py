@@ -53,10 +53,11 @@ def build_parser():
     parser.add_argument("--logits", default="f32", choices=["f32", "f16"],
                         help="storage of the softmax rows between the model and the decoder on the device: float32 (the reference's) or "
                              "float16 (not a reference option; BASELINE configs[4])")
-    parser.add_argument("--decode-math", default="fast", choices=["fast", "glibc"],
-                        help="arithmetic of the beam search's log / logaddexp: this library's routines (default; within an ulp of libm's, "
-                             "labelings identical unless two labelings tie within a few ulp) or glibc 2.35's operation sequence (scores bit-"
-                             "identical to the reference's on an x86-64 FMA host, including exactly tied labelings; 10-35 %% slower beam search)")
+    parser.add_argument("--decode-math", default="glibc", choices=["glibc", "fast"],
+                        help="arithmetic of the beam search's log / logaddexp: glibc 2.35's operation sequence (default: scores bit-identical "
+                             "to the reference's on an x86-64 FMA host, including exactly tied labelings) or this library's faster routines "
+                             "(within an ulp of libm's: labelings identical unless two labelings tie within a few ulp; 10-35 %% faster beam "
+                             "search)")
     parser.add_argument("--lm-hashed-context", action="store_true",
                         help="global mode: accept a --context-len longer than the RNA model's k-mers (up to 256) by addressing the model's "
                              "table with a hash of the context (a synthetic long-context LM: no reference behaviour -- the reference raises "
@@ -357,7 +358,7 @@ def apply_artifacts(args, be, art):
     be.set_precision(getattr(args, "precision", "fp32"))
     args._lm_loaded = False
     be.set_logits(getattr(args, "logits", "f32"))
-    be.set_decode_math(getattr(args, "decode_math", "fast"))
+    be.set_decode_math(getattr(args, "decode_math", "glibc"))
     if art["lm_table"] is not None:
         if art.get("lm_hashed_order"):
             be.load_lm_hashed(art["lm_table"], art["lm_hashed_order"], art["lm_k"])

@@ -85,7 +85,7 @@ def test_golden_scores_bit_exact_in_glibc_mode(be, golden_dir):
                 assert sc[0] == exp or (np.isnan(exp) and np.isnan(sc[0])), (c["mat"], c["k"], c["W"], float(sc[0]).hex(), c["final"][0]["pr_total"])
     finally:
         be.load_lm(None, 0)
-        be.set_decode_math("fast")
+        be.set_decode_math("glibc")
 
 
 def test_golden_lm(be, golden_dir):

@@ -13,6 +13,8 @@ w = weights.synthetic_weights(seed=1234).copy()
 if soft:
     w[-645:-5] *= np.float32(0.05)
 be.load_weights(w)
+if hasattr(be, "set_decode_math"):
+    be.set_decode_math(sys.argv[4] if len(sys.argv) > 4 else "fast")   # profiles/r02d_*: the fast arithmetic (round 1's decoder has no other)
 reads = synthetic.synthetic_reads(n // 8, 4096, seed=5)
 win, valid = synthetic.reads_to_windows(reads, T, 512)[:2]
 win = np.ascontiguousarray(win, dtype=np.float32)

@@ -8,6 +8,7 @@ from radian_amd.backend import RD_TIMER_DECODE
 T = 1024
 be = Backend(0)
 be.load_weights(weights.synthetic_weights(seed=1234))
+be.set_decode_math(sys.argv[1] if len(sys.argv) > 1 else "fast")   # the figures in DESIGN.md 4.4 are of the fast arithmetic
 n = 512
 reads = synthetic.synthetic_reads(n // 8, 4096, seed=5)
 win, valid_w = synthetic.reads_to_windows(reads, T, 512)[:2]
