@@ -17,9 +17,10 @@
 // child[c][i] == node[j]; the two probabilities are then combined with logaddexp exactly as the
 // reference does.  Back-pointers (parent<<2 | label) in HBM give the final labeling by traceback.
 //
-// Scores are float64 log-probabilities; log is ROCm's double-precision device function, logaddexp runs on
-// range-specific exp / log1p routines (below; all <= 1 ulp from glibc's), so scores agree with the reference
-// to a few ulp and the emitted labeling is identical unless two beams tie within that distance.
+// Scores are float64 log-probabilities.  Default arithmetic (GX): log / exp / log1p evaluated with glibc 2.35's operation
+// sequence (glibc_math.h), so scores are the reference's bit for bit on an x86-64 FMA host.  Fast arithmetic
+// (rd_set_decode_math 0): log is ROCm's device function and logaddexp runs on the range-specific exp / log1p routines below
+// (all <= 1 ulp from glibc's): scores agree to a few ulp and the labeling is identical unless two beams tie within that distance.
 #include "common.h"
 #include "glibc_math.h"
 #include "glibc_tables.h"
