@@ -259,13 +259,13 @@ GM_FN double gm_log1p_unit(double t)
     const uint32_t hx = (uint32_t)(gm_bits(t) >> 32);
     int k = 0;
     int32_t hu = 1;
-    double f = t, c = 0.0;
+    double f = t, cn = 0.0, cd = 1.0;
     if (hx >= 0x3FDA827Au && hx < 0x7ff00000u) {              // 0.41422 <= t (<= 1): u = 1 + t in [sqrt 2, 2]
         double u = 1.0 + t;
         hu = (int32_t)(gm_bits(u) >> 32);
         k = (hu >> 20) - 1023;                                  // 0, or 1 for u = 2
-        c = (k > 0) ? 1.0 - (u - t) : t - (u - 1.0);
-        c = c / u;
+        cn = (k > 0) ? 1.0 - (u - t) : t - (u - 1.0);          // correction term c = cn / u, divided below
+        cd = u;
         hu &= 0x000fffff;
         if (hu < 0x6a09e) {
             u = gm_dbl((gm_bits(u) & 0xffffffffull) | ((uint64_t)(uint32_t)(hu | 0x3ff00000) << 32));
@@ -276,6 +276,9 @@ GM_FN double gm_log1p_unit(double t)
         }
         f = u - 1.0;
     }
+    // (outside the block, so that the two divisions of the routine are independent chains of one instruction stream; lanes
+    // that skipped the block divide 0 by 1)
+    const double c = cn / cd;
     const double hfsq = (0.5 * f) * f;
     const double kd = (double)k;
     const double s = f / (2.0 + f);
