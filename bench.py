@@ -126,8 +126,9 @@ def e2e_raw_leg(device, pool, n_reads, precision):
     args._lm_loaded = False
     bes = [Backend(device) for _ in range(2)]
     try:
+        bes[0].load_weights(weights.synthetic_weights(seed=1234))
+        bes[1].clone_artifacts_from(bes[0])      # (as radian_amd.basecall.main sets up its further contexts)
         for b in bes:
-            b.load_weights(weights.synthetic_weights(seed=1234))
             b.set_precision(precision)
 
         def go(n, seed):
@@ -160,11 +161,14 @@ def global_leg(device, batches_host, read_off, reads_per_batch, steps, W, table,
     try:
         for _ in range(2):
             b = Backend(device)
-            b.load_weights(weights.synthetic_weights(seed=1234))
-            if hashed:
-                b.load_lm_hashed(table, table_order, context_len)
+            if bes:
+                b.clone_artifacts_from(bes[0])
             else:
-                b.load_lm(table, table_order)
+                b.load_weights(weights.synthetic_weights(seed=1234))
+                if hashed:
+                    b.load_lm_hashed(table, table_order, context_len)
+                else:
+                    b.load_lm(table, table_order)
             b.set_logits(logits)
             d = []
             for norm in batches_host:

@@ -232,6 +232,9 @@ int rd_rccl_probe(void);
 int rd_rccl_unique_id(uint8_t id_out[128]);                       /* rank 0, then shared out of band */
 int rd_rccl_init(rd_ctx* ctx, int rank, int nranks, const uint8_t id[128]);
 int rd_rccl_bcast_model(rd_ctx* ctx, int root);                   /* weights (+ LM when loaded on root) */
+/* Hand the loaded artefacts of `src` (weights in every packing, LM table) to `dst`, another context of this process: what
+ * rd_rccl_bcast_model does for another rank, with a device copy as the transport.  No reference counterpart. */
+int rd_clone_artifacts(rd_ctx* dst, rd_ctx* src);
 int rd_rccl_allreduce_max(rd_ctx* ctx, double* inout, int n);     /* host values, max over ranks */
 int rd_rccl_barrier(rd_ctx* ctx);
 int rd_rccl_finalize(rd_ctx* ctx);

@@ -64,6 +64,7 @@ SIGNATURES = {
     "rd_rccl_unique_id": (c_i, [c_vp]),
     "rd_rccl_init": (c_i, [c_vp, c_i, c_i, c_vp]),
     "rd_rccl_bcast_model": (c_i, [c_vp, c_i]),
+    "rd_clone_artifacts": (c_i, [c_vp, c_vp]),
     "rd_rccl_allreduce_max": (c_i, [c_vp, c_vp, c_i]),
     "rd_rccl_barrier": (c_i, [c_vp]),
     "rd_rccl_finalize": (c_i, [c_vp]),

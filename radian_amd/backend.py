@@ -372,6 +372,11 @@ class Backend:
     def rccl_finalize(self):
         self._check(self._L.rd_rccl_finalize(self._h))
 
+    def clone_artifacts_from(self, src):
+        """Take the loaded weights (every packing) and LM table of another Backend of this process by a device copy
+        (rd_clone_artifacts): the receiver's code of the multi-GPU broadcast, without parsing / repacking again."""
+        self._check(self._L.rd_clone_artifacts(self._h, src._h))
+
     def rccl_bcast_model(self, root=0):
         self._check(self._L.rd_rccl_bcast_model(self._h, root))
 

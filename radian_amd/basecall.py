@@ -352,13 +352,17 @@ def load_artifacts(args):
     return art
 
 
-def apply_artifacts(args, be, art):
-    """Device half: hand the parsed artefacts to a Backend."""
-    be.load_weights(art["weights"], art["dilations"])
+def apply_artifacts(args, be, art, clone_from=None):
+    """Device half: hand the parsed artefacts to a Backend -- or, for a further context of the same process, take the device
+    images of the Backend that already holds them (clone_from)."""
     be.set_precision(getattr(args, "precision", "fp32"))
-    args._lm_loaded = False
     be.set_logits(getattr(args, "logits", "f32"))
     be.set_decode_math(getattr(args, "decode_math", "glibc"))
+    if clone_from is not None:
+        be.clone_artifacts_from(clone_from)
+        return
+    be.load_weights(art["weights"], art["dilations"])
+    args._lm_loaded = False
     if art["lm_table"] is not None:
         if art.get("lm_hashed_order"):
             be.load_lm_hashed(art["lm_table"], art["lm_hashed_order"], art["lm_k"])
@@ -381,8 +385,8 @@ def main(argv=None):
     from .backend import Backend
     art = load_artifacts(args)
     bes = [Backend(args.device) for _ in range(max(1, args.device_contexts))]
-    for b in bes:
-        apply_artifacts(args, b, art)
+    for i, b in enumerate(bes):
+        apply_artifacts(args, b, art, clone_from=bes[0] if i else None)
     del art
     writer = FastaWriter(args.fasta_dir)
     try:

@@ -1872,6 +1872,57 @@ extern "C" int rd_rccl_finalize(rd_ctx* ctx)
     return RD_OK;
 }
 
+// What a receiver must know before the device images arrive (the sender's side of rd_rccl_bcast_model / rd_clone_artifacts)
+static void artifacts_header(const rd_ctx* ctx, BcastHeader& hd)
+{
+    hd = BcastHeader{};
+    hd.model_loaded = 1;
+    hd.nblocks = ctx->model.nblocks;
+    for (int i = 0; i < RD_MAX_BLOCKS; i++) hd.dil[i] = ctx->model.dil[i];
+    hd.model_floats = (int64_t)model_layout(ctx->model.nblocks).total;
+    for (int i = 0; i < 2 * RD_MAX_BLOCKS; i++) hd.inv_scale[i] = ctx->model.inv_scale[i];
+    hd.inv_scale_d1 = ctx->model.inv_scale_d1;
+    hd.lm_loaded = ctx->lm.loaded ? 1 : 0;
+    hd.lm_k = ctx->lm.k;
+    hd.lm_order = ctx->lm.table_order;
+    hd.lm_hashed = ctx->lm.hashed;
+    hd.lm_doubles = ctx->lm.loaded ? (int64_t)5 << (2 * ctx->lm.table_order) : 0;
+}
+
+// The receiver's side: geometry and scales from the header, storage reserved and bound; the images are not there yet
+// (artifacts_arrived marks them loaded).
+static int artifacts_prepare(rd_ctx* ctx, const BcastHeader& hd)
+{
+    RD_REQUIRE(hd.model_loaded == 1 && hd.nblocks >= 1 && hd.nblocks <= RD_MAX_BLOCKS && hd.model_floats == (int64_t)model_layout(hd.nblocks).total,
+               "artefact header: %d blocks, %lld floats do not describe a model of this library", hd.nblocks, (long long)hd.model_floats);
+    Model& m = ctx->model;
+    m.loaded = false;
+    m.nblocks = hd.nblocks;
+    for (int i = 0; i < RD_MAX_BLOCKS; i++) m.dil[i] = hd.dil[i];
+    for (int i = 0; i < 2 * RD_MAX_BLOCKS; i++) m.inv_scale[i] = hd.inv_scale[i];
+    m.inv_scale_d1 = hd.inv_scale_d1;
+    if (m.storage.reserve((size_t)hd.model_floats * 4)) return RD_ERR_NOMEM;
+    model_bind(m, model_layout(m.nblocks));
+    ctx->lm.loaded = false;
+    ctx->lm.gate_valid = false;
+    if (hd.lm_loaded) {
+        RD_REQUIRE(hd.lm_order >= 1 && hd.lm_order <= 13 && hd.lm_doubles == ((int64_t)5 << (2 * hd.lm_order)),
+                   "artefact header: LM table of order %d with %lld doubles", hd.lm_order, (long long)hd.lm_doubles);
+        ctx->lm.k = hd.lm_k;
+        ctx->lm.table_order = hd.lm_order;
+        ctx->lm.hashed = hd.lm_hashed;
+        if (ctx->lm.storage.reserve((size_t)hd.lm_doubles * 8)) return RD_ERR_NOMEM;
+        lm_bind(ctx->lm);
+    }
+    return RD_OK;
+}
+
+static void artifacts_arrived(rd_ctx* ctx, const BcastHeader& hd)
+{
+    ctx->model.loaded = true;
+    if (hd.lm_loaded) ctx->lm.loaded = true;
+}
+
 extern "C" int rd_rccl_bcast_model(rd_ctx* ctx, int root)
 {
     RD_REQUIRE(ctx && ctx->rccl, "rd_rccl_bcast_model: rd_rccl_init not called");
@@ -1881,17 +1932,7 @@ extern "C" int rd_rccl_bcast_model(rd_ctx* ctx, int root)
     BcastHeader hd = {};
     if (st->rank == root) {
         RD_REQUIRE(ctx->model.loaded, "rd_rccl_bcast_model: root has no weights loaded");
-        hd.model_loaded = 1;
-        hd.nblocks = ctx->model.nblocks;
-        for (int i = 0; i < RD_MAX_BLOCKS; i++) hd.dil[i] = ctx->model.dil[i];
-        hd.model_floats = (int64_t)model_layout(ctx->model.nblocks).total;
-        for (int i = 0; i < 2 * RD_MAX_BLOCKS; i++) hd.inv_scale[i] = ctx->model.inv_scale[i];
-        hd.inv_scale_d1 = ctx->model.inv_scale_d1;
-        hd.lm_loaded = ctx->lm.loaded ? 1 : 0;
-        hd.lm_k = ctx->lm.k;
-        hd.lm_order = ctx->lm.table_order;
-        hd.lm_hashed = ctx->lm.hashed;
-        hd.lm_doubles = ctx->lm.loaded ? (int64_t)5 << (2 * ctx->lm.table_order) : 0;
+        artifacts_header(ctx, hd);
     }
     if (st->scratch.reserve(sizeof(BcastHeader))) return RD_ERR_NOMEM;
     RD_HIP(hipMemcpyAsync(st->scratch.p, &hd, sizeof(hd), hipMemcpyHostToDevice, ctx->stream));
@@ -1899,23 +1940,8 @@ extern "C" int rd_rccl_bcast_model(rd_ctx* ctx, int root)
     RD_HIP(hipMemcpyAsync(&hd, st->scratch.p, sizeof(hd), hipMemcpyDeviceToHost, ctx->stream));
     RD_HIP(hipStreamSynchronize(ctx->stream));
     if (st->rank != root) {
-        Model& m = ctx->model;
-        m.loaded = false;
-        m.nblocks = hd.nblocks;
-        for (int i = 0; i < RD_MAX_BLOCKS; i++) m.dil[i] = hd.dil[i];
-        for (int i = 0; i < 2 * RD_MAX_BLOCKS; i++) m.inv_scale[i] = hd.inv_scale[i];
-        m.inv_scale_d1 = hd.inv_scale_d1;
-        if (m.storage.reserve((size_t)hd.model_floats * 4)) return RD_ERR_NOMEM;
-        model_bind(m, model_layout(m.nblocks));
-        ctx->lm.loaded = false;
-        ctx->lm.gate_valid = false;
-        if (hd.lm_loaded) {
-            ctx->lm.k = hd.lm_k;
-            ctx->lm.table_order = hd.lm_order;
-            ctx->lm.hashed = hd.lm_hashed;
-            if (ctx->lm.storage.reserve((size_t)hd.lm_doubles * 8)) return RD_ERR_NOMEM;
-            lm_bind(ctx->lm);
-        }
+        int rc = artifacts_prepare(ctx, hd);
+        if (rc) return rc;
     }
     // one broadcast of the packed weights (8.8 MB) and, when present, one of the LM table + entropies
     RD_NCCL(g_rccl.Broadcast(ctx->model.storage.p, ctx->model.storage.p, (size_t)hd.model_floats, ncclFloat32, root, st->comm,
@@ -1924,8 +1950,30 @@ extern "C" int rd_rccl_bcast_model(rd_ctx* ctx, int root)
         RD_NCCL(g_rccl.Broadcast(ctx->lm.storage.p, ctx->lm.storage.p, (size_t)hd.lm_doubles, ncclFloat64, root, st->comm,
                                  ctx->stream));
     RD_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->model.loaded = true;
-    if (hd.lm_loaded) ctx->lm.loaded = true;
+    artifacts_arrived(ctx, hd);
+    return RD_OK;
+}
+
+// A second context of the same process takes the device images of a loaded one (weights in all three packings, LM table,
+// entropies): the receiver's code of rd_rccl_bcast_model with a device-to-device copy as the transport.  The driver's
+// extra contexts of a GPU use it instead of parsing and repacking the artefacts again; peer copies make it work across the
+// GPUs of one process too.
+extern "C" int rd_clone_artifacts(rd_ctx* dst, rd_ctx* src)
+{
+    RD_REQUIRE(dst && src && dst != src, "rd_clone_artifacts: two distinct contexts are needed");
+    RD_REQUIRE(src->model.loaded, "rd_clone_artifacts: the source context has no weights loaded");
+    BcastHeader hd;
+    artifacts_header(src, hd);
+    RD_HIP(hipSetDevice(src->device));
+    RD_HIP(hipStreamSynchronize(src->stream));
+    RD_HIP(hipSetDevice(dst->device));
+    int rc = artifacts_prepare(dst, hd);
+    if (rc) return rc;
+    RD_HIP(hipMemcpyAsync(dst->model.storage.p, src->model.storage.p, (size_t)hd.model_floats * 4, hipMemcpyDefault, dst->stream));
+    if (hd.lm_loaded)
+        RD_HIP(hipMemcpyAsync(dst->lm.storage.p, src->lm.storage.p, (size_t)hd.lm_doubles * 8, hipMemcpyDefault, dst->stream));
+    RD_HIP(hipStreamSynchronize(dst->stream));
+    artifacts_arrived(dst, hd);
     return RD_OK;
 }
 

@@ -18,6 +18,12 @@ class OracleBackend:
     def set_logits(self, mode):
         assert mode in ("f32", 0)
 
+    def set_decode_math(self, mode):
+        pass   # the checker IS the host's libm
+
+    def clone_artifacts_from(self, src):
+        self.w, self.dil, self.lm, self.k = src.w, src.dil, src.lm, src.k
+
     def load_weights(self, flat, dilations=(1, 2, 4, 8, 16, 32)):
         self.w = np.asarray(flat, dtype=np.float32)
         self.dil = tuple(dilations)

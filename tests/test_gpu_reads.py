@@ -195,3 +195,39 @@ def test_long_read_global_streamed(be, oracle):
     mat = oracle.assemble_matrices(probs, pad, 128)
     exp, _ = oracle.beam_search_labels(mat, 6)
     assert mat.shape[0] == 60000 and np.array_equal(got, exp)
+
+
+def test_clone_artifacts_gives_an_identical_context():
+    """rd_clone_artifacts = the receiver's half of the multi-GPU broadcast (header -> reserve / bind -> images -> loaded) with a
+    device copy as the transport: a context that never parsed anything must compute exactly what the source computes, in every
+    matrix-product mode, with the LM, and keep working after the source is gone"""
+    from radian_amd import Backend, weights, synthetic
+    rng = np.random.default_rng(4)
+    table = rng.dirichlet([0.3] * 4, size=4 ** 4)
+    src = Backend(0)
+    src.load_weights(weights.synthetic_weights(seed=99, dilations=(1, 2, 4, 8)), (1, 2, 4, 8))
+    src.load_lm(table, 4)
+    dst = Backend(0)
+    with pytest.raises(Exception):
+        Backend(0).clone_artifacts_from(dst)          # nothing loaded in the source: an error, not a crash
+    dst.clone_artifacts_from(src)
+    reads = [r.astype(np.float32) for r in synthetic.synthetic_reads(6, 3000, seed=2)]
+    sigs = [(r - r.mean()) / r.std() for r in reads]
+    try:
+        for prec in ("fp32", "f16x3", "bf16x3"):
+            src.set_precision(prec)
+            dst.set_precision(prec)
+            a = src.basecall_reads_global(sigs, 1024, 256, 6, True, 0.3, 1.0)
+            b = dst.basecall_reads_global(sigs, 1024, 256, 6, True, 0.3, 1.0)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), prec
+        src.set_precision("fp32")
+        c_src = src.basecall_reads_chunk(sigs, 1024, 256, 10)
+        src.close()
+        src = None
+        dst.set_precision("fp32")
+        c = dst.basecall_reads_chunk(sigs, 1024, 256, 10)
+        assert len(c) == 6 and all(len(x) == len(y) and all(np.array_equal(p, q) for p, q in zip(x, y)) for x, y in zip(c, c_src))
+    finally:
+        if src is not None:
+            src.close()
+        dst.close()
