@@ -301,9 +301,14 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
     __shared__ double sent[LM ? 64 : 1];
     __shared__ int seg_s[NS], seg_v[NS], mflag[NW];
     __shared__ unsigned tab[TN];
-    __shared__ uint64_t gx_exp[GX ? 256 : 1];     // glibc arithmetic mode: exp's table
-    if constexpr (GX)
-        for (int i = tid; i < 256; i += TPB) gx_exp[i] = g_gm_exp_tab[i];
+    // glibc arithmetic: exp's table.  One candidate per lane (the forms whose point is a short time step): a copy in LDS, 2 KiB.
+    // Two candidates per lane (the form for thousands of sequences, where LDS per sequence decides how many stay resident --
+    // 16 per CU for a 4096-sequence launch -- and other waves hide a global load's latency): read in place, through the L1.
+    constexpr bool GXL = GX && R == 1;
+    __shared__ uint64_t gx_lds[GXL ? 256 : 1];
+    if constexpr (GXL)
+        for (int i = tid; i < 256; i += TPB) gx_lds[i] = g_gm_exp_tab[i];
+    const uint64_t* const gx_exp = GXL ? gx_lds : g_gm_exp_tab;
     __shared__ __attribute__((aligned(16))) unsigned ring[2][HC ? WM : 1][16];   // long contexts: the last 256 labels of each beam, 2 bits each
 
     for (int i = tid; i < TN; i += TPB) tab[i] = i == 0 ? 0u : 0xffffffffu;    // (the empty labeling: id 0 in slot 0)
