@@ -49,10 +49,12 @@ def test_long_context_hashed_lm_vs_oracle(oracle, k, order, W):
             lens[0] = tmax
             mats, off, lens = _mats(np.random.default_rng(k + W + int(scale * 10)), 120, tmax, scale)
             for s_thr, r_thr in ((0.0, 5.0), (0.5, 0.5)):
-                got = be.decode_batch(mats, off, lens, W, use_lm=True, s_threshold=s_thr, r_threshold=r_thr)
                 exp = oracle.beam_search_batch(mats, off, lens, W, table, s_thr, r_thr, k, hash_order=order)
-                bad = [i for i in range(len(lens)) if not np.array_equal(got[i], exp[i])]
-                assert not bad, (k, order, W, scale, s_thr, bad[:5], len(bad))
+                for form in (("waves", "lanes") if W > 12 else ("auto",)):     # both launch shapes of a wide beam (rd_set_decode_form)
+                    be.set_decode_form(form)
+                    got = be.decode_batch(mats, off, lens, W, use_lm=True, s_threshold=s_thr, r_threshold=r_thr)
+                    bad = [i for i in range(len(lens)) if not np.array_equal(got[i], exp[i])]
+                    assert not bad, (k, order, W, form, scale, s_thr, bad[:5], len(bad))
                 if s_thr == 0.0:
                     nolm = oracle.beam_search_batch(mats, off, lens, W)
                     long_enough = [i for i in range(len(lens)) if len(exp[i]) > k + 5]
