@@ -127,6 +127,11 @@ def test_f16_logits_chunk_vs_oracle_and_f32(oracle, W):
             f32 = [f for fr in be.basecall_reads_chunk(list(norm), CHUNK, STEP, W) for f in fr]
             be.set_logits("f16")
             f16 = [f for fr in be.basecall_reads_chunk(list(norm), CHUNK, STEP, W) for f in fr]
+            if W > 12:                      # the other launch shape of a wide beam reads the f16 rows the same way
+                be.set_decode_form("lanes")
+                f16_lanes = [f for fr in be.basecall_reads_chunk(list(norm), CHUNK, STEP, W) for f in fr]
+                be.set_decode_form("auto")
+                assert all(np.array_equal(a, b) for a, b in zip(f16, f16_lanes)), (name, W)
             be.set_logits("f32")
             off = np.arange(512, dtype=np.int64) * CHUNK
             exp = oracle.beam_search_batch(p16.astype(np.float32).reshape(-1, 5), off, valid, W)
