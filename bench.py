@@ -9,10 +9,13 @@ Inputs are resident in HBM when the timed region starts.  One process per GPU; r
 data-path collective (weak scaling); the only RCCL traffic is the start-up broadcast of the weights.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-No PyTorch in the measured process: rendezvous for the RCCL unique id goes through a file keyed by
-MASTER_PORT, barrier and max-over-ranks through RCCL (rd_rccl_*).
+With --gpus N > 1 and no WORLD_SIZE in the environment this process is only the LAUNCHER: before anything touches a GPU it
+makes a private rendezvous directory, starts N fresh copies of itself with RANK / LOCAL_RANK / WORLD_SIZE set (one per
+GPU), stops the job when one of them fails, and forwards rank 0's single JSON line.  A foreign launcher that sets those
+variables itself (e.g. `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) is honoured too: then
+the ranks find each other through a directory named after that launcher's pid.  No PyTorch in any bench process: the
+128-byte RCCL id travels through the rendezvous directory, barrier and max-over-ranks through RCCL (rd_rccl_*).
 """
 import argparse
 import json
@@ -249,6 +252,33 @@ def global_leg(device, batches_host, read_off, reads_per_batch, steps, W, table,
                              "other context's beam search"}
 
 
+def self_launch(world, argv, worker_cmd=None):
+    """--gpus N without a launcher: be the launcher.  Never creates a Backend, never loads the HIP library: the ranks are
+    fresh child processes (radian_amd.launch.run_ranks: one failing rank stops the others, exit codes come back).  Rank 0's
+    stdout carries the job's one JSON line and is forwarded; everything else the ranks print goes to stderr.
+    worker_cmd: what to start per rank (tests pass a stand-in); default = this script with the same arguments."""
+    import shutil
+    import tempfile
+    from radian_amd.launch import run_ranks
+    scratch = tempfile.mkdtemp(prefix="radian_bench_")
+    try:
+        cmd = list(worker_cmd) if worker_cmd is not None else [sys.executable, os.path.abspath(__file__)] + list(argv)
+        rcs, out0 = run_ranks(world, cmd, env_extra={"RD_BENCH_RDV": scratch}, capture_rank0=True)
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    if any(rcs):
+        sys.stderr.write(out0)
+        print(f"[bench] multi-GPU run failed: rank exit codes {rcs}", file=sys.stderr)
+        return 1
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if len(lines) != 1:
+        sys.stderr.write(out0)
+        print(f"[bench] expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    print(lines[0])
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -275,10 +305,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))   # this process is the launcher; it never touches a GPU
+    args.gpus = world
 
     from radian_amd import Backend, weights, synthetic
     from radian_amd.backend import RD_TIMER_CONV, RD_TIMER_DECODE, RD_TIMER_HEAD
@@ -293,6 +322,8 @@ def main():
     be = Backend(device)
     comm_kind = "single"
     comm = None
+    rccl_nranks = 1
+    per_rank_ms = None
     if world > 1:
         from radian_amd import dist
         # RCCL prints a version banner on the C-level stdout; stdout must carry the one JSON line only
@@ -304,8 +335,15 @@ def main():
             # over xGMI; the 128-byte RCCL id goes through a file keyed by the launcher's pid (no PyTorch in this process).
             # All ranks agree on the transport before anyone uses it (dist.connect: RCCL on every rank, or the file
             # transport on every rank -- never a mix, which would leave one side inside ncclBroadcast forever).
-            comm, comm_kind = dist.connect(be, rank, world, dist.uid_path())
+            uid_file = dist.uid_path(directory=os.environ.get("RD_BENCH_RDV"))   # own launcher: its scratch; foreign: /tmp, by launcher pid
+            try:
+                comm, comm_kind = dist.connect(be, rank, world, uid_file)
+            except dist.StartupFailed as e:
+                print(f"[bench] rank {rank}: {e}", file=sys.stderr)
+                sys.stderr.flush()
+                os._exit(3)   # a helper thread is stuck inside ncclCommInitRank: no interpreter shutdown, the launcher stops the job
             comm.bcast_artifacts(be, lambda b: b.load_weights(weights.synthetic_weights(seed=1234)))
+            rccl_nranks = comm.nranks_seen()   # collective on the file transport, local on RCCL (ncclCommCount)
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd1, 1)
@@ -360,6 +398,7 @@ def main():
         be.pipe_submit(d, BATCH_WINDOWS, CHUNK, valid, BEAM, lab, ln)
 
     def timed(fn):
+        nonlocal per_rank_ms
         # pre-heat: on a box whose GPU has been idle, the first ~0.2 s of work runs slower (measured: the same 20-step region 232 ms
         # right after start-up, 198 ms from the second region on; tools/submit_diag.py), which is a third of a 0.2-s timed region.
         # Untimed steps for args.preheat_ms, then the contract's W warm-up steps, then the K timed steps.
@@ -385,6 +424,7 @@ def main():
         el = time.perf_counter() - t0
         if world > 1:
             comm.barrier()
+            per_rank_ms = [x / args.steps * 1e3 for x in comm.allgather(el)]   # every rank's own clock over the same K steps
             el = float(comm.allreduce_max([el])[0])
         return el
 
@@ -498,7 +538,7 @@ def main():
     # secondaries, reported beside the headline (one GPU, fp32 headline only): the same job in the other matrix-product
     # modes; configs[3]'s global + LM geometry; the raw-reads end-to-end driver loop
     sec = {}
-    if args.precision == "fp32" and not args.no_secondary and not args.windowed:
+    if world == 1 and args.precision == "fp32" and not args.no_secondary and not args.windowed:
         for mode, key, desc, acc in (
                 ("bf16x3", "secondary_bf16x3",
                  "three-term bf16 split: hi+mid+lo reconstructs every finite fp32 operand exactly; six v_mfma_f32_32x32x16_bf16 per "
@@ -580,9 +620,13 @@ def main():
                 "model_rows_per_step": rows_streamed,
                 "chunk_len": CHUNK, "step_size": STEP, "batch_windows": BATCH_WINDOWS, "beam_width": BEAM,
                 "decode_type": "chunk", "samples_per_step_per_gpu": samples_per_step, "sharding": "reads per rank, no data-path collective", "startup_comm": comm_kind,
+                "launcher": "bench.py (own)" if "RD_BENCH_RDV" in os.environ else ("foreign (RANK/WORLD_SIZE were set)" if world > 1 else "none"),
                 "pipelining": f"{args.lanes} forward streams taking the steps' batches in turn (independent kernel chains fill each other's last, partial round of workgroups) + 1 decode stream: beam search + label copy-out of a group of {args.decode_group} batches overlaps the next group's forwards; all labels on host at stop",
             },
             "roofline": roof,
+            # multi-GPU evidence: the transport every rank agreed on, the communicator size as RCCL reports it
+            # (ncclCommCount; on the file transport: ranks that answered an exchange), every rank's own ms per step
+            "startup_comm": comm_kind, "rccl_nranks": rccl_nranks, "ms_per_step_per_rank": per_rank_ms,
         }
         out.update(sec)
         if cpu is not None:
@@ -591,6 +635,9 @@ def main():
         print(json.dumps(out))
     if comm is not None:
         comm.close()
+        if "RD_BENCH_RDV" not in os.environ:
+            from radian_amd import dist
+            dist.leave(rank, world, dist.uid_path())
     for b in batches:
         be.dev_free(b[0])
         be.dev_free(b[3])

@@ -237,6 +237,8 @@ int rd_rccl_bcast_model(rd_ctx* ctx, int root);                   /* weights (+ 
 int rd_clone_artifacts(rd_ctx* dst, rd_ctx* src);
 int rd_rccl_allreduce_max(rd_ctx* ctx, double* inout, int n);     /* host values, max over ranks */
 int rd_rccl_barrier(rd_ctx* ctx);
+/* Size of the communicator as RCCL itself reports it (ncclCommCount): the evidence that N ranks really joined. */
+int rd_rccl_comm_count(rd_ctx* ctx, int* nranks);
 int rd_rccl_finalize(rd_ctx* ctx);
 
 #ifdef __cplusplus

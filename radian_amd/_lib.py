@@ -67,6 +67,7 @@ SIGNATURES = {
     "rd_clone_artifacts": (c_i, [c_vp, c_vp]),
     "rd_rccl_allreduce_max": (c_i, [c_vp, c_vp, c_i]),
     "rd_rccl_barrier": (c_i, [c_vp]),
+    "rd_rccl_comm_count": (c_i, [c_vp, ctypes.POINTER(c_i)]),
     "rd_rccl_finalize": (c_i, [c_vp]),
 }
 

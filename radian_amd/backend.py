@@ -387,3 +387,9 @@ class Backend:
 
     def rccl_barrier(self):
         self._check(self._L.rd_rccl_barrier(self._h))
+
+    def rccl_comm_count(self):
+        """ranks in the communicator as RCCL reports them (ncclCommCount)"""
+        n = ctypes.c_int(0)
+        self._check(self._L.rd_rccl_comm_count(self._h, ctypes.byref(n)))
+        return n.value

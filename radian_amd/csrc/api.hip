@@ -1762,6 +1762,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -1793,6 +1794,7 @@ int rccl_load()
     RD_SYM(GetUniqueId, "ncclGetUniqueId");
     RD_SYM(CommInitRank, "ncclCommInitRank");
     RD_SYM(CommDestroy, "ncclCommDestroy");
+    RD_SYM(CommCount, "ncclCommCount");
     RD_SYM(Broadcast, "ncclBroadcast");
     RD_SYM(AllReduce, "ncclAllReduce");
     RD_SYM(GetErrorString, "ncclGetErrorString");
@@ -1987,6 +1989,16 @@ extern "C" int rd_rccl_allreduce_max(rd_ctx* ctx, double* inout, int n)
     RD_NCCL(g_rccl.AllReduce(st->scratch.p, st->scratch.p, (size_t)n, ncclFloat64, ncclMax, st->comm, ctx->stream));
     RD_HIP(hipMemcpyAsync(inout, st->scratch.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     RD_HIP(hipStreamSynchronize(ctx->stream));
+    return RD_OK;
+}
+
+extern "C" int rd_rccl_comm_count(rd_ctx* ctx, int* nranks)
+{
+    RD_REQUIRE(ctx && ctx->rccl && nranks, "rd_rccl_comm_count: bad argument / rd_rccl_init not called");
+    RcclState* st = (RcclState*)ctx->rccl;
+    int n = 0;
+    RD_NCCL(g_rccl.CommCount(st->comm, &n));
+    *nranks = n;
     return RD_OK;
 }
 

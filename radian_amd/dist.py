@@ -12,6 +12,8 @@ all of them did -- a rank never sits in ncclBroadcast while another waits at a f
 import heapq
 import json
 import os
+import tempfile
+import threading
 import time
 
 import numpy as np
@@ -30,15 +32,29 @@ def _proc_start_time(pid):
 
 
 def uid_path(tag=None, directory=None):
-    """Rendezvous path for one launch.  With `directory` (the launcher's private mkdtemp scratch) the name is unique by
-    construction.  Otherwise (bench.py under torch.distributed.run): all ranks are children of the same launcher
-    process, so its pid + start time names the launch and a file left by an earlier, crashed launch can never match."""
+    """Rendezvous path for one launch.  With `directory` (the launcher's private mkdtemp scratch: radian_amd.launch and
+    bench.py's own launcher) the name is unique by construction.  Otherwise (a foreign launcher such as
+    torch.distributed.run): all ranks are children of the same launcher process, so its pid + start time names the
+    launch, and the launcher's restart counter names the attempt -- a worker group restarted by the same agent never
+    reads the files (unique id, init outcomes) of the attempt before it."""
     if directory is not None:
         return os.path.join(directory, "rccl_uid")
     if tag is None:
         ppid = os.getppid()
-        tag = f"{os.environ.get('MASTER_PORT', '29500')}_{ppid}_{_proc_start_time(ppid)}"
-    return f"/tmp/radian_rccl_uid_{tag}"
+        attempt = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+        tag = f"{os.environ.get('MASTER_PORT', '29500')}_{ppid}_{_proc_start_time(ppid)}_a{attempt}"
+    return os.path.join(tempfile.gettempdir(), f"radian_rccl_uid_{tag}")
+
+
+class StartupFailed(RuntimeError):
+    """The collective start-up cannot complete (a peer reported a failure while this rank is still inside
+    ncclCommInitRank, which cannot be cancelled): the process should exit non-zero NOW so that its launcher stops the job
+    (launch.wait_all / torch.distributed.run both do).  `stuck` tells the caller that a helper thread is still blocked in
+    the RCCL call: leave with os._exit, not through interpreter shutdown."""
+
+    def __init__(self, msg, stuck=False):
+        super().__init__(msg)
+        self.stuck = stuck
 
 
 class Rendezvous:
@@ -48,11 +64,25 @@ class Rendezvous:
         self.dir, self.rank, self.world, self.timeout = directory, rank, world, timeout
         os.makedirs(directory, exist_ok=True)
 
-    def gather(self, phase, value):
+    def publish(self, phase, value):
         mine = os.path.join(self.dir, f"{phase}.{self.rank}")
         with open(mine + ".tmp", "w") as f:
             f.write(value)
         os.replace(mine + ".tmp", mine)
+
+    def peek(self, phase):
+        """{rank: value} of what has been published for `phase` so far (no waiting)"""
+        out = {}
+        for r in range(self.world):
+            try:
+                with open(os.path.join(self.dir, f"{phase}.{r}")) as f:
+                    out[r] = f.read()
+            except OSError:
+                pass
+        return out
+
+    def gather(self, phase, value):
+        self.publish(phase, value)
         out = []
         t0 = time.time()
         for r in range(self.world):
@@ -96,8 +126,21 @@ class SingleComm:
     def bcast_artifacts(self, be, load_fn):
         load_fn(be)
 
+    def allgather(self, value):
+        return [float(value)]
+
+    def nranks_seen(self):
+        return 1
+
     def close(self):
         pass
+
+
+def _allgather_by_max(comm, value):
+    """every rank's non-negative value, by one max-reduction of a one-hot vector (the comms only offer max)"""
+    v = np.zeros(comm.world, dtype=np.float64)
+    v[comm.rank] = float(value)
+    return [float(x) for x in comm.allreduce_max(v)]
 
 
 class RcclComm:
@@ -117,6 +160,13 @@ class RcclComm:
         if self.rank == 0:
             load_fn(be)
         be.rccl_bcast_model(0)
+
+    def allgather(self, value):
+        return _allgather_by_max(self, value)
+
+    def nranks_seen(self):
+        """the communicator's size as RCCL reports it (ncclCommCount)"""
+        return self.be.rccl_comm_count()
 
     def close(self):
         pass
@@ -155,6 +205,13 @@ class FileComm:
     def bcast_artifacts(self, be, load_fn):
         load_fn(be)
 
+    def allgather(self, value):
+        return self._exchange(value)
+
+    def nranks_seen(self):
+        """ranks that answered the latest exchange (there is no communicator to ask)"""
+        return len(self._exchange(0.0))
+
     def close(self):
         self.barrier()
         # once everyone has passed exchange k, every file of exchanges < k has been read by all ranks; the files of the
@@ -166,14 +223,18 @@ class FileComm:
                 pass
 
 
-def connect(be, rank, world, uid_file, allow_file_fallback=True, timeout=120.0, force_collective=False):
+def connect(be, rank, world, uid_file, allow_file_fallback=True, timeout=120.0, force_collective=False, stuck_grace=10.0):
     """Collective choice of the transport -> (comm, kind) with kind 'rccl' | 'file-fallback' | 'single'.
 
     Phase 1 (nothing collective has been called yet): every rank checks that librccl loads (rank 0 also draws the unique
-    id) and publishes ok / fail; if anyone failed, NO rank calls ncclCommInitRank.  Phase 2: every rank calls
-    ncclCommInitRank and publishes its outcome; RCCL is used only if all succeeded, otherwise every rank drops its
-    communicator and uses the file transport (or raises, with allow_file_fallback=False, so that the launcher can report
-    and stop the job).  A rank that dies in between makes the others' gather time out and raise."""
+    id) and publishes ok / fail; if anyone failed, NO rank calls ncclCommInitRank and all use the file transport.
+    Phase 2: ncclCommInitRank runs on a helper thread while the rank's main thread watches the rendezvous.  Outcomes:
+      * every rank's init returned ok                      -> RCCL everywhere;
+      * every rank's init RETURNED and some failed         -> everyone drops its communicator, file transport everywhere
+        (this is what two ranks on one GPU do: RCCL refuses the duplicate device on both sides at once);
+      * a peer published a failure (or vanished) while this rank is STILL inside ncclCommInitRank -- the collective cannot
+        complete and cannot be cancelled -> StartupFailed after `stuck_grace` seconds: fail fast, the launcher stops the job.
+    With allow_file_fallback=False every failure raises instead (the launcher reports and stops the job)."""
     if world == 1 and not force_collective:   # (force_collective: a one-rank RCCL communicator, for the worker-route test)
         return SingleComm(), "single"
     rdv = Rendezvous(uid_file + ".rdv", rank, world, timeout)
@@ -191,11 +252,32 @@ def connect(be, rank, world, uid_file, allow_file_fallback=True, timeout=120.0, 
     errors = [f"rank {r}: {v[5:].strip()}" for r, v in enumerate(phase1) if v.startswith("fail")]
     if not errors:
         uid0 = bytes.fromhex(phase1[0][3:])
-        try:
-            be.rccl_init(rank, world, uid0)
-            mine = "ok"
-        except Exception as e:
-            mine = f"fail: {e}"
+        box = {}
+
+        def init():
+            try:
+                be.rccl_init(rank, world, uid0)
+                box["out"] = "ok"
+            except Exception as e:
+                box["out"] = f"fail: {e}"
+
+        th = threading.Thread(target=init, name="rccl-init", daemon=True)
+        th.start()
+        t0, seen_fail = time.time(), None
+        while th.is_alive():
+            th.join(0.02)
+            if not th.is_alive():
+                break
+            now = time.time()
+            failed = {r: v for r, v in rdv.peek("init").items() if v.startswith("fail")}
+            if failed and seen_fail is None:
+                seen_fail = now
+            if seen_fail is not None and now - seen_fail > stuck_grace:
+                raise StartupFailed("RCCL start-up failed on " + "; ".join(f"rank {r}: {v[5:].strip()}" for r, v in sorted(failed.items()))
+                                    + f"; rank {rank} is still inside ncclCommInitRank and cannot leave it", stuck=True)
+            if now - t0 > timeout:
+                raise StartupFailed(f"rank {rank}: ncclCommInitRank did not return within {timeout:.0f} s", stuck=True)
+        mine = box["out"]
         phase2 = rdv.gather("init", mine)
         errors = [f"rank {r}: {v[5:].strip()}" for r, v in enumerate(phase2) if v.startswith("fail")]
         if not errors:
@@ -212,6 +294,31 @@ def connect(be, rank, world, uid_file, allow_file_fallback=True, timeout=120.0, 
         import sys
         print(f"[radian_amd.dist] {msg}; all {world} ranks use the file transport and load the artefacts themselves", file=sys.stderr)
     return FileComm(rank, world, uid_file + ".fc"), "file-fallback"
+
+
+def leave(rank, world, uid_file, timeout=10.0):
+    """After comm.close(): remove the launch's rendezvous files when nobody needs them any more (a foreign launcher has no
+    scratch directory to delete).  Every rank says goodbye; rank 0 waits for the others (bounded), then deletes."""
+    import glob
+    import shutil
+    d = uid_file + ".rdv"
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, f"bye.{rank}"), "w"):
+            pass
+        if rank != 0:
+            return
+        t0 = time.time()
+        while time.time() - t0 < timeout and not all(os.path.exists(os.path.join(d, f"bye.{r}")) for r in range(world)):
+            time.sleep(0.005)
+        shutil.rmtree(d, ignore_errors=True)
+        for p in glob.glob(glob.escape(uid_file) + "*"):
+            try:
+                os.remove(p)
+            except OSError:
+                pass
+    except OSError:
+        pass
 
 
 # ------------------------------------------------------------------------------------------------ work distribution
@@ -264,7 +371,7 @@ class FileReadQueue:
     moves the cursor to the next file when the file is used up.  Only the claimant needs the file's read count, so a
     rank opens exactly the files it takes work from; claims come out in increasing (file, read) order."""
 
-    def __init__(self, path, block=256):
+    def __init__(self, path, block=256, on_claim=None):
         import fcntl
         self._fcntl = fcntl
         self.block = int(block)
@@ -273,6 +380,7 @@ class FileReadQueue:
         self._fd = os.open(path, os.O_RDWR | os.O_CREAT, 0o600)
         self.claimed = []          # [(file, lo, hi)]
         self.opened = set()        # files whose read count this rank had to look up
+        self.on_claim = on_claim   # on_claim(file, lo, hi) as soon as a block is this rank's (the launcher's streaming merge)
 
     def claims(self, sources):
         """Generator of (file_index, lo, hi) blocks owned by this rank; sources[i].n_reads() gives a file's read count."""
@@ -301,6 +409,8 @@ class FileReadQueue:
             if got is None:
                 return
             self.claimed.append(got)
+            if self.on_claim is not None:
+                self.on_claim(*got)
             yield got
 
     def close(self):
@@ -326,9 +436,12 @@ def _key(k):
 
 
 def iter_results_file(path):
+    """records of a rank's result file; the launcher's claim / end marks (JSON objects) are not records"""
     with open(path) as f:
         for line in f:
-            yield json.loads(line)
+            o = json.loads(line)
+            if isinstance(o, list):
+                yield o
 
 
 def merge_result_files(paths):

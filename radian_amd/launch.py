@@ -14,25 +14,128 @@ import tempfile
 import time
 
 
+class StreamMerger:
+    """Merges the per-rank result files into reads-{n}.fasta WHILE the ranks are still writing them, so that what is left
+    to do after the last worker exits is the last block, not every read (the merge runs at ~2*10^5 records/s: 1 M reads
+    merged afterwards would add seconds behind ~20 s of 8-GPU compute).
+
+    A rank's file is a sequence of lines in the order things happen on that rank: {"claim": [file, lo, hi]} when it takes a
+    block from the work queue, [key, read_id, sequence] per finished read (increasing key: results leave the driver in
+    input order), {"end": true} last.  A record with key m can be written as soon as no rank can still produce a smaller
+    key: a rank with parsed-but-unwritten records is represented by the first of them; one without is bounded from below
+    by the first key it may still produce -- the next expected read of its oldest unfinished claim (a claim is finished
+    when a record of a later claim, or the end mark, shows up: skipped reads leave no record), else its latest key.
+    One record per rank is all the merge needs in memory beyond what it has parsed and not yet been allowed to write."""
+
+    INF = (float("inf"),)
+
+    def __init__(self, scratch, world, fasta_dir):
+        from collections import deque
+        from .basecall import FastaWriter
+        self.paths = [os.path.join(scratch, f"rank{r}.jsonl") for r in range(world)]
+        self.world = world
+        self.fh = [None] * world
+        self.tail = [b""] * world
+        self.recs = [deque() for _ in range(world)]      # parsed, not yet written
+        self.claims = [deque() for _ in range(world)]    # [file, next expected read, hi] of unfinished claims, oldest first
+        self.last = [(-1,)] * world                      # latest key seen from the rank
+        self.ended = [False] * world
+        self.writer = FastaWriter(fasta_dir)
+        self.n = 0
+
+    def _read(self, r):
+        if self.fh[r] is None:
+            try:
+                self.fh[r] = open(self.paths[r], "rb")
+            except OSError:
+                return
+        data = self.fh[r].read()
+        if not data:
+            return
+        lines = (self.tail[r] + data).split(b"\n")
+        self.tail[r] = lines.pop()
+        for ln in lines:
+            if not ln:
+                continue
+            o = json.loads(ln)
+            if isinstance(o, dict):
+                if "claim" in o:
+                    fi, lo, hi = o["claim"]
+                    self.claims[r].append([fi, lo, hi])
+                elif o.get("end"):
+                    self.ended[r] = True
+                    self.claims[r].clear()
+                continue
+            key = _key(o[0])
+            cl = self.claims[r]
+            while cl and not (len(key) == 2 and cl[0][0] == key[0] and cl[0][1] <= key[1] < cl[0][2]):
+                cl.popleft()                                 # an older claim with nothing more to come
+            if cl:
+                cl[0][1] = key[1] + 1
+            self.last[r] = key
+            self.recs[r].append((key, o[1], o[2]))
+
+    def _bound(self, r):
+        """no record that rank r has not handed over yet can have a key below this"""
+        if self.recs[r]:
+            return self.recs[r][0][0]
+        if self.ended[r]:
+            return self.INF
+        if self.claims[r]:
+            return (self.claims[r][0][0], self.claims[r][0][1])
+        return self.last[r]
+
+    def poll(self):
+        for r in range(self.world):
+            if not self.ended[r]:
+                self._read(r)
+        while True:
+            bounds = [self._bound(r) for r in range(self.world)]
+            best = None
+            for r in range(self.world):
+                if self.recs[r] and (best is None or bounds[r] < bounds[best]):
+                    best = r
+            if best is None or any(bounds[r] < bounds[best] for r in range(self.world) if r != best):
+                return
+            _, rid, seq = self.recs[best].popleft()
+            self.writer.write(rid, seq)
+            self.n += 1
+
+    def finish(self):
+        """every worker has exited: read what is left, write it, close the FASTA.  -> number of records written"""
+        try:
+            for r in range(self.world):
+                self._read(r)
+                self.ended[r] = True      # a rank that died before its end mark has nothing more to say either
+                self.claims[r].clear()
+            self.poll()
+            assert not any(self.recs), "internal: records left after the final merge pass"
+        finally:
+            self.close()
+        return self.n
+
+    def close(self):
+        self.writer.close()
+        for f in self.fh:
+            if f is not None:
+                f.close()
+
+
+def _key(k):
+    return tuple(k) if isinstance(k, (list, tuple)) else (k,)
+
+
 def merge_to_fasta(scratch, world, fasta_dir):
-    """Per-rank result files -> reads-{n}.fasta in input order; one record per rank in memory at a time."""
-    from .basecall import FastaWriter
-    from .dist import merge_result_files
-    writer = FastaWriter(fasta_dir)
-    n = 0
-    try:
-        for _, rid, seq in merge_result_files([os.path.join(scratch, f"rank{r}.jsonl") for r in range(world)]):
-            writer.write(rid, seq)
-            n += 1
-    finally:
-        writer.close()
-    return n
+    """Per-rank result files (complete) -> reads-{n}.fasta in input order."""
+    return StreamMerger(scratch, world, fasta_dir).finish()
 
 
-def wait_all(procs, poll=0.05):
+def wait_all(procs, poll=0.05, on_poll=None):
     """Wait for every worker; as soon as one exits non-zero, stop the others (they may be blocked in a collective that
-    will never complete) and return the exit codes."""
+    will never complete) and return the exit codes.  on_poll() runs once per poll interval while workers are alive."""
     while True:
+        if on_poll is not None:
+            on_poll()
         rcs = [p.poll() for p in procs]
         if any(rc not in (None, 0) for rc in rcs):
             for p in procs:
@@ -51,41 +154,100 @@ def wait_all(procs, poll=0.05):
         time.sleep(poll)
 
 
+def run_ranks(world, cmd, env_extra=None, capture_rank0=False, on_poll=None):
+    """Start `cmd` once per rank (RANK / LOCAL_RANK / WORLD_SIZE in the environment; fresh processes -- the parent has not
+    touched a GPU and never does), wait with wait_all's one-fails-all-stop rule.  capture_rank0: rank 0's stdout is
+    collected and returned (the others' goes to the parent's stderr), for launchers whose rank 0 prints the job's result.
+    on_poll(): called every poll while the workers run (the CLI's streaming merge).  -> (exit codes, rank 0's stdout)."""
+    import threading
+    procs, chunks = [], []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **(env_extra or {}))
+        out = None
+        if capture_rank0:
+            out = subprocess.PIPE if rank == 0 else sys.stderr
+        procs.append(subprocess.Popen(list(cmd), env=env, stdout=out))
+    reader = None
+    if capture_rank0:
+        def pump():
+            for line in procs[0].stdout:
+                chunks.append(line)
+        reader = threading.Thread(target=pump, daemon=True)
+        reader.start()
+    rcs = wait_all(procs, on_poll=on_poll)
+    if reader is not None:
+        reader.join(timeout=5.0)
+    return rcs, b"".join(chunks).decode("utf-8", "replace")
+
+
 def run_multi_gpu(args, argv):
     from . import fast5
     from .basecall import load_artifacts
     world = args.gpus
     load_artifacts(args)   # host-only validation: raises here, in the parent, exactly what a single-GPU run would raise
     scratch = tempfile.mkdtemp(prefix="radian_mgpu_")
+    merger = None
     try:
         with open(os.path.join(scratch, "files.json"), "w") as f:
             json.dump(fast5.list_files(args.fast5_dir), f)   # one enumeration: every rank sees the same file order
-        procs = []
-        for rank in range(world):
-            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
-                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-            cmd = [sys.executable, "-m", "radian_amd.launch", "--worker", scratch, "--"] + list(argv)
-            procs.append(subprocess.Popen(cmd, env=env))
-        rcs = wait_all(procs)
+        merger = StreamMerger(scratch, world, args.fasta_dir)
+        cmd = [sys.executable, "-m", "radian_amd.launch", "--worker", scratch, "--"] + list(argv)
+        rcs, _ = run_ranks(world, cmd, on_poll=merger.poll)   # the FASTA grows while the ranks work
         if any(rcs):
             raise SystemExit(f"multi-GPU run failed: worker exit codes {rcs}")
-        merge_to_fasta(scratch, world, args.fasta_dir)
+        n = merger.finish()
+        merger = None
+        ranks = []
+        for r in range(world):
+            with open(os.path.join(scratch, f"contexts{r}.json")) as f:
+                ranks.append(json.load(f))
+        return {"records": n, "ranks": ranks}   # what each rank ran with: device, device contexts, agreed transport
     finally:
+        if merger is not None:
+            merger.close()
         shutil.rmtree(scratch, ignore_errors=True)
 
 
+class _RankFile:
+    """rank{r}.jsonl as StreamMerger reads it; flushed at claims and every 0.1 s so the parent can merge as the rank goes"""
+
+    def __init__(self, path):
+        import threading
+        self.f = open(path, "w")
+        self.t = time.time()
+        self.lock = threading.Lock()   # claims come from the driver's reading thread, results from its host stage
+
+    def claim(self, fi, lo, hi):
+        with self.lock:
+            self.f.write(json.dumps({"claim": [fi, lo, hi]}) + "\n")
+            self.f.flush()
+
+    def emit(self, key, rid, seq):
+        with self.lock:
+            self.f.write(json.dumps([list(key) if isinstance(key, tuple) else key, rid, seq]) + "\n")
+            now = time.time()
+            if now - self.t > 0.1:
+                self.f.flush()
+                self.t = now
+
+    def end(self):
+        with self.lock:
+            self.f.write(json.dumps({"end": True}) + "\n")
+            self.f.close()
+
+
 def run_rank(args, be, comm, scratch, sources, rank, world, stitch_pool=None, backends=None):
-    """One rank's share of the job, after the artefacts are on its device: claim work, basecall, write rank{r}.jsonl
-    (records in increasing (file, read) order), barrier."""
+    """One rank's share of the job, after the artefacts are on its device: claim work, basecall on `backends` (the device
+    contexts of this rank's GPU; default: the one that received the broadcast), write rank{r}.jsonl as it goes, barrier."""
     from .basecall import run
     from .dist import FileReadQueue
-    queue = FileReadQueue(os.path.join(scratch, "queue"), args.queue_block) if args.queue_block > 0 else None
-    tmp = os.path.join(scratch, f"rank{rank}.jsonl.tmp")
-    with open(tmp, "w") as f:
-        def emit(key, rid, seq):
-            f.write(json.dumps([list(key) if isinstance(key, tuple) else key, rid, seq]) + "\n")
-        run(args, backends or be, writer=None, shard=(rank, world), stitch_pool=stitch_pool, queue=queue, sources=sources, on_result=emit)
-    os.replace(tmp, os.path.join(scratch, f"rank{rank}.jsonl"))
+    out = _RankFile(os.path.join(scratch, f"rank{rank}.jsonl"))
+    queue = None
+    if args.queue_block > 0:
+        queue = FileReadQueue(os.path.join(scratch, "queue"), args.queue_block, on_claim=out.claim)
+    run(args, backends or be, writer=None, shard=(rank, world), stitch_pool=stitch_pool, queue=queue, sources=sources, on_result=out.emit)
+    out.end()
     if queue is not None:
         queue.close()
     comm.barrier()
@@ -96,25 +258,40 @@ def worker(scratch, argv):
     from . import fast5
     from .backend import Backend
     from .basecall import apply_artifacts, build_parser, load_artifacts, make_stitch_pool
-    from .dist import connect, env_rank_world, uid_path
+    from .dist import StartupFailed, connect, env_rank_world, uid_path
     args = build_parser().parse_args(argv)
     rank, local_rank, world = env_rank_world()
     pool = make_stitch_pool(args.stitch_workers) if args.decode_type == "chunk" else None   # before the GPU is touched
-    be = Backend(int(os.environ.get("RD_CLI_DEVICE", local_rank)))   # override only for rehearsals on a 1-GPU box
+    device = int(os.environ.get("RD_CLI_DEVICE", local_rank))   # override only for rehearsals on a 1-GPU box
+    be = Backend(device)
     # every rank uses RCCL or none does (dist.connect); the rendezvous lives in the launcher's private scratch directory
-    comm, kind = connect(be, rank, world, uid_path(directory=scratch), force_collective=True)
+    try:
+        comm, kind = connect(be, rank, world, uid_path(directory=scratch), force_collective=True)
+    except StartupFailed as e:
+        print(f"[radian_amd.launch] rank {rank}: {e}", file=sys.stderr)
+        sys.stderr.flush()
+        os._exit(3)   # a helper thread is stuck inside ncclCommInitRank; the parent stops the other ranks
     # rank 0 parses / repacks the artefacts; everyone gets the device images by one broadcast (file transport: each
     # rank loads them itself).  The parent has validated them already, so rank 0 cannot fail here for a bad argument.
     comm.bcast_artifacts(be, lambda b: apply_artifacts(args, b, load_artifacts(args)))
-    be.set_precision(args.precision)   # context state, not part of the broadcast images
-    be.set_logits(args.logits)
-    be.set_decode_math(args.decode_math)
+    # the rank's further device contexts (--device-contexts, as in a single-GPU run: one context's forward overlaps the
+    # other's beam search) take the images from the one that received the broadcast -- a device copy, no second parse
+    backends = [be] + [Backend(device) for _ in range(max(1, args.device_contexts) - 1)]
+    for b in backends[1:]:
+        b.clone_artifacts_from(be)
+    for b in backends:
+        b.set_precision(args.precision)   # context state, not part of the broadcast images
+        b.set_logits(args.logits)
+        b.set_decode_math(args.decode_math)
     args._lm_loaded = (args.rna_model != "None" and args.decode_type == "global" and os.path.exists(args.rna_model))
     with open(os.path.join(scratch, "files.json")) as f:
         sources = [fast5.Fast5Source(p) for p in json.load(f)]
-    run_rank(args, be, comm, scratch, sources, rank, world, stitch_pool=pool)
+    with open(os.path.join(scratch, f"contexts{rank}.json"), "w") as f:
+        json.dump({"device": device, "contexts": len(backends), "transport": kind}, f)   # (what the worker-route test reads)
+    run_rank(args, be, comm, scratch, sources, rank, world, stitch_pool=pool, backends=backends)
     comm.close()
-    be.close()
+    for b in reversed(backends):
+        b.close()
     if pool is not None:
         pool.shutdown()
 

@@ -144,11 +144,23 @@ def test_world8_file_queue_order_and_fasta_rotation(tmp_path):
     scratch = tmp_path / "scratch"
     scratch.mkdir()
     json.dump(files, open(scratch / "files.json", "w"))
-    procs, outs = _spawn([os.path.join(ROOT, "tests", "_queue_worker.py"), str(scratch), "0.002"], world)
-    assert all(p.returncode == 0 for p in procs), outs
     out_dir = tmp_path / "out"
     out_dir.mkdir()
-    n = launch.merge_to_fasta(str(scratch), world, str(out_dir))
+    # the launcher's route: the parent merges WHILE the ranks work (launch.StreamMerger fed by wait_all's poll)
+    import time
+    merger = launch.StreamMerger(str(scratch), world, str(out_dir))
+    progress = []
+    def poll():
+        merger.poll()
+        progress.append(merger.n)
+    rcs, _ = launch.run_ranks(world, [sys.executable, os.path.join(ROOT, "tests", "_queue_worker.py"), str(scratch), "0.002"],
+                              env_extra={"OMP_NUM_THREADS": "1"}, on_poll=poll)
+    t_last = time.time()
+    assert rcs == [0] * world, rcs
+    n = merger.finish()
+    tail = time.time() - t_last
+    assert tail <= 0.5, f"merge tail after the last worker: {tail:.2f} s"
+    assert progress[-1] >= 0.8 * n and any(0 < x < n for x in progress), (progress[-1], n)   # it really merged as they went
     # expected: the single-process order = files in list order, reads in name order
     exp = []
     for path in files:
@@ -249,3 +261,72 @@ def test_launcher_stops_job_when_a_worker_fails(tmp_path):
     argv = [str(tmp_path / "in"), str(tmp_path / "out"), "--sig-model", "synthetic:1", "--sig-config", "none", "--gpus", "2"]
     with pytest.raises(FileNotFoundError):   # default --rna-model is not shipped; global mode needs it
         launch.run_multi_gpu(basecall.build_parser().parse_args(argv), argv)
+
+
+def test_bench_self_launch_with_stub_ranks(tmp_path, capfd):
+    """`python bench.py --gpus N` without a launcher: bench.self_launch starts N fresh ranks (here a device-less stand-in
+    that runs the product's start-up through the launcher's private rendezvous directory), forwards rank 0's ONE JSON line,
+    removes its scratch directory; a failing rank stops the others promptly and the launcher returns non-zero."""
+    import glob
+    import tempfile
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    stub = os.path.join(ROOT, "tests", "_bench_stub_rank.py")
+    before = set(glob.glob(os.path.join(tempfile.gettempdir(), "radian_bench_*")))
+    rc = bench.self_launch(3, [], worker_cmd=[sys.executable, stub, "ok"])
+    out = capfd.readouterr().out.strip().splitlines()
+    assert rc == 0 and len(out) == 1, out
+    line = json.loads(out[0])
+    assert line["n_gpus"] == 3 and line["rccl_nranks"] == 3 and line["ms_per_step_per_rank"] == [1.0, 2.0, 3.0]
+    t0 = time.time()
+    rc = bench.self_launch(3, [], worker_cmd=[sys.executable, stub, "fail1"])
+    cap = capfd.readouterr()
+    assert rc == 1 and cap.out.strip() == "" and "exit codes" in cap.err and time.time() - t0 < 30
+    assert set(glob.glob(os.path.join(tempfile.gettempdir(), "radian_bench_*"))) == before
+
+
+def test_bench_parent_never_loads_the_hip_library(tmp_path):
+    """The launcher process of `bench.py --gpus N` must not touch a GPU: it runs to completion (here: to the failure of its
+    ranks, which have no GPU) without libradian_hip.so ever being mapped -- RADIAN_HIP_LIB points at a file that is not a
+    library, so any load in the PARENT would raise there instead of in the ranks."""
+    bogus = tmp_path / "not_a_lib.so"
+    bogus.write_text("x")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=dict(os.environ, RADIAN_HIP_LIB=str(bogus)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    err = r.stderr.decode()
+    assert r.returncode == 1 and r.stdout.decode().strip() == ""
+    assert "multi-GPU run failed: rank exit codes" in err          # the parent got as far as reaping its ranks
+    assert err.count("invalid ELF header") >= 1 or "not_a_lib" in err   # ... and the ranks were the ones that tried to load it
+
+
+def test_connect_fails_fast_when_a_peer_fails_while_this_rank_is_inside_init(tmp_path):
+    """a rank whose ncclCommInitRank fails leaves its peers blocked inside theirs.  The peers' main threads watch
+    the rendezvous and raise StartupFailed(stuck=True) after the grace period instead of hanging for the full timeout."""
+    script = tmp_path / "s.py"
+    script.write_text(
+        "import os, sys, time\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from radian_amd import dist\n"
+        "rank, _, world = dist.env_rank_world()\n"
+        "class Be:\n"
+        "    def rccl_unique_id(self): return bytes(128)\n"
+        "    def rccl_probe(self): pass\n"
+        "    def rccl_init(self, r, w, uid):\n"
+        "        if rank == 1: raise RuntimeError('ncclCommInitRank: unhandled system error')\n"
+        "        time.sleep(600)   # the collective never completes without rank 1\n"
+        "t0 = time.time()\n"
+        "try:\n"
+        f"    dist.connect(Be(), rank, world, os.path.join({str(tmp_path)!r}, 'uid'), timeout=60, stuck_grace=0.5)\n"
+        "except dist.StartupFailed as e:\n"
+        "    assert e.stuck and 'rank 1' in str(e) and time.time() - t0 < 20, e\n"
+        "    os._exit(3)\n"
+        "except RuntimeError as e:\n"
+        "    sys.exit(4 if rank == 1 else 5)   # rank 1 waits for the others' outcome, which never comes\n"
+        "sys.exit(0)\n")
+    import time
+    from radian_amd import launch
+    t0 = time.time()
+    rcs, _ = launch.run_ranks(3, [sys.executable, str(script)])
+    assert rcs[0] == 3 or rcs[2] == 3, rcs       # a stuck rank left first; wait_all then stopped the rest
+    assert all(rc != 0 for rc in rcs) and time.time() - t0 < 40, rcs

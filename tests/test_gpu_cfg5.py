@@ -61,7 +61,7 @@ def test_long_context_hashed_lm_vs_oracle(oracle, k, order, W):
                     if k <= 40:
                         assert long_enough and any(not np.array_equal(exp[i], nolm[i]) for i in long_enough)
         if k == 256:   # the window really is exceeded
-            assert max(len(e) for e in exp) > 256 or True
+            assert max(len(e) for e in exp) > 256   # (270+ labels on the last set; 300+ on the flat one)
     finally:
         be.close()
 

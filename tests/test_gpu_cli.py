@@ -40,11 +40,10 @@ def _read_fasta(d):
 
 
 def _expected(be, oracle, ids, sig, chunk, step, W, mode, table=None, k=0):
-    from radian_amd.preprocess import mad_normalise, get_windows
     out = []
     for r in ids:
-        win, pad = get_windows(mad_normalise(sig[r], 4), chunk, step)
-        probs = be.forward(win.astype(np.float32))
+        win, pad = oracle.get_windows(oracle.mad_normalise(sig[r], 4), chunk, step)   # the expected side is oracle-only
+        probs = be.forward(np.asarray(win, dtype=np.float32))
         if mode == "chunk":
             frags = []
             for i in range(probs.shape[0]):
@@ -107,16 +106,20 @@ def test_cli_worker_path_with_rccl_single_rank(tmp_path, golden_dir):
     argv_b = [in_dir, str(b_dir)] + argv[2:]
     args = basecall.build_parser().parse_args(argv_b)
     args.gpus = 1
-    launch.run_multi_gpu(args, argv_b)
+    report = launch.run_multi_gpu(args, argv_b)
     assert _read_fasta(str(a_dir)) == _read_fasta(str(b_dir))
     assert len(_read_fasta(str(b_dir))) == 5
+    # the worker drives its GPU the way the single-GPU CLI does: --device-contexts (default 2) contexts, the further ones
+    # filled by rd_clone_artifacts from the one that received the broadcast; the one-rank communicator is RCCL's
+    assert report["ranks"] == [{"device": 0, "contexts": 2, "transport": "rccl"}], report
+    assert report["records"] == 5
 
 
 def test_cli_cfg5_flags_f16_logits_and_hashed_long_context(tmp_path, golden_dir, oracle):
     """the configs[4] flags end to end through the CLI: --logits f16 --lm-hashed-context --context-len 40 --beam-width 25 (global),
     against the oracle's long-context decode of the f16-rounded GPU rows; and both precision flags reach the device."""
     from radian_amd import Backend, basecall, weights, lm
-    from radian_amd.preprocess import mad_normalise, get_windows
+    mad_normalise, get_windows = oracle.mad_normalise, oracle.get_windows
     ids, sig, in_dir, lm_path = _make_inputs(tmp_path, golden_dir)
     out_dir = tmp_path / "out"
     out_dir.mkdir()
@@ -130,7 +133,7 @@ def test_cli_cfg5_flags_f16_logits_and_hashed_long_context(tmp_path, golden_dir,
     exp = []
     for r in ids:
         win, pad = get_windows(mad_normalise(sig[r], 4), 1024, 512)
-        probs = be.forward(win.astype(np.float32)).astype(np.float16).astype(np.float32)
+        probs = be.forward(np.asarray(win, dtype=np.float32)).astype(np.float16).astype(np.float32)
         mat = oracle.assemble_matrices(probs, pad, 512)
         lab = oracle.beam_search_batch(mat, [0], [mat.shape[0]], 25, table, 0.0, 5.0, 40, hash_order=k)[0]
         exp.append((r, "".join("ACGT"[c] for c in lab)[::-1]))
