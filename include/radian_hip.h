@@ -217,6 +217,36 @@ int rd_basecall_reads_global_resident(rd_ctx* ctx, const float* d_signal, const 
 int rd_pipe_submit_reads(rd_ctx* ctx, const float* d_signal, const int64_t* read_off, int n_reads, int chunk_len,
                          int step, int beam_width, uint8_t* labels_out, int32_t* label_len);
 
+/* The same pipeline over batches of WHOLE READS, for both decode types and for raw input -- the loop body of
+ * radian/basecall.py:77-121 (mad_normalise, get_windows, predict, assemble_matrices, beam_search) for a stream of read
+ * batches inside ONE context: on the next forward lane [raw form: H2D of the samples out of the lane's pinned staging block,
+ * MAD normalisation] -> streamed forward -> [global: per-read assembly]; on the decode stream, per GROUP of batches, the
+ * beam search of every read (global; LM-gated with use_lm) or window (chunk) + labels to the host.  A group closes after
+ * rd_pipe_config batches, or -- global mode -- as soon as its forward rows cover the beam search of its longest read (a
+ * read's search is one serial chain of a time step per sample, which only the next group's forwards can hide).
+ * Contracts as rd_basecall_reads_global / rd_basecall_raw_global / rd_basecall_raw_chunk, except:
+ *   - labels_out / label_len / status of a submitted batch are valid once rd_pipe_progress reports it delivered (or after
+ *     rd_pipe_flush); the caller keeps them alive until then.  raw / read_off / label_off may be reused when the call returns;
+ *     d_signal must stay untouched until delivery;
+ *   - empty reads are rejected (RD_ERR_ARG): basecall.py:77-82 skips them before this point.
+ * Batches whose read lengths equal the previous batch's on the same lane reuse its tile descriptors; otherwise the plan
+ * is rebuilt on the host and uploaded behind the lane's previous forward -- no stream is drained for it. */
+int rd_pipe_submit_reads_global(rd_ctx* ctx, const float* d_signal, const int64_t* read_off, int n_reads, int chunk_len,
+                                int step, int beam_width, int use_lm, double s_thr, double r_thr, uint8_t* labels_out,
+                                const int64_t* label_off, int32_t* label_len);
+int rd_pipe_submit_raw_global(rd_ctx* ctx, const int16_t* raw, const int64_t* read_off, int n_reads, int outlier_clip,
+                              int chunk_len, int step, int beam_width, int use_lm, double s_thr, double r_thr,
+                              uint8_t* labels_out, const int64_t* label_off, int32_t* label_len, int32_t* status);
+int rd_pipe_submit_raw_chunk(rd_ctx* ctx, const int16_t* raw, const int64_t* read_off, int n_reads, int outlier_clip,
+                             int chunk_len, int step, int beam_width, uint8_t* labels_out, int32_t* label_len, int32_t* status);
+/* Deliver finished groups of the reads-level pipeline to their callers, in submission order.  Without blocking when
+ * wait_for <= 0; otherwise returns once at least wait_for of the batches submitted so far (counted since the context was
+ * created) have been delivered, closing the open group if what is awaited sits in it.  *delivered = that count. */
+int rd_pipe_progress(rd_ctx* ctx, int64_t wait_for, int64_t* delivered);
+/* Batches submitted to the reads-level pipeline so far: right after a submit, the number rd_pipe_progress must reach for
+ * that batch to have been delivered. */
+int rd_pipe_submitted(rd_ctx* ctx, int64_t* submitted);
+
 /* ---- kernel timing on the launch stream (HIP events) --------------------------------------- */
 #define RD_TIMER_CONV 0   /* dilated conv 256->256 (MFMA), the dominant kernel */
 #define RD_TIMER_DECODE 1 /* beam search */

@@ -44,6 +44,11 @@ SIGNATURES = {
     "rd_basecall_reads_chunk_resident": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp]),
     "rd_basecall_reads_global_resident": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp]),
     "rd_pipe_submit_reads": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp]),
+    "rd_pipe_submit_reads_global": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp]),
+    "rd_pipe_submit_raw_global": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp, c_vp]),
+    "rd_pipe_submit_raw_chunk": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
+    "rd_pipe_progress": (c_i, [c_vp, c_i64, c_i64p]),
+    "rd_pipe_submitted": (c_i, [c_vp, c_i64p]),
     "rd_normalise_reads": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_vp, c_vp]),
     "rd_basecall_raw_chunk": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
     "rd_basecall_raw_global": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp, c_vp]),

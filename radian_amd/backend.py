@@ -21,6 +21,32 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
+class PipeTicket:
+    """One batch queued on a Backend's reads-level pipeline (Backend.pipe_submit_raw).  The arrays the library writes into
+    live here until the batch is delivered."""
+
+    def __init__(self, be, decode_type, off, n):
+        self.be, self.decode_type, self.off, self.n = be, decode_type, off, n
+        self.status = np.zeros(n, dtype=np.int32)
+        self.labels = self.lens = self.label_off = self.nw = None
+        self.seq = 0
+
+    def done(self):
+        return self.be.pipe_progress(0) >= self.seq
+
+    def result(self):
+        """(labels, status) as basecall_raw_global / basecall_raw_chunk return them; blocks until delivered"""
+        if self.be.pipe_progress(self.seq) < self.seq:
+            raise RadianHipError("pipeline did not deliver the awaited batch")
+        if self.decode_type == "global":
+            return [self.labels[self.off[r]: self.off[r] + self.lens[r]].copy() for r in range(self.n)], self.status
+        out, w = [], 0
+        for n in self.nw:
+            out.append([self.labels[w + i, : self.lens[w + i]].copy() for i in range(n)])
+            w += n
+        return out, self.status
+
+
 class Backend:
     """Owns an rd_ctx.  All compute goes to the HIP library; nothing here falls back to the CPU."""
 
@@ -333,6 +359,52 @@ class Backend:
         self._check(self._L.rd_basecall_reads_global_resident(self._h, d_signal, _p(read_off), int(n_reads), int(chunk_len),
                                                               int(step), int(beam_width), 1 if use_lm else 0, float(s_threshold),
                                                               float(r_threshold), _p(labels), _p(label_off), _p(lens)))
+
+    # ------------------------------------------------------------------ reads-level pipeline (one context, pipe_reads.hip)
+    def pipe_submit_reads_global(self, d_signal, read_off, n_reads, chunk_len, step, beam_width, use_lm, s_threshold, r_threshold,
+                                 labels, label_off, lens):
+        """Pipelined global-mode batch of normalised reads resident in HBM (rd_pipe_submit_reads_global); labels / lens are
+        filled once pipe_progress reports the batch delivered (or at pipe_flush)."""
+        self._check(self._L.rd_pipe_submit_reads_global(self._h, d_signal, _p(read_off), int(n_reads), int(chunk_len), int(step),
+                                                        int(beam_width), 1 if use_lm else 0, float(s_threshold), float(r_threshold),
+                                                        _p(labels), _p(label_off), _p(lens)))
+
+    def pipe_progress(self, wait_for=0):
+        """Deliver finished groups of the reads-level pipeline; blocks until `wait_for` submits (counted over the context's
+        life) are delivered when wait_for > 0.  -> number of submits delivered so far."""
+        n = ctypes.c_int64(0)
+        self._check(self._L.rd_pipe_progress(self._h, int(wait_for), ctypes.byref(n)))
+        return n.value
+
+    def pipe_submit_raw(self, decode_type, raws, outlier_clip, chunk_len, step, beam_width, use_lm=False, s_threshold=0.0,
+                        r_threshold=0.0):
+        """Pipelined form of basecall_raw_global / basecall_raw_chunk: queue a batch of raw int16 reads and return a
+        PipeTicket; ticket.result() gives what the unpipelined call returns once the batch is delivered."""
+        flat, off = self._pack_raw(raws)
+        n = len(raws)
+        t = PipeTicket(self, decode_type, off, n)
+        if decode_type == "global":
+            t.labels = np.zeros(int(off[-1]) + 1, dtype=np.uint8)
+            t.lens = np.zeros(n, dtype=np.int32)
+            t.label_off = np.ascontiguousarray(off[:-1])
+            self._check(self._L.rd_pipe_submit_raw_global(self._h, _p(flat), _p(off), n, int(outlier_clip), int(chunk_len), int(step),
+                                                          int(beam_width), 1 if use_lm else 0, float(s_threshold), float(r_threshold),
+                                                          _p(t.labels), _p(t.label_off), _p(t.lens), _p(t.status)))
+        else:
+            t.nw = [self.count_windows(off[r + 1] - off[r], chunk_len, step) for r in range(n)]
+            tot = int(sum(t.nw))
+            t.labels = np.zeros((tot, chunk_len), dtype=np.uint8)
+            t.lens = np.zeros(tot, dtype=np.int32)
+            self._check(self._L.rd_pipe_submit_raw_chunk(self._h, _p(flat), _p(off), n, int(outlier_clip), int(chunk_len), int(step),
+                                                         int(beam_width), _p(t.labels), _p(t.lens), _p(t.status)))
+        t.seq = self.pipe_submitted()
+        return t
+
+    def pipe_submitted(self):
+        """batches submitted to the reads-level pipeline so far = the pipe_progress count at which the latest one is delivered"""
+        n = ctypes.c_int64(0)
+        self._check(self._L.rd_pipe_submitted(self._h, ctypes.byref(n)))
+        return n.value
 
     def pipe_config(self, group_batches):
         self._check(self._L.rd_pipe_config(self._h, int(group_batches)))

@@ -44,8 +44,13 @@ def build_parser():
     # extensions
     parser.add_argument("--device", default=0, type=int, help="GPU index (single-process run)")
     parser.add_argument("--gpus", default=1, type=int, help="shard reads over this many GPUs (one process each)")
-    parser.add_argument("--device-contexts", default=2, type=int,
-                        help="independent device contexts (streams) per GPU: batch i+1's forward overlaps batch i's beam search")
+    parser.add_argument("--device-contexts", default=None, type=int,
+                        help="independent device contexts per GPU, taking the batches in turn.  Default 1: a context pipelines by "
+                             "itself (forwards of consecutive batches on rotating streams, the beam search of a group of batches on a "
+                             "further stream under the next group's forwards); 2 with --no-pipeline")
+    parser.add_argument("--no-pipeline", action="store_true",
+                        help="one blocking device call per batch (rd_basecall_raw_*) instead of the in-context pipeline "
+                             "(rd_pipe_submit_raw_*); overlap then comes from --device-contexts 2 only")
     parser.add_argument("--precision", default="fp32", choices=["fp32", "f16x3", "bf16x3"],
                         help="matrix products of the signal model: exact fp32 MFMA (default); split-f16 products (22-bit operands, fp32 "
                              "accumulation, about 2x faster; DESIGN.md 4.7); three-term bf16 split (every fp32 operand exact, six bf16 "
@@ -67,9 +72,10 @@ def build_parser():
     parser.add_argument("--queue-block", default=256, type=int,
                         help="--gpus N: reads per claim of the per-node work queue (0: static round-robin by read index)")
     parser.add_argument("--gpu-batch-windows", default=None, type=int,
-                        help="device batch size across reads, in windows (chunk mode) or chunk_len-row units (global mode).  Default: 4096; "
-                             "in global mode a batch that holds long reads grows (up to 16384) until its forward covers the longest read's "
-                             "beam search, which is one serial chain per read")
+                        help="device batch size across reads, in windows (chunk mode) or chunk_len-row units (global mode).  Default: 4096 "
+                             "(about 1.3 GB of activations per forward stream in fp32); with --no-pipeline a global-mode batch that holds "
+                             "long reads grows (up to 16384 units, about 50 GB per context) until its forward covers the longest read's "
+                             "beam search, which is one serial chain per read -- the pipeline groups batches on the device for that instead")
     return parser
 
 
@@ -222,6 +228,9 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
     (string stitch, FASTA write) run concurrently; output order is the input order."""
     from concurrent.futures import ThreadPoolExecutor
     backends = list(be) if isinstance(be, (list, tuple)) else [be]
+    # in-context pipeline (rd_pipe_submit_raw_*): a device call only QUEUES the batch and returns a ticket; results are
+    # collected a few batches later, in order
+    pipelined = not getattr(args, "no_pipeline", False) and all(hasattr(b, "pipe_submit_raw") for b in backends)
     if args.step_size <= 0:
         raise ValueError("Step size must be > 0")            # preprocess.py:5-8
     if args.step_size > args.chunk_len:
@@ -258,14 +267,24 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
 
     def on_device(backend, b):
         t0 = time()
+        if pipelined:
+            return backend.pipe_submit_raw(args.decode_type, [raw for _, raw in b], args.outlier_clip, args.chunk_len, args.step_size,
+                                           args.beam_width, use_lm, args.sig_threshold, args.rna_threshold), t0
         labels, status = device_batch(backend, b, args, use_lm)
         return labels, status, (time() - t0) / len(b)
+
+    def collect(ticket, t0, n):
+        labels, status = ticket.result()                # blocks until the batch's group has been decoded
+        return labels, status, (time() - t0) / n
 
     def retire(keep):
         """hand the oldest device results to the host stage (in submission order) until `keep` batches are in flight"""
         while len(in_flight) > keep:
-            fut, b, b_idx = in_flight.pop(0)
-            labels, status, dur = fut.result()          # re-raises device-side errors
+            fut, b, b_idx, k = in_flight.pop(0)
+            res = fut.result()                          # re-raises device-side errors
+            if pipelined:                               # (the context's calls stay on its own thread)
+                res = dev_pools[k].submit(collect, res[0], res[1], len(b)).result()
+            labels, status, dur = res
             finishing.append(host_pool.submit(finish, b, b_idx, labels, status, dur))
             while len(finishing) > 2:
                 finishing.pop(0).result()               # re-raises host-side errors
@@ -279,7 +298,7 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
     def batch_limit(longest_read):
         if args.gpu_batch_windows is not None:
             return args.gpu_batch_windows
-        if args.decode_type != "global":
+        if args.decode_type != "global" or pipelined:   # (the pipeline covers a long read's chain by grouping batches)
             return 4096
         return max(4096, min(16384, longest_read * chain_rows // args.chunk_len))
 
@@ -289,8 +308,8 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
             return
         k = n_submitted % len(backends)
         n_submitted += 1
-        in_flight.append((dev_pools[k].submit(on_device, backends[k], batch), batch, batch_idx))
-        retire(len(backends))
+        in_flight.append((dev_pools[k].submit(on_device, backends[k], batch), batch, batch_idx, k))
+        retire(len(backends) * (8 if pipelined else 1))
         batch, batch_idx, n_win = [], [], 0
 
     def drain():
@@ -371,6 +390,13 @@ def apply_artifacts(args, be, art, clone_from=None):
         args._lm_loaded = True
 
 
+def n_contexts(args):
+    """device contexts per GPU: 1 when a context pipelines by itself, 2 with --no-pipeline, or what --device-contexts says"""
+    if args.device_contexts is not None:
+        return max(1, args.device_contexts)
+    return 2 if args.no_pipeline else 1
+
+
 def setup_backend(args, be):
     """Load weights and (when given) the RNA model into a Backend; mirrors basecall.py:47-62."""
     apply_artifacts(args, be, load_artifacts(args))
@@ -384,7 +410,7 @@ def main(argv=None):
     pool = make_stitch_pool(args.stitch_workers) if args.decode_type == "chunk" else None   # before the GPU is touched
     from .backend import Backend
     art = load_artifacts(args)
-    bes = [Backend(args.device) for _ in range(max(1, args.device_contexts))]
+    bes = [Backend(args.device) for _ in range(n_contexts(args))]
     for i, b in enumerate(bes):
         apply_artifacts(args, b, art, clone_from=bes[0] if i else None)
     del art

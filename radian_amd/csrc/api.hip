@@ -2,7 +2,9 @@
 // Context, artefact loading/repacking, host-pointer wrappers around the device paths, fused paths,
 // kernel timers and the RCCL start-up broadcast.
 #include "common.h"
+#include "plan.h"
 #include "../../include/radian_hip.h"
+
 
 #include <cmath>
 #include <dlfcn.h>
@@ -11,6 +13,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+
+using namespace rdi;
 
 // --------------------------------------------------------------------------------------------- errors
 static thread_local char g_err[1024] = "";
@@ -128,6 +132,7 @@ static void timer_free(KernelTimer& t)
 
 extern "C" int rd_rccl_finalize(rd_ctx* ctx);
 void rd_pipe_destroy_internal(rd_ctx* ctx);
+int rd_pipe_drain_decode_internal(rd_ctx* ctx);
 void rd_plan_cache_destroy_internal(rd_ctx* ctx);
 
 extern "C" int rd_destroy(rd_ctx* ctx)
@@ -137,6 +142,7 @@ extern "C" int rd_destroy(rd_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     rd_rccl_finalize(ctx);
     rd_pipe_destroy_internal(ctx);
+    rd_rpipe_destroy(ctx);
     rd_plan_cache_destroy_internal(ctx);
     timer_free(ctx->timer_conv);
     timer_free(ctx->timer_decode);
@@ -624,7 +630,11 @@ int decode_and_fetch(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t
     if (n_seq == 0) return RD_OK;
     SeqMeta sm;
     std::vector<int64_t> lab_off;
-    int rc = prepare_seq_meta(ctx, seq_off, seq_off2, split, seq_len, n_seq, W, sm, lab_off);
+    // beam searches still in flight on a pipeline's decode stream use the context's trie workspace: let them finish
+    int rc = rd_pipe_drain_decode_internal(ctx);
+    if (rc) return rc;
+    if ((rc = rd_rpipe_drain_decode(ctx))) return rc;
+    rc = prepare_seq_meta(ctx, seq_off, seq_off2, split, seq_len, n_seq, W, sm, lab_off);
     if (rc) return rc;
     if (ctx->ws_labels.reserve((size_t)sm.total_labels + 16)) return RD_ERR_NOMEM;
     uint8_t* d_labels = ctx->ws_labels.as<uint8_t>();
@@ -669,26 +679,6 @@ extern "C" int rd_forward(rd_ctx* ctx, const float* windows, int n_windows, int 
     RD_HIP(hipMemcpyAsync(probs, ctx->ws_probs.p, n * 20, hipMemcpyDeviceToHost, ctx->stream));
     RD_HIP(hipStreamSynchronize(ctx->stream));
     return RD_OK;
-}
-
-static int64_t assembled_rows(int nW, int T, int pad, int step)
-{
-    int64_t N = 0;
-    for (int i = 0; i < nW; i++) {
-        int rows = (i == nW - 1) ? T - pad : T;
-        int64_t end = (int64_t)i * step + rows;
-        if (rows > 0 && end > N) N = end;
-    }
-    return N;
-}
-
-static int assembled_is_f64(int nW, int T, int pad, int step)
-{
-    // some time step is covered twice <=> a window i >= 1 with rows starts inside window i-1
-    if (step >= T) return 0;
-    if (nW >= 3) return 1;
-    if (nW == 2 && T - pad > 0) return 1;
-    return 0;
 }
 
 extern "C" int rd_assemble(rd_ctx* ctx, const float* probs, int n_windows, int chunk_len, int pad, int step, double* out,
@@ -871,120 +861,6 @@ extern "C" int rd_basecall_global(rd_ctx* ctx, const float* windows, int chunk_l
 // N + (nW-1)*halo rows per read instead of nW*chunk_len (chunk mode), or N rows (global mode, where only the earliest
 // covering window's row of each time step is ever used, matrix_assembly.py:46-53; valid when step <= chunk_len - halo).
 namespace {
-
-inline int count_windows(int64_t N, int chunk, int step) { return (N < chunk ? 0 : (int)((N - chunk) / step) + 1) + 1; }
-
-struct WindowGeom {
-    int nW, pad;
-};
-inline WindowGeom window_geom(int64_t N, int chunk, int step)
-{
-    WindowGeom g;
-    g.nW = count_windows(N, chunk, step);
-    const int64_t last_start = (int64_t)(g.nW - 1) * step;
-    g.pad = (int)(chunk - (N - last_start));   // >= 1 always (preprocess.py:17-19)
-    return g;
-}
-
-struct ReadsPlan {
-    int n_layers = 0;                       // 2 * nblocks + 1
-    bool per_layer = false;                 // false: tiles[0] serves every layer
-    std::vector<TileDesc> tiles[RD_MAX_LAYERS];
-    int64_t rows[RD_MAX_LAYERS] = {0};      // time steps evaluated per layer
-    // per decoded sequence (chunk mode: window; global mode: read)
-    std::vector<int64_t> off1, off2;
-    std::vector<int32_t> split, valid;
-    std::vector<int32_t> read_win_off;   // n_reads + 1
-    std::vector<int64_t> read_row;       // first stream row of each read
-    int64_t total_rows = 0;
-    int n_windows = 0;
-};
-
-void add_segment(std::vector<TileDesc>& list, int64_t& rows, int64_t seg_row, int64_t src_row, int len, int in_len,
-                 int64_t alt_row = 0, int alt_in = INT32_MAX, int alt_res = INT32_MAX)
-{
-    for (int t0 = 0; t0 < len; t0 += 32) {   // 32-row sub-tiles; four of them (of any segments) make a workgroup tile
-        TileDesc td;
-        td.seg_row = seg_row;
-        td.src_row = src_row;
-        td.alt_row = alt_row;
-        td.t0 = t0;
-        td.seg_len = len;
-        td.in_len = in_len;
-        td.alt_in = alt_in;
-        td.alt_res = alt_res;
-        td.pad_ = 0;
-        list.push_back(td);
-    }
-    rows += len;
-}
-
-// Rows of a head that differ from the stream, per tensor: the signal has none; a k=3 conv of dilation d adds 2d.
-struct LayerHalo {
-    int h_in, h_res, h_out;
-};
-void layer_halos(const Model& m, LayerHalo* lh)
-{
-    int H = 0;  // halo of the block input
-    for (int b = 0; b < m.nblocks; b++) {
-        const int d = m.dil[b];
-        lh[2 * b] = {H, H, H + 2 * d};               // first conv (block 0: from the raw signal)
-        lh[2 * b + 1] = {H + 2 * d, H, H + 4 * d};   // second conv, residual = block input
-        H += 4 * d;
-    }
-    lh[2 * m.nblocks] = {H, H, H};                   // dense head
-}
-
-// chunk mode: one stream per read + one head per window i >= 1; per-layer head lengths
-int plan_reads_chunk(const Model& m, const int64_t* read_off, int n_reads, int chunk, int step, int halo, ReadsPlan& P)
-{
-    LayerHalo lh[RD_MAX_LAYERS];
-    layer_halos(m, lh);
-    P.n_layers = 2 * m.nblocks + 1;
-    P.per_layer = true;
-    int64_t row = 0;
-    P.read_win_off.assign(1, 0);
-    // A layer's tile list holds the streams of ALL reads first, then the heads: workgroups are dispatched in list order as
-    // slots free up, so the full 128-row stream tiles fill the rounds and the short head tiles (few rows, waves without rows
-    // skip their MFMAs) make up the last, partial round -- longest-processing-time-first.  (Tiles of one launch are
-    // independent: a head reads its later rows from the layer's INPUT tensor.)
-    std::vector<TileDesc> heads[RD_MAX_LAYERS];
-    for (int r = 0; r < n_reads; r++) {
-        const int64_t N = read_off[r + 1] - read_off[r];
-        RD_REQUIRE(N >= 1, "read %d is empty", r);
-        RD_REQUIRE(N < INT32_MAX, "read %d too long", r);
-        const WindowGeom g = window_geom(N, chunk, step);
-        const int64_t stream_row = row;
-        P.read_row.push_back(stream_row);
-        for (int li = 0; li < P.n_layers; li++) add_segment(P.tiles[li], P.rows[li], stream_row, read_off[r], (int)N, (int)N);
-        row += N;
-        for (int i = 0; i < g.nW; i++) {
-            const int valid = (i < g.nW - 1) ? chunk : chunk - g.pad;
-            const int h = (i == 0) ? 0 : (halo < valid ? halo : valid);
-            int64_t o1 = stream_row + (int64_t)i * step;
-            if (h > 0) {
-                o1 = row;
-                const int64_t alt = stream_row + (int64_t)i * step;
-                for (int li = 0; li < P.n_layers; li++) {
-                    const int len = lh[li].h_out < valid ? lh[li].h_out : valid;   // rows of this head the layer must produce
-                    if (len > 0)
-                        add_segment(heads[li], P.rows[li], row, read_off[r] + (int64_t)i * step, len, valid, alt, lh[li].h_in, lh[li].h_res);
-                }
-                row += h;
-            }
-            P.off1.push_back(o1);
-            P.off2.push_back(stream_row + (int64_t)i * step);
-            P.split.push_back(h);
-            P.valid.push_back(valid);
-        }
-        P.n_windows += g.nW;
-        P.read_win_off.push_back(P.n_windows);
-    }
-    for (int li = 0; li < P.n_layers; li++) P.tiles[li].insert(P.tiles[li].end(), heads[li].begin(), heads[li].end());
-    P.total_rows = row;
-    return RD_OK;
-}
-
 struct PlanCache {
     int chunk = -1, step = -1, halo = -1, mode = -1, nblocks = -1;
     int dil[RD_MAX_BLOCKS] = {0};   // per-layer head lengths depend on every block's dilation, not only on their sum
@@ -1046,18 +922,6 @@ struct Pipe {
     int lanes = 2;          // forward lanes the submitted batches rotate over
     int next_lane = 0;
 };
-
-int pinned_reserve(void** p, size_t* cap, size_t bytes)
-{
-    if (bytes <= *cap) return RD_OK;
-    if (*p) (void)hipHostFree(*p);
-    *p = nullptr;
-    *cap = 0;
-    size_t want = align_up(bytes + bytes / 8, 1 << 16);
-    RD_HIP(hipHostMalloc(p, want, hipHostMallocDefault));
-    *cap = want;
-    return RD_OK;
-}
 
 int pipe_get(rd_ctx* ctx, Pipe** out)
 {
@@ -1138,6 +1002,7 @@ int pipe_launch_decode(rd_ctx* ctx, Pipe* p, PipeSlot& s)
     }
     if (s.labels.reserve(nT + 16)) return RD_ERR_NOMEM;
     if ((rc = pinned_reserve(&s.h_out, &s.h_out_cap, align_up(nT, 256) + n * 4))) return rc;
+    if ((rc = rd_rpipe_drain_decode(ctx))) return rc;   // (beam searches of the other pipeline use the same trie workspace)
     for (int l = 0; l < RD_MAX_LANES; l++)   // every forward that wrote into this slot has finished (a lane's event is its latest forward)
         if (s.lane_mask & (1u << l)) RD_HIP(hipStreamWaitEvent(p->s_dec, ctx->lanes[l].done, 0));
     RD_HIP(hipMemcpyAsync(s.meta.p, s.h_meta, o_llen, hipMemcpyHostToDevice, p->s_dec));
@@ -1216,6 +1081,13 @@ void pipe_destroy(rd_ctx* ctx)
 
 void rd_pipe_destroy_internal(rd_ctx* ctx) { pipe_destroy(ctx); }
 
+int rd_pipe_drain_decode_internal(rd_ctx* ctx)
+{
+    Pipe* p = (Pipe*)ctx->pipe;
+    if (p && p->s_dec && (p->slot[0].busy || p->slot[1].busy)) RD_HIP(hipStreamSynchronize(p->s_dec));
+    return RD_OK;
+}
+
 extern "C" int rd_pipe_config(rd_ctx* ctx, int group_batches)
 {
     RD_REQUIRE(ctx, "rd_pipe_config: null context");
@@ -1224,9 +1096,10 @@ extern "C" int rd_pipe_config(rd_ctx* ctx, int group_batches)
     Pipe* p = nullptr;
     int rc = pipe_get(ctx, &p);
     if (rc) return rc;
-    RD_REQUIRE(p->slot[0].nwin == 0 && p->slot[1].nwin == 0 && !p->slot[0].busy && !p->slot[1].busy,
+    RD_REQUIRE(p->slot[0].nwin == 0 && p->slot[1].nwin == 0 && !p->slot[0].busy && !p->slot[1].busy && rd_rpipe_idle(ctx),
                "rd_pipe_config: pipeline not empty (call rd_pipe_flush first)");
     p->group = group_batches;
+    ctx->pipe_group = group_batches;
     return RD_OK;
 }
 
@@ -1237,10 +1110,11 @@ extern "C" int rd_pipe_set_lanes(rd_ctx* ctx, int lanes)
     Pipe* p = nullptr;
     int rc = pipe_get(ctx, &p);
     if (rc) return rc;
-    RD_REQUIRE(p->slot[0].nwin == 0 && p->slot[1].nwin == 0 && !p->slot[0].busy && !p->slot[1].busy,
+    RD_REQUIRE(p->slot[0].nwin == 0 && p->slot[1].nwin == 0 && !p->slot[0].busy && !p->slot[1].busy && rd_rpipe_idle(ctx),
                "rd_pipe_set_lanes: pipeline not empty (call rd_pipe_flush first)");
     p->lanes = lanes;
     p->next_lane = 0;
+    ctx->pipe_lanes = lanes;
     return RD_OK;
 }
 
@@ -1284,10 +1158,11 @@ extern "C" int rd_pipe_submit(rd_ctx* ctx, const float* d_windows, int n_windows
 extern "C" int rd_pipe_flush(rd_ctx* ctx)
 {
     RD_REQUIRE(ctx, "rd_pipe_flush: null context");
-    Pipe* p = (Pipe*)ctx->pipe;
-    if (!p) return RD_OK;
     RD_HIP(hipSetDevice(ctx->device));
     int rc;
+    if ((rc = rd_rpipe_flush(ctx))) return rc;   // the reads-level pipeline (pipe_reads.hip)
+    Pipe* p = (Pipe*)ctx->pipe;
+    if (!p) return RD_OK;
     // order of completion on the decode stream: the other slot's group (if any) was launched first
     PipeSlot& a = p->slot[p->cur ^ 1];
     PipeSlot& b = p->slot[p->cur];
@@ -1298,39 +1173,6 @@ extern "C" int rd_pipe_flush(rd_ctx* ctx)
 
 // --------------------------------------------------------------------------------------------- reads-level entry points
 namespace {
-
-// global mode: one stream per read when the geometry allows it, else per-window segments in a uniform row layout
-int plan_reads_global(const Model& m, const int64_t* read_off, int n_reads, int chunk, int step, int halo, ReadsPlan& P, bool* streamed)
-{
-    const bool st = step <= chunk - halo;
-    *streamed = st;
-    P.n_layers = 2 * m.nblocks + 1;
-    P.per_layer = false;
-    int64_t row = 0;
-    P.read_win_off.assign(1, 0);
-    for (int r = 0; r < n_reads; r++) {
-        const int64_t N = read_off[r + 1] - read_off[r];
-        RD_REQUIRE(N >= 1, "read %d is empty", r);
-        RD_REQUIRE(N < INT32_MAX, "read %d too long", r);
-        const WindowGeom g = window_geom(N, chunk, step);
-        P.read_row.push_back(row);
-        if (st) {
-            add_segment(P.tiles[0], P.rows[0], row, read_off[r], (int)N, (int)N);
-            row += N;
-        } else {
-            for (int i = 0; i < g.nW; i++) {
-                const int valid = (i < g.nW - 1) ? chunk : chunk - g.pad;
-                if (valid > 0) add_segment(P.tiles[0], P.rows[0], row + (int64_t)i * chunk, read_off[r] + (int64_t)i * step, valid, valid);
-            }
-            row += (int64_t)g.nW * chunk;
-        }
-        P.valid.push_back(g.pad);   // per read: the pad of its last window
-        P.n_windows += g.nW;
-        P.read_win_off.push_back(P.n_windows);
-    }
-    P.total_rows = row;
-    return RD_OK;
-}
 
 int get_plan(rd_ctx* ctx, const int64_t* read_off, int n_reads, int chunk, int step, int mode, const ReadsPlan** out,
              const TileLists** lists, bool* streamed)

@@ -39,7 +39,52 @@ __global__ __launch_bounds__(256) void assemble_kernel(const IT* __restrict__ pr
     for (int c = 0; c < 5; c++) out[t * 5 + c] = x[c];
 }
 
+// The same gather for a BATCH of reads in one launch (the pipelined global path): blockIdx.y = read, one record per read.
+template <typename IT>
+__global__ __launch_bounds__(256) void assemble_batch_kernel(const IT* __restrict__ probs, const AsmRead* __restrict__ reads, int T, int step,
+                                                              double* __restrict__ out, int streamed)
+{
+    const AsmRead rd = reads[blockIdx.y];
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rd.N) return;
+    const int nW = rd.nW, pad = rd.pad;
+    int64_t lo = t - T + 1;
+    int i_min = lo <= 0 ? 0 : (int)((lo + step - 1) / step);
+    int i_max = (int)(t / step);
+    if (i_max > nW - 1) i_max = nW - 1;
+    if (i_max == nW - 1 && t >= (int64_t)(nW - 1) * step + (T - pad)) i_max--;
+    if (i_min > i_max) i_min = i_max;
+    const IT* base = probs + (size_t)rd.src_row * 5;
+    const IT* r = streamed ? base + (size_t)t * 5 : base + ((size_t)i_min * T + (size_t)(t - (int64_t)i_min * step)) * 5;
+    double x[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) x[c] = (double)r[c];
+    if (i_max > i_min) {
+        double norm = (((fabs(x[0]) + fabs(x[1])) + fabs(x[2])) + fabs(x[3])) + fabs(x[4]);
+        if (norm == 0.0) norm = 1.0;
+#pragma unroll
+        for (int c = 0; c < 5; c++) x[c] = x[c] / norm;
+    }
+    double* o = out + (size_t)(rd.out_row + t) * 5;
+#pragma unroll
+    for (int c = 0; c < 5; c++) o[c] = x[c];
+}
+
 }  // namespace
+
+int rd_assemble_batch_dev(hipStream_t st, const void* d_probs, const AsmRead* d_reads, int n_reads, int64_t max_n, int T, int step,
+                          double* d_out, int streamed, int in_f16)
+{
+    if (n_reads <= 0 || max_n <= 0) return RD_OK;
+    const int threads = 256;
+    const dim3 grid((unsigned)((max_n + threads - 1) / threads), (unsigned)n_reads);
+    if (in_f16)
+        hipLaunchKernelGGL(assemble_batch_kernel<_Float16>, grid, dim3(threads), 0, st, (const _Float16*)d_probs, d_reads, T, step, d_out, streamed);
+    else
+        hipLaunchKernelGGL(assemble_batch_kernel<float>, grid, dim3(threads), 0, st, (const float*)d_probs, d_reads, T, step, d_out, streamed);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
 
 int rd_assemble_dev(rd_ctx* ctx, const void* d_probs, int nW, int T, int pad, int step, double* d_out, int64_t N, int streamed, int in_f16)
 {

@@ -156,7 +156,10 @@ struct rd_ctx {
     size_t h_stage_cap = 0;
     KernelTimer timer_conv, timer_decode, timer_head, timer_in;
     void* rccl = nullptr;  // RcclState*
-    void* pipe = nullptr;  // Pipe* (two-stream forward/decode software pipeline)
+    void* pipe = nullptr;  // Pipe* (two-stream forward/decode software pipeline over chunk-mode batches, api.hip)
+    void* rpipe = nullptr; // ReadsPipe* (the same scheme over batches of whole reads, global mode / raw input, pipe_reads.hip)
+    int pipe_group = 4;    // batches per beam-search launch (rd_pipe_config)
+    int pipe_lanes = 2;    // forward streams the submitted batches rotate over (rd_pipe_set_lanes)
     void* plan_cache[2] = {nullptr, nullptr};  // PlanCache* for chunk / global reads-level plans
 };
 
@@ -176,11 +179,27 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype /* 0 f32, 1 f64, 2
                   const int32_t* d_seq_split = nullptr);
 // preprocess.hip
 int rd_normalise_dev(rd_ctx* ctx, const int16_t* d_raw, const int64_t* d_read_off, int n_reads, int clip, float* d_out,
-                     int32_t* d_status);
+                     int32_t* d_status, hipStream_t stream = nullptr /* default: ctx->stream */);
 // assemble.hip
+// one read of a batched assembly: its forward rows start at row src_row of the probability buffer (streamed: row t of the
+// read; windowed: window i at src_row + i*T), its N assembled float64 rows go to row out_row of the output
+struct AsmRead {
+    int64_t src_row, out_row;
+    int32_t N, nW, pad, pad_;
+};
+int rd_assemble_batch_dev(hipStream_t st, const void* d_probs, const AsmRead* d_reads, int n_reads, int64_t max_n, int T, int step,
+                          double* d_out, int streamed, int in_f16);
 int rd_assemble_dev(rd_ctx* ctx, const void* d_probs, int nW, int T, int pad, int step, double* d_out, int64_t N,
                     int streamed = 0 /* 1: d_probs is the streamed forward [N][5]; row t is taken from row t */,
                     int in_f16 = 0 /* 1: d_probs rows are _Float16 */);
+
+// api.hip
+int rd_pipe_drain_decode_internal(rd_ctx* ctx);   // wait for the chunk pipeline's beam searches in flight
+// pipe_reads.hip
+int rd_rpipe_flush(rd_ctx* ctx);
+bool rd_rpipe_idle(const rd_ctx* ctx);
+int rd_rpipe_drain_decode(rd_ctx* ctx);   // wait for the pipeline's beam searches in flight (they share the trie workspace)
+void rd_rpipe_destroy(rd_ctx* ctx);
 
 extern "C" int rd_decode_max_width(void);
 

@@ -1,0 +1,644 @@
+// pipe_reads.hip -- software pipeline over batches of WHOLE READS inside one rd_ctx (declared in include/radian_hip.h):
+// rd_pipe_submit_reads_global / rd_pipe_submit_raw_global / rd_pipe_submit_raw_chunk / rd_pipe_progress.
+//
+// The loop body of radian/basecall.py:77-121 for a stream of read batches.  What runs where:
+//   forward lane (rotating, rd_pipe_set_lanes; each lane owns its activation tensors, staging and tile descriptors):
+//       [raw form: H2D of the int16 samples out of the lane's pinned staging block -> mad_normalise (preprocess.py:24-49)]
+//       -> streamed TCN forward (every time step once) into the open GROUP's probability rows
+//       -> [global mode: per-read assembly (matrix_assembly.py:6-53) of the batch into the group's float64 matrix]
+//   decode stream (high priority): per closed group ONE metadata upload, the beam search of every read (global: LM-gated,
+//       decode.py:100-212) or window (chunk) of the group, labels + lengths (+ normalisation status) to pinned host memory.
+// A group closes when it holds rd_pipe_config batches -- or, in global mode, as soon as its forward work covers the beam
+// search of its longest read: a read's search is one serial chain of one time step per sample (~2 us each), which only
+// the NEXT group's forwards can hide, so a group needs ~100 forward rows per chain step and no more.
+// Results are delivered in submission order: rd_pipe_progress hands over finished groups without blocking (or blocks
+// until a given number of submits has been delivered); rd_pipe_flush delivers everything.
+#include "common.h"
+#include "plan.h"
+#include "../../include/radian_hip.h"
+
+#include <string.h>
+
+using namespace rdi;
+
+namespace {
+
+// forward rows a group must hold per beam-search step of its longest read before it may close early (global mode):
+// forward ~29 M rows/s = 34 ns per row; a step costs 1.6-2.0 us (W <= 12), 2.7-3.1 us (W <= 25), 4-6 us beyond
+inline int64_t chain_rows(int W) { return W <= 12 ? 96 : W <= 25 ? 140 : 260; }
+
+struct RSub {                 // one submitted batch inside a group
+    int n_seq = 0, seq0 = 0;  // its decoded sequences (global: reads; chunk: windows) = [seq0, seq0 + n_seq) of the group
+    int n_reads = 0, read0 = 0;
+    uint8_t* user_labels = nullptr;
+    int32_t* user_lens = nullptr;
+    int32_t* user_status = nullptr;        // raw form: per read
+    std::vector<int64_t> user_label_off;   // per sequence
+};
+
+struct RSeq {                 // one decoded sequence of a group
+    int64_t off1, off2;       // source rows (rows [0, split) from off1, the rest from off2 - see DecodeArgs); global: off1 only
+    int32_t split, len;
+    int32_t is64;             // global: rows come from the group's float64 matrix
+    int64_t label_off;        // inside the group's label buffer
+};
+
+struct RSlot {                // a group
+    DevBuf probs, mat, meta, labels, status;
+    void* h_meta = nullptr;
+    size_t h_meta_cap = 0;
+    void* h_out = nullptr;
+    size_t h_out_cap = 0;
+    hipEvent_t dec_done = nullptr;
+    bool busy = false;        // beam search launched, results not yet delivered
+    int64_t launch_seq = 0;   // order of the launches on the decode stream
+    // what makes a group homogeneous
+    int mode = -1, W = 0, f16 = 0, use_lm = 0;
+    double s_thr = 0.0, r_thr = 0.0;
+    int64_t rows = 0, rows64 = 0, cap_rows = 0, labels_total = 0, longest = 0;
+    int n_reads = 0;
+    size_t status_off = 0;    // inside h_out, valid while busy
+    std::vector<int> order;   // decode order of the sequences (global: float64 ones first), valid while busy
+    int n64 = 0;
+    std::vector<RSub> subs;
+    std::vector<RSeq> seqs;
+    unsigned lane_mask = 0;
+    int64_t grow_hint = 0;    // rows to reserve next time the slot is empty (a group had to close for lack of room)
+};
+
+struct RLane {                // per forward lane: staging + descriptors of the lane's latest submit
+    DevBuf tiles;             // tile descriptors | AsmRead records
+    DevBuf raw;               // read offsets | status | int16 samples
+    DevBuf sig;               // normalised signal
+    void* h_stage = nullptr;
+    size_t h_stage_cap = 0;
+    hipEvent_t staged = nullptr;
+    bool staged_pending = false;
+    // the plan the descriptors on the device were built from
+    bool valid = false;
+    int chunk = -1, step = -1, mode = -1, nblocks = -1;
+    int dil[RD_MAX_BLOCKS] = {0};
+    std::vector<int64_t> lens;
+    ReadsPlan plan;
+    bool streamed = false;
+    TileLists lists;
+    size_t n_desc = 0;
+};
+
+struct ReadsPipe {
+    hipStream_t s_dec = nullptr;
+    RSlot slot[2];
+    RLane lane[RD_MAX_LANES];
+    int cur = 0;
+    int next_lane = 0;
+    int64_t submitted = 0, delivered = 0, launches = 0;
+};
+
+void slot_reset(RSlot& s)
+{
+    s.subs.clear();
+    s.seqs.clear();
+    s.order.clear();
+    s.rows = s.rows64 = s.labels_total = s.longest = 0;
+    s.n_reads = 0;
+    s.lane_mask = 0;
+    s.mode = -1;
+}
+
+int rpipe_get(rd_ctx* ctx, ReadsPipe** out)
+{
+    if (!ctx->rpipe) {
+        ReadsPipe* p = new ReadsPipe();
+        ctx->rpipe = p;   // (owned by the context from here on: rd_rpipe_destroy frees whatever was created)
+        int lo = 0, hi = 0;
+        RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        RD_HIP(hipStreamCreateWithPriority(&p->s_dec, hipStreamNonBlocking, hi));
+        for (int i = 0; i < 2; i++) RD_HIP(hipEventCreateWithFlags(&p->slot[i].dec_done, hipEventDisableTiming));
+    }
+    *out = (ReadsPipe*)ctx->rpipe;
+    return RD_OK;
+}
+
+// deliver a finished (or awaited) group to its callers
+int slot_collect(ReadsPipe* p, RSlot& s)
+{
+    if (!s.busy) return RD_OK;
+    RD_HIP(hipEventSynchronize(s.dec_done));
+    s.busy = false;
+    const uint8_t* hl = (const uint8_t*)s.h_out;
+    const size_t o_len = align_up((size_t)s.labels_total + 16, 256);
+    const int32_t* hlen = (const int32_t*)((const char*)s.h_out + o_len);
+    const int32_t* hstat = (const int32_t*)((const char*)s.h_out + s.status_off);
+    int rc = RD_OK;
+    // hlen is in decode order
+    std::vector<int32_t> len_of(s.seqs.size());
+    for (size_t k = 0; k < s.order.size(); k++) len_of[s.order[k]] = hlen[k];
+    for (const RSub& sb : s.subs) {
+        for (int i = 0; i < sb.n_seq; i++) {
+            const RSeq& q = s.seqs[sb.seq0 + i];
+            const int32_t n = len_of[sb.seq0 + i];
+            if (n < 0 || n > q.len) {
+                rd_set_error("pipeline: sequence %d produced an impossible label length %d (rows %d)", sb.seq0 + i, n, q.len);
+                rc = RD_ERR_STATE;
+                continue;
+            }
+            sb.user_lens[i] = n;
+            if (n) memcpy(sb.user_labels + sb.user_label_off[i], hl + q.label_off, (size_t)n);
+        }
+        if (sb.user_status)
+            for (int r = 0; r < sb.n_reads; r++) sb.user_status[r] = hstat[sb.read0 + r];
+    }
+    p->delivered += (int64_t)s.subs.size();
+    slot_reset(s);
+    return rc;
+}
+
+// beam search + copy-out of everything forwarded into the group so far
+int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
+{
+    if (s.seqs.empty() || s.busy) return RD_OK;
+    int rc;
+    const size_t n = s.seqs.size();
+    // decode order: global mode runs the float64 (assembled) reads first, then the float32 ones (reads that one window
+    // covers: the reference decodes their float32 rows as they are, matrix_assembly.py:46-53)
+    s.order.clear();
+    for (size_t i = 0; i < n; i++)
+        if (s.seqs[i].is64) s.order.push_back((int)i);
+    s.n64 = (int)s.order.size();
+    for (size_t i = 0; i < n; i++)
+        if (!s.seqs[i].is64) s.order.push_back((int)i);
+    const size_t a8 = align_up(n * 8, 256), a4 = align_up(n * 4, 256);
+    const size_t o_off2 = a8, o_node = 2 * a8, o_lab = 3 * a8, o_len = 4 * a8, o_split = o_len + a4, o_llen = o_split + a4;
+    const size_t meta_bytes = o_llen + a4;
+    if ((rc = pinned_reserve(&s.h_meta, &s.h_meta_cap, meta_bytes))) return rc;
+    if (s.meta.reserve(meta_bytes)) return RD_ERR_NOMEM;
+    char* hm = (char*)s.h_meta;
+    int64_t *h1 = (int64_t*)hm, *h2 = (int64_t*)(hm + o_off2), *hn = (int64_t*)(hm + o_node), *hl = (int64_t*)(hm + o_lab);
+    int32_t *hlen = (int32_t*)(hm + o_len), *hsp = (int32_t*)(hm + o_split);
+    int64_t nodes[2] = {0, 0};
+    for (size_t k = 0; k < n; k++) {
+        const RSeq& q = s.seqs[s.order[k]];
+        const int pass = (int)k < s.n64 ? 0 : 1;
+        h1[k] = q.off1;
+        h2[k] = q.off2;
+        hsp[k] = q.split;
+        hlen[k] = q.len;
+        hl[k] = q.label_off;
+        hn[k] = nodes[pass];                       // the two passes run one after the other and share the trie workspace
+        nodes[pass] += 1 + (int64_t)s.W * q.len;
+    }
+    if (s.labels.reserve((size_t)s.labels_total + 16)) return RD_ERR_NOMEM;
+    const size_t ho_len = align_up((size_t)s.labels_total + 16, 256);
+    s.status_off = ho_len + align_up(n * 4, 256);
+    if ((rc = pinned_reserve(&s.h_out, &s.h_out_cap, s.status_off + (size_t)s.n_reads * 4 + 16))) return rc;
+    if ((rc = rd_pipe_drain_decode_internal(ctx))) return rc;   // (beam searches of the chunk pipeline use the same trie workspace)
+    for (int l = 0; l < RD_MAX_LANES; l++)   // every forward / assembly that wrote into this group has finished
+        if (s.lane_mask & (1u << l)) RD_HIP(hipStreamWaitEvent(p->s_dec, ctx->lanes[l].done, 0));
+    RD_HIP(hipMemcpyAsync(s.meta.p, s.h_meta, o_llen, hipMemcpyHostToDevice, p->s_dec));
+    char* dm = (char*)s.meta.p;
+    for (int pass = 0; pass < 2; pass++) {
+        const int k0 = pass == 0 ? 0 : s.n64, k1 = pass == 0 ? s.n64 : (int)n;
+        if (k1 == k0) continue;
+        const bool chunk = s.mode == 0;
+        const void* src = pass == 0 ? s.mat.p : s.probs.p;
+        const int ptype = pass == 0 ? 1 : (s.f16 ? 2 : 0);
+        rc = rd_decode_dev(ctx, src, ptype, (const int64_t*)dm + k0, (const int32_t*)(dm + o_len) + k0, (const int64_t*)(dm + o_node) + k0,
+                           (const int64_t*)(dm + o_lab) + k0, k1 - k0, nodes[pass], s.W, s.use_lm, s.s_thr, s.r_thr, s.labels.as<uint8_t>(),
+                           (int32_t*)(dm + o_llen) + k0, nullptr, p->s_dec, chunk ? (const int64_t*)(dm + o_off2) + k0 : nullptr,
+                           chunk ? (const int32_t*)(dm + o_split) + k0 : nullptr);
+        if (rc) return rc;
+    }
+    RD_HIP(hipMemcpyAsync(s.h_out, s.labels.p, (size_t)s.labels_total, hipMemcpyDeviceToHost, p->s_dec));
+    RD_HIP(hipMemcpyAsync((char*)s.h_out + ho_len, dm + o_llen, n * 4, hipMemcpyDeviceToHost, p->s_dec));
+    if (s.n_reads && s.status.p)
+        RD_HIP(hipMemcpyAsync((char*)s.h_out + s.status_off, s.status.p, (size_t)s.n_reads * 4, hipMemcpyDeviceToHost, p->s_dec));
+    RD_HIP(hipEventRecord(s.dec_done, p->s_dec));
+    s.busy = true;
+    s.launch_seq = ++p->launches;
+    return RD_OK;
+}
+
+int close_group(rd_ctx* ctx, ReadsPipe* p)
+{
+    int rc = slot_launch_decode(ctx, p, p->slot[p->cur]);
+    if (rc) return rc;
+    p->cur ^= 1;
+    return RD_OK;
+}
+
+// a group that can take `rows` more probability rows with these decode parameters; closes / recycles groups as needed
+int open_slot(rd_ctx* ctx, ReadsPipe* p, int mode, int W, int f16, int use_lm, double s_thr, double r_thr, int64_t rows, RSlot** out)
+{
+    int rc;
+    RSlot* s = &p->slot[p->cur];
+    const bool same = s->mode == mode && s->W == W && s->f16 == f16 && s->use_lm == use_lm && s->s_thr == s_thr && s->r_thr == r_thr;
+    if (!s->seqs.empty() && (!same || s->rows + rows > s->cap_rows)) {
+        if (same) s->grow_hint = 2 * (s->rows + rows);   // closed for lack of room: the slot grows when it is empty again
+        if ((rc = close_group(ctx, p))) return rc;
+        s = &p->slot[p->cur];
+    }
+    if (s->busy && (rc = slot_collect(p, *s))) return rc;   // the slot's previous group goes to its callers first
+    if (s->seqs.empty()) {
+        const int64_t want = rows > s->grow_hint ? rows : s->grow_hint;
+        if (want > s->cap_rows) {
+            const int64_t cap = want + want / 4;
+            // (nothing in flight reads this slot: its group was delivered)
+            if (s->probs.reserve((size_t)cap * 20) || (mode == 1 && s->mat.reserve((size_t)(cap + 1) * 40))) return RD_ERR_NOMEM;
+            s->cap_rows = cap;
+        }
+    }
+    s->mode = mode;
+    s->W = W;
+    s->f16 = f16;
+    s->use_lm = use_lm;
+    s->s_thr = s_thr;
+    s->r_thr = r_thr;
+    *out = s;
+    return RD_OK;
+}
+
+// Plan (segments, tile descriptors) of a batch on a lane, host side.  *miss: the batch's read lengths differ from the lane's
+// previous batch, R.plan was rebuilt and its descriptors (*n_desc of them) must be uploaded (lane_plan_upload).
+int lane_plan_build(rd_ctx* ctx, RLane& R, const int64_t* read_off, int n_reads, int chunk, int step, int mode, bool* miss, size_t* n_desc)
+{
+    const int halo = rd_model_halo(ctx);
+    std::vector<int64_t> lens(n_reads);
+    for (int r = 0; r < n_reads; r++) lens[r] = read_off[r + 1] - read_off[r];
+    bool hit = R.valid && R.chunk == chunk && R.step == step && R.mode == mode && R.nblocks == ctx->model.nblocks && R.lens == lens;
+    for (int b = 0; hit && b < ctx->model.nblocks; b++) hit = R.dil[b] == ctx->model.dil[b];
+    *miss = !hit;
+    *n_desc = R.n_desc;
+    if (hit) return RD_OK;
+    R.valid = false;
+    R.plan = ReadsPlan();
+    int rc = mode == 0 ? plan_reads_chunk(ctx->model, read_off, n_reads, chunk, step, halo, R.plan)
+                       : plan_reads_global(ctx->model, read_off, n_reads, chunk, step, halo, R.plan, &R.streamed);
+    if (rc) return rc;
+    R.n_desc = plan_pad_tiles(R.plan);
+    *n_desc = R.n_desc;
+    R.chunk = chunk;
+    R.step = step;
+    R.mode = mode;
+    R.nblocks = ctx->model.nblocks;
+    for (int b = 0; b < RD_MAX_BLOCKS; b++) R.dil[b] = b < ctx->model.nblocks ? ctx->model.dil[b] : 0;
+    R.lens.swap(lens);
+    return RD_OK;
+}
+
+// descriptors of a rebuilt plan: into the staging block at hs, one copy to the lane's descriptor buffer on the lane's
+// stream (behind the lane's previous forward, which still reads the old ones)
+int lane_plan_upload(FwdLane* L, RLane& R, char* hs)
+{
+    ReadsPlan& P = R.plan;
+    size_t off = 0;
+    for (int li = 0; li < RD_MAX_LAYERS; li++) {
+        R.lists.d[li] = nullptr;
+        R.lists.n[li] = 0;
+        R.lists.rows[li] = 0;
+    }
+    for (int li = 0; li < P.n_layers; li++) {
+        if (P.per_layer || li == 0) {
+            const std::vector<TileDesc>& v = P.tiles[li];
+            if (!v.empty()) memcpy(hs + off * sizeof(TileDesc), v.data(), v.size() * sizeof(TileDesc));
+            R.lists.d[li] = R.tiles.as<TileDesc>() + off;
+            R.lists.n[li] = (int)(v.size() / 4);
+            R.lists.rows[li] = P.rows[li];
+            off += v.size();
+        } else {
+            R.lists.d[li] = R.lists.d[0];
+            R.lists.n[li] = R.lists.n[0];
+            R.lists.rows[li] = R.lists.rows[0];
+        }
+    }
+    if (off) RD_HIP(hipMemcpyAsync(R.tiles.p, hs, off * sizeof(TileDesc), hipMemcpyHostToDevice, L->st));
+    // the host copies of the descriptors are not needed again (the per-sequence vectors of the plan are)
+    for (int li = 0; li < RD_MAX_LAYERS; li++) std::vector<TileDesc>().swap(P.tiles[li]);
+    R.valid = true;
+    return RD_OK;
+}
+
+int check_args(rd_ctx* ctx, const void* signal, const int64_t* read_off, int n_reads, int chunk_len, int step, int W)
+{
+    RD_REQUIRE(ctx && signal && read_off, "null argument");
+    RD_REQUIRE(n_reads >= 1 && chunk_len >= 1, "bad shape");
+    RD_REQUIRE(step >= 1 && step <= chunk_len, "step %d must be in [1, chunk_len]", step);
+    RD_REQUIRE(W >= 1 && W <= rd_decode_max_width(), "beam_width %d out of range", W);
+    RD_REQUIRE(read_off[0] == 0, "read_off[0] must be 0");
+    for (int r = 0; r < n_reads; r++) RD_REQUIRE(read_off[r + 1] > read_off[r], "read %d is empty (the caller skips empty reads, basecall.py:77-82)", r);
+    if (!ctx->model.loaded) {
+        rd_set_error("no weights loaded (rd_load_weights)");
+        return RD_ERR_STATE;
+    }
+    return RD_OK;
+}
+
+// One submit: [raw -> normalise] -> plan -> forward -> [assembly] on the next lane, its sequences appended to the open group.
+// raw == nullptr: d_signal is the normalised signal resident in HBM.
+int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int clip, const int64_t* read_off, int n_reads, int chunk_len,
+           int step, int W, int use_lm, double s_thr, double r_thr, uint8_t* labels_out, const int64_t* label_off, int32_t* label_len,
+           int32_t* status)
+{
+    int rc;
+    RD_HIP(hipSetDevice(ctx->device));
+    ReadsPipe* p = nullptr;
+    if ((rc = rpipe_get(ctx, &p))) return rc;
+    const int n_lanes = ctx->pipe_lanes < 1 ? 1 : ctx->pipe_lanes;
+    const int lane = p->next_lane % n_lanes;
+    FwdLane* L = nullptr;
+    if ((rc = rd_lane_get(ctx, lane, &L))) return rc;
+    RLane& R = p->lane[lane];
+    const size_t n_samples = (size_t)read_off[n_reads];
+    const int f16 = ctx->logits_f16;
+
+    // ---- host side first: the lane's staging block is free again, the plan is known, every buffer is large enough
+    if (R.staged_pending) {
+        RD_HIP(hipEventSynchronize(R.staged));
+        R.staged_pending = false;
+    }
+    if (!R.staged) RD_HIP(hipEventCreateWithFlags(&R.staged, hipEventDisableTiming));
+    bool miss = false;
+    size_t n_desc = 0;
+    if ((rc = lane_plan_build(ctx, R, read_off, n_reads, chunk_len, step, mode, &miss, &n_desc))) return rc;
+    const ReadsPlan& P = R.plan;
+    // staging block: [read offsets | raw samples] | descriptors (plan miss) | AsmRead records (global mode)
+    const size_t st_off = align_up((size_t)(n_reads + 1) * 8, 256);
+    const size_t st_raw = raw ? align_up(n_samples * 2 + 16, 256) : 0;
+    const size_t st_desc = miss ? align_up(n_desc * sizeof(TileDesc), 256) : 0;
+    const size_t st_asm = mode == 1 ? align_up((size_t)n_reads * sizeof(AsmRead), 256) : 0;
+    const size_t o_raw = st_off, o_desc = raw ? st_off + st_raw : 0, o_asm = o_desc + st_desc;
+    if ((rc = pinned_reserve(&R.h_stage, &R.h_stage_cap, o_asm + st_asm + 256))) return rc;
+    char* hs = (char*)R.h_stage;
+    // device: descriptors | AsmRead records
+    const size_t d_asm = align_up(n_desc * sizeof(TileDesc), 256);
+    if (d_asm + st_asm + 256 > R.tiles.cap) {
+        RD_HIP(hipStreamSynchronize(L->st));   // the lane's previous forward may still read the old descriptors
+        if (!miss) {                           // (cannot happen: a hit has the same reads, hence the same sizes)
+            rd_set_error("internal: descriptor buffer too small on a plan hit");
+            return RD_ERR_STATE;
+        }
+        if (R.tiles.reserve(d_asm + st_asm + (d_asm + st_asm) / 4 + 256)) {
+            R.valid = false;
+            return RD_ERR_NOMEM;
+        }
+    }
+    // device: read offsets | status | int16 samples ; normalised signal
+    const size_t d_st = st_off, d_raw = st_off + align_up((size_t)n_reads * 4, 256);
+    if (raw && (d_raw + st_raw > R.raw.cap || n_samples * 4 + 16 > R.sig.cap)) {
+        RD_HIP(hipStreamSynchronize(L->st));   // the lane's previous forward still reads its signal
+        if (R.raw.reserve(d_raw + st_raw + (d_raw + st_raw) / 4) || R.sig.reserve(n_samples * 4 + n_samples + 16)) return RD_ERR_NOMEM;
+    }
+
+    // ---- the group this batch joins (may close / deliver earlier groups)
+    RSlot* s = nullptr;
+    if ((rc = open_slot(ctx, p, mode, W, f16, use_lm, s_thr, r_thr, P.total_rows, &s))) return rc;
+
+    // ---- its sequences (and, in global mode, the per-read assembly records), not yet part of the group
+    RSub sb;
+    sb.seq0 = (int)s->seqs.size();
+    sb.read0 = s->n_reads;
+    sb.n_reads = n_reads;
+    sb.user_labels = labels_out;
+    sb.user_lens = label_len;
+    sb.user_status = raw ? status : nullptr;
+    std::vector<RSeq> seqs;
+    int64_t longest = 0, rows64 = s->rows64, labels_total = s->labels_total, max_n = 0;
+    int n64 = 0;
+    if (mode == 1) {
+        AsmRead* ar = (AsmRead*)(hs + o_asm);
+        for (int r = 0; r < n_reads; r++) {
+            const int nW = P.read_win_off[r + 1] - P.read_win_off[r];
+            const int pad = P.valid[r];
+            const int64_t N = assembled_rows(nW, chunk_len, pad, step);
+            RD_REQUIRE(N == read_off[r + 1] - read_off[r], "internal: assembled length mismatch for read %d", r);
+            RSeq q;
+            q.split = 0;
+            q.len = (int32_t)N;
+            q.is64 = assembled_is_f64(nW, chunk_len, pad, step);
+            q.label_off = labels_total;
+            if (q.is64) {
+                AsmRead& a = ar[n64++];
+                a.src_row = s->rows + P.read_row[r];
+                a.out_row = rows64;
+                a.N = (int32_t)N;
+                a.nW = nW;
+                a.pad = pad;
+                a.pad_ = 0;
+                q.off1 = q.off2 = rows64;   // float64 rows go behind the group's previous ones
+                rows64 += N;
+                if (N > max_n) max_n = N;
+            } else {
+                q.off1 = q.off2 = s->rows + P.read_row[r];   // single coverage: the forward's rows are consecutive time steps
+            }
+            labels_total += N;
+            if (N > longest) longest = N;
+            seqs.push_back(q);
+            sb.user_label_off.push_back(label_off[r]);
+        }
+        sb.n_seq = n_reads;
+    } else {
+        for (int w = 0; w < P.n_windows; w++) {
+            RSeq q;
+            q.off1 = P.off1[w] + s->rows;
+            q.off2 = P.off2[w] + s->rows;
+            q.split = P.split[w];
+            q.len = P.valid[w];
+            q.is64 = 0;
+            q.label_off = labels_total;
+            labels_total += chunk_len;
+            seqs.push_back(q);
+            sb.user_label_off.push_back((int64_t)w * chunk_len);
+        }
+        sb.n_seq = P.n_windows;
+    }
+    if (raw && (size_t)(s->n_reads + n_reads) * 4 > s->status.cap) {
+        // growing moves the statuses already gathered for this group (few bytes; the lanes that wrote them must be done)
+        DevBuf nb;
+        if (nb.reserve((size_t)(s->n_reads + n_reads) * 8 + 4096)) return RD_ERR_NOMEM;
+        if (s->n_reads && s->status.p) {
+            for (int l = 0; l < RD_MAX_LANES; l++)
+                if (s->lane_mask & (1u << l)) RD_HIP(hipStreamSynchronize(ctx->lanes[l].st));
+            RD_HIP(hipMemcpy(nb.p, s->status.p, (size_t)s->n_reads * 4, hipMemcpyDeviceToDevice));
+        }
+        s->status.release();
+        s->status = nb;
+    }
+
+    // ---- the lane's work, in stream order: copies out of the staging block, normalise, forward, assembly
+    const float* sig = d_signal;
+    if (raw) {
+        memcpy(hs, read_off, (size_t)(n_reads + 1) * 8);
+        memcpy(hs + o_raw, raw, n_samples * 2);
+        char* base = (char*)R.raw.p;
+        RD_HIP(hipMemcpyAsync(base, hs, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, L->st));
+        RD_HIP(hipMemcpyAsync(base + d_raw, hs + o_raw, n_samples * 2, hipMemcpyHostToDevice, L->st));
+        if ((rc = rd_normalise_dev(ctx, (const int16_t*)(base + d_raw), (const int64_t*)base, n_reads, clip, R.sig.as<float>(),
+                                   (int32_t*)(base + d_st), L->st)))
+            return rc;
+        sig = R.sig.as<float>();
+    }
+    if (miss && (rc = lane_plan_upload(L, R, hs + o_desc))) {
+        R.valid = false;
+        return rc;
+    }
+    AsmRead* d_ar = (AsmRead*)((char*)R.tiles.p + d_asm);
+    if (n64) RD_HIP(hipMemcpyAsync(d_ar, hs + o_asm, (size_t)n64 * sizeof(AsmRead), hipMemcpyHostToDevice, L->st));
+    RD_HIP(hipEventRecord(R.staged, L->st));   // the staging block is free once these copies are done
+    R.staged_pending = true;
+    const size_t rb = f16 ? 10 : 20;
+    if ((rc = rd_forward_tiles_dev(ctx, sig, R.lists, P.total_rows, (char*)s->probs.p + (size_t)s->rows * rb, lane, f16))) return rc;
+    if (n64 && (rc = rd_assemble_batch_dev(L->st, s->probs.p, d_ar, n64, max_n, chunk_len, step, s->mat.as<double>(), R.streamed ? 1 : 0, f16)))
+        return rc;
+    if (raw)
+        RD_HIP(hipMemcpyAsync((char*)s->status.p + (size_t)s->n_reads * 4, (char*)R.raw.p + d_st, (size_t)n_reads * 4, hipMemcpyDeviceToDevice, L->st));
+    RD_HIP(hipEventRecord(L->done, L->st));   // the decode stream waits for this before it reads the group
+
+    // ---- the batch is part of the group
+    s->seqs.insert(s->seqs.end(), seqs.begin(), seqs.end());
+    s->rows64 = rows64;
+    s->labels_total = labels_total;
+    s->lane_mask |= 1u << lane;
+    s->n_reads += n_reads;
+    s->rows += P.total_rows;
+    if (longest > s->longest) s->longest = longest;
+    s->subs.push_back(std::move(sb));
+    p->next_lane = (lane + 1) % n_lanes;
+    p->submitted++;
+    const bool full = (int)s->subs.size() >= ctx->pipe_group;
+    const bool covered = mode == 1 && s->rows >= chain_rows(W) * s->longest;
+    if (full || covered) return close_group(ctx, p);
+    return RD_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ internal hooks
+bool rd_rpipe_idle(const rd_ctx* ctx)
+{
+    const ReadsPipe* p = (const ReadsPipe*)ctx->rpipe;
+    return !p || (p->slot[0].seqs.empty() && p->slot[1].seqs.empty() && !p->slot[0].busy && !p->slot[1].busy);
+}
+
+int rd_rpipe_drain_decode(rd_ctx* ctx)
+{
+    ReadsPipe* p = (ReadsPipe*)ctx->rpipe;
+    if (p && p->s_dec && (p->slot[0].busy || p->slot[1].busy)) RD_HIP(hipStreamSynchronize(p->s_dec));
+    return RD_OK;
+}
+
+int rd_rpipe_flush(rd_ctx* ctx)
+{
+    ReadsPipe* p = (ReadsPipe*)ctx->rpipe;
+    if (!p) return RD_OK;
+    int rc;
+    RSlot& a = p->slot[p->cur ^ 1];   // launched before the open group, if at all
+    RSlot& b = p->slot[p->cur];
+    if ((rc = slot_launch_decode(ctx, p, b))) return rc;
+    if ((rc = slot_collect(p, a))) return rc;
+    return slot_collect(p, b);
+}
+
+void rd_rpipe_destroy(rd_ctx* ctx)
+{
+    ReadsPipe* p = (ReadsPipe*)ctx->rpipe;
+    if (!p) return;
+    if (p->s_dec) (void)hipStreamSynchronize(p->s_dec);
+    for (int i = 0; i < 2; i++) {
+        RSlot& s = p->slot[i];
+        s.probs.release();
+        s.mat.release();
+        s.meta.release();
+        s.labels.release();
+        s.status.release();
+        if (s.h_meta) (void)hipHostFree(s.h_meta);
+        if (s.h_out) (void)hipHostFree(s.h_out);
+        if (s.dec_done) (void)hipEventDestroy(s.dec_done);
+    }
+    for (int i = 0; i < RD_MAX_LANES; i++) {
+        RLane& R = p->lane[i];
+        R.tiles.release();
+        R.raw.release();
+        R.sig.release();
+        if (R.h_stage) (void)hipHostFree(R.h_stage);
+        if (R.staged) (void)hipEventDestroy(R.staged);
+    }
+    if (p->s_dec) (void)hipStreamDestroy(p->s_dec);
+    delete p;
+    ctx->rpipe = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" int rd_pipe_submit_reads_global(rd_ctx* ctx, const float* d_signal, const int64_t* read_off, int n_reads, int chunk_len, int step,
+                                           int beam_width, int use_lm, double s_thr, double r_thr, uint8_t* labels_out,
+                                           const int64_t* label_off, int32_t* label_len)
+{
+    int rc = check_args(ctx, d_signal, read_off, n_reads, chunk_len, step, beam_width);
+    if (rc) return rc;
+    RD_REQUIRE(labels_out && label_off && label_len, "rd_pipe_submit_reads_global: null output");
+    return submit(ctx, 1, d_signal, nullptr, 0, read_off, n_reads, chunk_len, step, beam_width, use_lm ? 1 : 0, s_thr, r_thr, labels_out, label_off,
+                  label_len, nullptr);
+}
+
+extern "C" int rd_pipe_submit_raw_global(rd_ctx* ctx, const int16_t* raw, const int64_t* read_off, int n_reads, int outlier_clip, int chunk_len,
+                                         int step, int beam_width, int use_lm, double s_thr, double r_thr, uint8_t* labels_out,
+                                         const int64_t* label_off, int32_t* label_len, int32_t* status)
+{
+    int rc = check_args(ctx, raw, read_off, n_reads, chunk_len, step, beam_width);
+    if (rc) return rc;
+    RD_REQUIRE(labels_out && label_off && label_len && status, "rd_pipe_submit_raw_global: null output");
+    return submit(ctx, 1, nullptr, raw, outlier_clip, read_off, n_reads, chunk_len, step, beam_width, use_lm ? 1 : 0, s_thr, r_thr, labels_out,
+                  label_off, label_len, status);
+}
+
+extern "C" int rd_pipe_submit_raw_chunk(rd_ctx* ctx, const int16_t* raw, const int64_t* read_off, int n_reads, int outlier_clip, int chunk_len,
+                                        int step, int beam_width, uint8_t* labels_out, int32_t* label_len, int32_t* status)
+{
+    int rc = check_args(ctx, raw, read_off, n_reads, chunk_len, step, beam_width);
+    if (rc) return rc;
+    RD_REQUIRE(labels_out && label_len && status, "rd_pipe_submit_raw_chunk: null output");
+    return submit(ctx, 0, nullptr, raw, outlier_clip, read_off, n_reads, chunk_len, step, beam_width, 0, 0.0, 0.0, labels_out, nullptr, label_len,
+                  status);
+}
+
+extern "C" int rd_pipe_submitted(rd_ctx* ctx, int64_t* submitted)
+{
+    RD_REQUIRE(ctx && submitted, "rd_pipe_submitted: null argument");
+    const ReadsPipe* p = (const ReadsPipe*)ctx->rpipe;
+    *submitted = p ? p->submitted : 0;
+    return RD_OK;
+}
+
+extern "C" int rd_pipe_progress(rd_ctx* ctx, int64_t wait_for, int64_t* delivered)
+{
+    RD_REQUIRE(ctx, "rd_pipe_progress: null context");
+    ReadsPipe* p = (ReadsPipe*)ctx->rpipe;
+    if (!p) {
+        if (delivered) *delivered = 0;
+        RD_REQUIRE(wait_for <= 0, "rd_pipe_progress: waiting for %lld submits, none made", (long long)wait_for);
+        return RD_OK;
+    }
+    RD_REQUIRE(wait_for <= p->submitted, "rd_pipe_progress: waiting for %lld submits, %lld made", (long long)wait_for, (long long)p->submitted);
+    RD_HIP(hipSetDevice(ctx->device));
+    int rc;
+    for (;;) {
+        // groups finish in launch order
+        RSlot* first = nullptr;
+        for (int i = 0; i < 2; i++)
+            if (p->slot[i].busy && (!first || p->slot[i].launch_seq < first->launch_seq)) first = &p->slot[i];
+        if (first) {
+            const bool need = p->delivered < wait_for;
+            if (need || hipEventQuery(first->dec_done) == hipSuccess) {
+                if ((rc = slot_collect(p, *first))) return rc;
+                continue;
+            }
+            (void)hipGetLastError();   // hipErrorNotReady is not an error
+            break;
+        }
+        if (p->delivered < wait_for) {   // what is awaited sits in the open group: close it
+            if ((rc = close_group(ctx, p))) return rc;
+            continue;
+        }
+        break;
+    }
+    if (delivered) *delivered = p->delivered;
+    return RD_OK;
+}

@@ -129,10 +129,10 @@ __global__ __launch_bounds__(256) void mad_normalise_kernel(const int16_t* __res
 
 // d_raw [total] int16, d_read_off [n_reads+1] -> d_out [total] float32, d_status [n_reads]
 int rd_normalise_dev(rd_ctx* ctx, const int16_t* d_raw, const int64_t* d_read_off, int n_reads, int clip, float* d_out,
-                     int32_t* d_status)
+                     int32_t* d_status, hipStream_t stream)
 {
     if (n_reads == 0) return RD_OK;
-    hipLaunchKernelGGL(mad_normalise_kernel, dim3(n_reads), dim3(256), 0, ctx->stream, d_raw, d_read_off, clip, d_out, d_status);
+    hipLaunchKernelGGL(mad_normalise_kernel, dim3(n_reads), dim3(256), 0, stream ? stream : ctx->stream, d_raw, d_read_off, clip, d_out, d_status);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }

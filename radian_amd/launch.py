@@ -257,7 +257,7 @@ def run_rank(args, be, comm, scratch, sources, rank, world, stitch_pool=None, ba
 def worker(scratch, argv):
     from . import fast5
     from .backend import Backend
-    from .basecall import apply_artifacts, build_parser, load_artifacts, make_stitch_pool
+    from .basecall import apply_artifacts, build_parser, load_artifacts, make_stitch_pool, n_contexts
     from .dist import StartupFailed, connect, env_rank_world, uid_path
     args = build_parser().parse_args(argv)
     rank, local_rank, world = env_rank_world()
@@ -276,7 +276,7 @@ def worker(scratch, argv):
     comm.bcast_artifacts(be, lambda b: apply_artifacts(args, b, load_artifacts(args)))
     # the rank's further device contexts (--device-contexts, as in a single-GPU run: one context's forward overlaps the
     # other's beam search) take the images from the one that received the broadcast -- a device copy, no second parse
-    backends = [be] + [Backend(device) for _ in range(max(1, args.device_contexts) - 1)]
+    backends = [be] + [Backend(device) for _ in range(n_contexts(args) - 1)]
     for b in backends[1:]:
         b.clone_artifacts_from(be)
     for b in backends:

@@ -103,14 +103,14 @@ def test_cli_worker_path_with_rccl_single_rank(tmp_path, golden_dir):
     argv = [in_dir, str(a_dir), "--decode-type", "chunk", "--beam-width", "3", "--step-size", "512", "--sig-model", "synthetic:7",
             "--sig-config", "none", "--rna-model", "None"]
     basecall.main(argv)
-    argv_b = [in_dir, str(b_dir)] + argv[2:]
+    argv_b = [in_dir, str(b_dir)] + argv[2:] + ["--device-contexts", "2"]
     args = basecall.build_parser().parse_args(argv_b)
     args.gpus = 1
     report = launch.run_multi_gpu(args, argv_b)
     assert _read_fasta(str(a_dir)) == _read_fasta(str(b_dir))
     assert len(_read_fasta(str(b_dir))) == 5
-    # the worker drives its GPU the way the single-GPU CLI does: --device-contexts (default 2) contexts, the further ones
-    # filled by rd_clone_artifacts from the one that received the broadcast; the one-rank communicator is RCCL's
+    # the worker honours --device-contexts like the single-GPU CLI: the further contexts are filled by rd_clone_artifacts
+    # from the one that received the broadcast; the one-rank communicator is RCCL's
     assert report["ranks"] == [{"device": 0, "contexts": 2, "transport": "rccl"}], report
     assert report["records"] == 5
 

@@ -1,0 +1,214 @@
+"""The reads-level pipeline inside one context (rd_pipe_submit_reads_global / rd_pipe_submit_raw_global /
+rd_pipe_submit_raw_chunk / rd_pipe_progress; csrc/pipe_reads.hip): forwards of consecutive batches on rotating lanes,
+per-read assembly on the lane, the beam search of a group of batches on the decode stream.
+
+Parity: every submitted batch's labels equal (a) the unpipelined entry point's on the same input and (b) the oracle's --
+normalise -> windows -> assemble (matrix_assembly.py:6-53) -> LM beam search (decode.py:100-212) of the GPU's own
+probabilities -- at BASELINE configs[3]'s geometry (64 reads x 4096, global, step 512, W = 10, 4^11-row LM, 0.5 / 0.5)
+with the soft head (the LM gate fires), and over ragged batches (plan rebuilt and uploaded per submit, reads shorter than
+a window, the streamed / windowed boundary at step 772 / 773, MAD-zero reads, f16 logits)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CHUNK, READ_LEN = 1024, 4096
+
+
+def _soft_weights():
+    from radian_amd import weights
+    w = weights.synthetic_weights(seed=1234).copy()
+    w[-645:-5] *= np.float32(0.05)        # soft rows: ~1000-base labelings per read, the LM gate fires
+    return w
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from radian_amd import Backend
+    b = Backend(0)
+    b.load_weights(_soft_weights())
+    yield b
+    b.close()
+
+
+def _ragged(rng, n, lo=1, hi=9000, special=()):
+    from radian_amd import synthetic
+    lens = [int(x) for x in rng.integers(lo, hi, size=n)]
+    for i, v in enumerate(special):
+        lens[i % n] = v
+    reads = [synthetic.synthetic_reads(1, L, seed=int(rng.integers(1 << 30)))[0] for L in lens]
+    return reads
+
+
+def test_pipe_global_cfg3_equals_unpipelined_and_oracle(dev, oracle):
+    from radian_amd import synthetic
+    k, W, step = 11, 10, 512
+    table = np.random.default_rng(0).dirichlet([0.3] * 4, size=4 ** k)
+    dev.load_lm(table, k)
+    try:
+        batches = [list(synthetic.synthetic_reads(64, READ_LEN, seed=1000 + b)) for b in range(3)]
+        ref = [dev.basecall_raw_global(b, 4, CHUNK, step, W, True, 0.5, 0.5) for b in batches]
+        dev.pipe_flush()
+        dev.pipe_config(4)
+        dev.pipe_set_lanes(2)
+        base = dev.pipe_progress(0)
+        tickets = [dev.pipe_submit_raw("global", batches[i % 3], 4, CHUNK, step, W, True, 0.5, 0.5) for i in range(7)]
+        # 64 x 4096 rows per submit < 96 rows x 4096 chain steps: a group closes after two submits, so by now three groups
+        # have been launched and the first ones delivered without anyone waiting for them
+        assert dev.pipe_progress(0) >= base + 2
+        for i, t in enumerate(tickets):
+            got, status = t.result()
+            assert not status.any()
+            bad = [r for r in range(64) if not np.array_equal(got[r], ref[i % 3][0][r])]
+            assert not bad, (i, bad[:8], len(bad))
+        assert dev.pipe_progress(0) == base + 7
+        # the oracle on batch 0: its own normalisation and windows, the GPU's probabilities
+        mats, lens = [], []
+        for raw in batches[0]:
+            win, pad = oracle.get_windows(oracle.mad_normalise(raw, 4), CHUNK, step)
+            m = oracle.assemble_matrices(dev.forward(np.asarray(win, dtype=np.float32)), pad, step)
+            mats.append(m)
+            lens.append(m.shape[0])
+        lens = np.asarray(lens, dtype=np.int32)
+        off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        exp = oracle.beam_search_batch(np.concatenate(mats), off, lens, W, table, 0.5, 0.5, k)
+        got = tickets[0].result()[0]
+        bad = [r for r in range(64) if not np.array_equal(got[r], exp[r])]
+        assert not bad, (bad[:8], len(bad))
+        nolm = oracle.beam_search_batch(np.concatenate(mats), off, lens, W)
+        assert sum(not np.array_equal(a, c) for a, c in zip(exp, nolm)) >= 32      # the gate really fired
+    finally:
+        dev.load_lm(None, 0)
+
+
+@pytest.mark.parametrize("step,W,logits", [(128, 6, "f32"), (512, 10, "f32"), (772, 3, "f32"), (773, 10, "f32"), (1024, 6, "f32"),
+                                           (512, 25, "f16"), (300, 13, "f32")])
+def test_pipe_global_ragged_equals_unpipelined(dev, step, W, logits):
+    """every submit has other read lengths (the lane's plan is rebuilt and uploaded behind its previous forward); reads of
+    1 .. 9000 samples incl. shorter than a window (float32 rows, no assembly), exactly a window, a multiple of the step; a
+    constant read (MAD = 0 -> status 1); group size 3 on 2 and 3 lanes"""
+    rng = np.random.default_rng(step * 100 + W)
+    table = np.random.default_rng(1).dirichlet([0.3] * 4, size=4 ** 3)
+    dev.load_lm(table, 3)
+    dev.set_logits(logits)
+    try:
+        for lanes in (2, 3):
+            batches = []
+            for i in range(7):
+                reads = _ragged(rng, int(rng.integers(1, 40)), special=(1, CHUNK, CHUNK - 1, CHUNK + 1, 4 * step, CHUNK + 3 * step))
+                if i % 2:
+                    reads[len(reads) // 2] = np.full(777, 5, dtype=np.int16)
+                batches.append(reads)
+            ref = [dev.basecall_raw_global(b, 4, CHUNK, step, W, True, 0.2, 0.9) for b in batches]
+            dev.pipe_flush()
+            dev.pipe_config(3)
+            dev.pipe_set_lanes(lanes)
+            tickets = [dev.pipe_submit_raw("global", b, 4, CHUNK, step, W, True, 0.2, 0.9) for b in batches]
+            dev.pipe_flush()
+            for i, t in enumerate(tickets):
+                assert t.done()
+                got, status = t.result()
+                assert np.array_equal(status, ref[i][1]), (i, status, ref[i][1])
+                bad = [r for r in range(len(batches[i])) if status[r] == 0 and not np.array_equal(got[r], ref[i][0][r])]
+                assert not bad, (step, W, lanes, i, bad[:8], len(bad))
+            assert any(s.any() for _, s in ref)
+    finally:
+        dev.set_logits("f32")
+        dev.load_lm(None, 0)
+        dev.pipe_config(4)
+        dev.pipe_set_lanes(2)
+
+
+@pytest.mark.parametrize("step,W", [(512, 10), (128, 6), (1000, 25)])
+def test_pipe_raw_chunk_ragged_equals_unpipelined(dev, step, W):
+    rng = np.random.default_rng(step + W)
+    batches = [_ragged(rng, int(rng.integers(1, 24)), hi=6000, special=(1, CHUNK, CHUNK + step)) for _ in range(6)]
+    batches.append(batches[2])          # the same lengths again on the same lane two submits later: a plan hit
+    batches.append(batches[2])
+    ref = [dev.basecall_raw_chunk(b, 4, CHUNK, step, W) for b in batches]
+    dev.pipe_flush()
+    dev.pipe_config(3)
+    tickets = [dev.pipe_submit_raw("chunk", b, 4, CHUNK, step, W) for b in batches]
+    for i, t in enumerate(tickets):
+        got, status = t.result()
+        assert np.array_equal(status, ref[i][1])
+        for r in range(len(batches[i])):
+            assert len(got[r]) == len(ref[i][0][r])
+            bad = [w for w in range(len(got[r])) if not np.array_equal(got[r][w], ref[i][0][r][w])]
+            assert not bad, (step, W, i, r, bad[:5])
+    dev.pipe_config(4)
+
+
+def test_pipe_resident_global_and_progress_contract(dev):
+    """rd_pipe_submit_reads_global on normalised reads resident in HBM; rd_pipe_progress: non-blocking with wait_for 0,
+    blocking (and closing the open group) with wait_for > 0, an error beyond what was submitted"""
+    from radian_amd import RadianHipError, synthetic
+    n, W, step = 48, 6, 128
+    raws = synthetic.synthetic_reads(n, READ_LEN, seed=77)
+    norm = np.stack([synthetic.mad_normalise(r, 4) for r in raws]).astype(np.float32)
+    ref = dev.basecall_reads_global(list(norm), CHUNK, step, W, False)
+    d = dev.dev_alloc(norm.nbytes)
+    dev.h2d(d, norm)
+    off = np.arange(n + 1, dtype=np.int64) * READ_LEN
+    lab_off = np.ascontiguousarray(off[:-1])
+    try:
+        dev.pipe_flush()
+        dev.pipe_config(8)
+        base = dev.pipe_progress(0)
+        outs = [(np.zeros(n * READ_LEN + 1, dtype=np.uint8), np.full(n, -1, dtype=np.int32)) for _ in range(3)]
+        # 48 x 4096 rows per submit >= 96 x 4096: every submit is a group of its own
+        for lab, ln in outs:
+            dev.pipe_submit_reads_global(d, off, n, CHUNK, step, W, False, 0.0, 0.0, lab, lab_off, ln)
+        assert dev.pipe_progress(base + 1) >= base + 1
+        assert outs[0][1].min() >= 0
+        with pytest.raises(RadianHipError):
+            dev.pipe_progress(base + 4)
+        dev.pipe_flush()
+        assert dev.pipe_progress(0) == base + 3
+        for lab, ln in outs:
+            for r in range(n):
+                assert np.array_equal(lab[off[r]: off[r] + ln[r]], ref[r]), r
+        # an unpipelined call between submits and their delivery shares the trie workspace: results stay right
+        lab, ln = np.zeros(n * READ_LEN + 1, dtype=np.uint8), np.full(n, -1, dtype=np.int32)
+        dev.pipe_submit_reads_global(d, off, n, CHUNK, step, W, False, 0.0, 0.0, lab, lab_off, ln)
+        again = dev.basecall_reads_global(list(norm), CHUNK, step, W, False)
+        dev.pipe_flush()
+        assert all(np.array_equal(a, b) for a, b in zip(again, ref))
+        assert all(np.array_equal(lab[off[r]: off[r] + ln[r]], ref[r]) for r in range(n))
+    finally:
+        dev.pipe_flush()
+        dev.dev_free(d)
+        dev.pipe_config(4)
+
+
+def test_cli_driver_pipelined_equals_blocking(tmp_path):
+    """radian_amd.basecall.run through the in-context pipeline (default) and with --no-pipeline: same results, same order,
+    both decode types, ragged reads in small device batches (several groups in flight)"""
+    from radian_amd import Backend, basecall
+    rng = np.random.default_rng(5)
+    reads = _ragged(rng, 90, lo=200, hi=7000)
+
+    class R:
+        def __init__(self, i, s):
+            self.read_id, self._s = f"r{i:04d}", s
+
+        def get_raw_data(self):
+            return self._s
+    for mode in ("global", "chunk"):
+        res = {}
+        for flag in ([], ["--no-pipeline"]):
+            args = basecall.build_parser().parse_args(["-", "-", "--decode-type", mode, "--step-size", "512", "--beam-width", "6", "--rna-model", "None",
+                                                       "--gpu-batch-windows", "64"] + flag)
+            args._lm_loaded = False
+            bes = [Backend(0) for _ in range(basecall.n_contexts(args))]
+            try:
+                bes[0].load_weights(_soft_weights())
+                for b in bes[1:]:
+                    b.clone_artifacts_from(bes[0])
+                import contextlib, io
+                with contextlib.redirect_stdout(io.StringIO()):
+                    res[bool(flag)] = basecall.run(args, bes, reads=iter([R(i, s) for i, s in enumerate(reads)]), writer=None)
+            finally:
+                for b in bes:
+                    b.close()
+        assert len(res[False]) == 90 and res[False] == res[True], mode
