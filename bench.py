@@ -34,6 +34,14 @@ FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2
 F16_MFMA_PEAK_TFLOPS = 16 * 157.3      # dense f16 MFMA = 16x the fp32 MFMA rate (~2.5 PFLOP/s)
 
 
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """progress line on stderr (stdout carries the one JSON line only)"""
+    print(f"[bench {time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def effective_cores():
     """CPU cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (a GPU box hands
     a job a share of the host -- os.cpu_count() reports every hardware thread of the machine)."""
@@ -118,46 +126,74 @@ class _MemRead:
         return self._sig
 
 
-def e2e_raw_leg(device, pool, n_reads, precision):
-    """BASELINE configs[2] end to end through the product's driver loop (radian_amd.basecall.run = basecall.py:69-141):
-    host int16 reads -> H2D -> MAD normalisation on the device -> forward -> chunk beam search -> labels to the host ->
-    simple_assembly consensus strings (stitch workers), results in input order; everything but fast5 parsing / FASTA IO."""
-    import contextlib
-    from radian_amd import Backend, basecall, synthetic, weights
-    args = basecall.build_parser().parse_args(["-", "-", "--decode-type", "chunk", "--step-size", str(STEP), "--chunk-len", str(CHUNK),
-                                               "--beam-width", str(BEAM), "--rna-model", "None"])
-    args._lm_loaded = False
-    bes = [Backend(device) for _ in range(2)]
-    try:
-        bes[0].load_weights(weights.synthetic_weights(seed=1234))
-        bes[1].clone_artifacts_from(bes[0])      # (as radian_amd.basecall.main sets up its further contexts)
-        for b in bes:
-            b.set_precision(precision)
+def soft_head_weights():
+    """the bench model with its last Dense kernel x 0.05 (the tests' soft head): softmax rows of ~0.85 nat entropy instead of
+    saturated ones, ~200-base fragments per window / ~1000 bases per read -- the beam search's and the stitch's real load"""
+    from radian_amd import weights
+    w = weights.synthetic_weights(seed=1234).copy()
+    w[-645:-5] *= np.float32(0.05)
+    return w
 
-        def go(n, seed):
-            raws = synthetic.synthetic_reads(n, READ_LEN, seed=seed)
-            reads = [_MemRead(f"{i:08d}", raws[i]) for i in range(n)]
+
+def ragged_lengths(n, seed, lo=1500, hi=60000, median=9000.0, sigma=0.8):
+    """seeded log-normal read lengths (dRNA reads are heavy-tailed): every device batch gets its own plan"""
+    rng = np.random.default_rng(seed)
+    return np.clip(np.exp(rng.normal(np.log(median), sigma, size=n)), lo, hi).astype(np.int64)
+
+
+def total_note(lengths, dt):
+    return f"{int(np.sum(lengths)) / dt / 1e6:.2f} M samples/s ({dt:.2f} s)"
+
+
+def driver_leg(device, pool, cli, lengths, seed, weights_flat, lm=None, warm_reads=256, desc=""):
+    """A job through the product's driver loop (radian_amd.basecall.run = basecall.py:69-141) with the CLI flags `cli`:
+    host int16 reads -> H2D -> MAD normalisation on the device -> streamed forward -> (assembly) -> beam search -> labels to
+    the host -> strings (chunk mode: simple_assembly in the stitch workers), results in input order; everything but fast5
+    parsing and FASTA writing.  Device contexts / pipelining as the CLI defaults choose them."""
+    import contextlib
+    from radian_amd import Backend, basecall
+    args = basecall.build_parser().parse_args(["-", "-"] + cli)
+    bes = [Backend(device) for _ in range(basecall.n_contexts(args))]
+    try:
+        bes[0].load_weights(weights_flat)
+        if lm is not None:
+            bes[0].load_lm(lm[0], lm[1])
+        for b in bes[1:]:
+            b.clone_artifacts_from(bes[0])
+        for b in bes:
+            b.set_decode_partition(args.decode_partition)
+        args._lm_loaded = lm is not None
+        rng = np.random.default_rng(seed)
+
+        def go(lens):
+            reads = [_MemRead(f"{i:08d}", np.rint(rng.normal(500.0, 80.0, size=int(n))).astype(np.int16)) for i, n in enumerate(lens)]
             with open(os.devnull, "w") as dn, contextlib.redirect_stdout(dn):
                 t0 = time.perf_counter()
-                res = basecall.run(args, bes, reads=iter(reads), writer=None, stitch_pool=pool)
+                res = basecall.run(args, bes, reads=iter(reads), writer=None, stitch_pool=pool if args.decode_type == "chunk" else None)
                 dt = time.perf_counter() - t0
-            assert len(res) == n and all(len(r[2]) > 0 for r in res)
-            return dt
-        go(1024, 70001)                      # warm-up: allocations, plans, worker start
-        dt = go(n_reads, 70002)
+            assert len(res) == len(lens) and all(len(r[2]) > 0 for r in res)
+            return dt, float(np.mean([len(r[2]) for r in res]))
+        go(lengths[:warm_reads])                  # warm-up: allocations, worker start
+        dt, mean_bases = go(lengths)
+        note(f"  {total_note(lengths, dt)}")
     finally:
         for b in bes:
             b.close()
-    return {"value": n_reads * READ_LEN / dt, "unit": "samples/s", "reads": n_reads, "seconds": dt,
-            "path": "host int16 -> H2D -> on-device mad_normalise -> streamed forward -> chunk beam search W=10 -> labels D2H -> "
-                    f"simple_assembly strings ({pool._max_workers if pool is not None else 0} stitch worker processes), 2 device contexts, "
-                    "batches of 512 reads; excludes fast5 parsing and FASTA writing"}
+    total = int(np.sum(lengths))
+    return {"value": total / dt, "unit": "samples/s", "reads": int(len(lengths)), "samples": total, "seconds": dt,
+            "mean_bases_per_read": mean_bases, "cli": " ".join(cli),
+            "device_contexts": len(bes), "pipelined": not args.no_pipeline,
+            "stitch_workers": (pool._max_workers if pool is not None and args.decode_type == "chunk" else 0),
+            "path": desc + "; host int16 -> H2D -> on-device mad_normalise -> streamed forward -> beam search -> labels D2H -> strings, "
+                           "through radian_amd.basecall.run; excludes fast5 parsing and FASTA writing"}
 
 
-def global_leg(device, batches_host, read_off, reads_per_batch, steps, W, table, table_order, context_len, hashed, logits, desc):
-    """Global decode (one beam search per read over the assembled float64 matrix) of the bench batches on one GPU, the way
-    the product's driver runs it (radian_amd.basecall.run): two device contexts on two host threads taking the steps in
-    turn, so that one step's forward overlaps the other's beam search; inputs resident in HBM, labels on the host at stop."""
+def global_leg(device, batches_host, read_off, reads_per_batch, steps, W, table, table_order, context_len, hashed, logits, desc,
+               weights_flat=None, warmup=4):
+    """Global decode (one beam search per read over the assembled float64 matrix) of the bench batches on one GPU, inputs
+    resident in HBM, labels on the host at stop.  `value`: ONE context, rd_pipe_submit_reads_global (forwards on two lanes,
+    assembly on the lane, the beam search of a group of steps on the decode stream under the next group's forwards).
+    `two_contexts_unpipelined`: round 2's way -- two contexts on two host threads taking the steps in turn."""
     import threading
     from radian_amd import Backend, weights
     bes, bufs = [], []
@@ -167,7 +203,7 @@ def global_leg(device, batches_host, read_off, reads_per_batch, steps, W, table,
             if bes:
                 b.clone_artifacts_from(bes[0])
             else:
-                b.load_weights(weights.synthetic_weights(seed=1234))
+                b.load_weights(weights_flat if weights_flat is not None else weights.synthetic_weights(seed=1234))
                 if hashed:
                     b.load_lm_hashed(table, table_order, context_len)
                 else:
@@ -181,6 +217,26 @@ def global_leg(device, batches_host, read_off, reads_per_batch, steps, W, table,
             bes.append(b)
             bufs.append(d)
         label_off = np.ascontiguousarray(read_off[:-1])
+        nb_host = len(batches_host)
+        # ---- one context, pipelined
+        be = bes[0]
+        ring = [(np.zeros(reads_per_batch * READ_LEN + 1, dtype=np.uint8), np.full(reads_per_batch, -1, dtype=np.int32)) for _ in range(16)]
+
+        def run_pipe(n):
+            for i in range(n):
+                lab, ln = ring[i % len(ring)]
+                be.pipe_submit_reads_global(bufs[0][i % nb_host], read_off, reads_per_batch, CHUNK, STEP, W, True, 0.5, 0.5, lab, label_off, ln)
+                if i >= 8:
+                    be.pipe_progress(be.pipe_submitted() - 8)   # at most 8 steps' buffers in flight (as the driver loop keeps them)
+            be.pipe_flush()
+            be.sync()
+        run_pipe(warmup)
+        t0 = time.perf_counter()
+        run_pipe(steps)
+        dt_pipe = time.perf_counter() - t0
+        assert all(o[1].min() > 0 for o in ring[: min(steps, len(ring))])
+        mean_bases = float(np.mean(ring[0][1]))
+        # ---- two contexts, unpipelined calls
         outs = [(np.zeros(reads_per_batch * READ_LEN + 1, dtype=np.uint8), np.zeros(reads_per_batch, dtype=np.int32)) for _ in range(2)]
         err = []
 
@@ -188,7 +244,7 @@ def global_leg(device, batches_host, read_off, reads_per_batch, steps, W, table,
             try:
                 lab, ln = outs[k]
                 for i in range(lo + k, hi, 2):
-                    bes[k].basecall_reads_global_resident(bufs[k][i % len(batches_host)], read_off, reads_per_batch, CHUNK, STEP, W, True,
+                    bes[k].basecall_reads_global_resident(bufs[k][i % nb_host], read_off, reads_per_batch, CHUNK, STEP, W, True,
                                                           0.5, 0.5, lab, label_off, ln)
                 bes[k].sync()
             except Exception as e:   # surfaced below
@@ -207,49 +263,18 @@ def global_leg(device, batches_host, read_off, reads_per_batch, steps, W, table,
         run(0, steps)
         dt = time.perf_counter() - t0
         assert all(o[1].min() > 0 for o in outs)
-        # the same job in calls of 512 reads (8 bench batches side by side): 512 beam-search waves per call instead of 64 --
-        # the per-read serial chain (4096 time steps) is then a small part of a call
-        big = np.concatenate(batches_host * 2)[: 8 * reads_per_batch]
-        nb = big.shape[0]
-        off_b = np.arange(nb + 1, dtype=np.int64) * READ_LEN
-        lab_b, len_b = np.zeros(nb * READ_LEN + 1, dtype=np.uint8), np.zeros(nb, dtype=np.int32)
-        dbig = [b.dev_alloc(big.nbytes) for b in bes]
-        for b, p in zip(bes, dbig):
-            b.h2d(p, big)
-
-        def worker_big(k, n):
-            try:
-                for _ in range(n):
-                    bes[k].basecall_reads_global_resident(dbig[k], off_b, nb, CHUNK, STEP, W, True, 0.5, 0.5, lab_b if k == 0 else lab_b.copy(),
-                                                          np.ascontiguousarray(off_b[:-1]), len_b if k == 0 else len_b.copy())
-                bes[k].sync()
-            except Exception as e:
-                err.append(e)
-
-        def run_big(n):
-            th = [threading.Thread(target=worker_big, args=(k, n)) for k in range(2)]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-            if err:
-                raise err[0]
-        run_big(1)
-        t0 = time.perf_counter()
-        run_big(2)
-        dt_big = time.perf_counter() - t0
-        for b, p in zip(bes, dbig):
-            b.dev_free(p)
     finally:
         for b, d in zip(bes, bufs):
             for p in d:
                 b.dev_free(p)
             b.close()
-    return {"value": steps * reads_per_batch * READ_LEN / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "value_calls_of_512_reads": 4 * nb * READ_LEN / dt_big,
-            "config": desc + "; 64 reads x 4096 per step, --decode-type global, step 512; streamed forward + assembly (f64) + LM beam "
-                             "search; 2 device contexts on 2 host threads (as radian_amd.basecall.run): a step's forward overlaps the "
-                             "other context's beam search"}
+    return {"value": steps * reads_per_batch * READ_LEN / dt_pipe, "unit": "samples/s", "ms_per_step": dt_pipe / steps * 1e3, "steps": steps,
+            "mean_bases_per_read": mean_bases,
+            "two_contexts_unpipelined": steps * reads_per_batch * READ_LEN / dt,
+            "config": desc + "; 64 reads x 4096 per step, --decode-type global, step 512; ONE device context, rd_pipe_submit_reads_global: "
+                             "streamed forward on two lanes + per-read assembly (f64) on the lane, LM beam search of a group of steps (closed "
+                             "as soon as its forward rows cover the 4096-step chain of a read: two steps) on the decode stream under the "
+                             "next group's forwards; two_contexts_unpipelined = round 2's scheme (two contexts on two host threads)"}
 
 
 def self_launch(world, argv, worker_cmd=None):
@@ -442,7 +467,9 @@ def main():
                 be.pipe_flush()
                 return out[0]
             check_against_oracle(be, batches[0], piped)
+    note(f"rank {rank}: inputs resident, timing {args.steps} steps")
     elapsed = timed(submit_windowed if args.windowed else submit)
+    note(f"rank {rank}: headline {world * args.steps * reads_per_batch * READ_LEN / elapsed / 1e6:.2f} M samples/s")
     for lab, ln in out[: max(1, min(len(out), args.steps))]:
         assert ln.min() >= 0 and ln.max() <= CHUNK and ln.sum() > 0
 
@@ -533,6 +560,9 @@ def main():
                       "shares the chip (profiles/*_kernel_stats_default_2lanes.csv); pipeline_frac is the timed region's own figure. "
                       "decode_*: unpipelined single-batch steps (512 sequences alone on the chip)",
             "decode_timesteps_per_s": float(sum(batches[i % n_batches][1].sum() for i in range(n_dec))) / max(1e-9, td["total_ms"] * 1e-3),
+            # SURVEY 8d asks for both figures of the beam search: time steps/s (above) and the HBM fraction its 20 B per
+            # time step amount to -- the kernel is issue / latency bound (a T-long serial chain per sequence), not HBM bound
+            "decode_hbm_frac": float(sum(batches[i % n_batches][1].sum() for i in range(n_dec))) / max(1e-9, td["total_ms"] * 1e-3) * 20.0 / 8.0e12,
             "decode_timesteps_per_s_" + other + "_math": float(sum(batches[i % n_batches][1].sum() for i in range(n_dec))) / max(1e-9, tdg["total_ms"] * 1e-3),
         }
     # secondaries, reported beside the headline (one GPU, fp32 headline only): the same job in the other matrix-product
@@ -548,6 +578,7 @@ def main():
                  "f16x3 split products (3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate; 22-bit operands)",
                  "max |softmax - float64-accumulated reference|: 6.6e-6 / 6.5e-5 (peaky head) vs 1.1e-5 / 7.1e-5 for the fp32-MFMA mode "
                  "(tests/test_gpu_forward.py)")):
+            note(key)
             try:
                 be.set_precision(mode)
             except Exception:
@@ -562,23 +593,61 @@ def main():
         norms = [np.stack([synthetic.mad_normalise(r, 4) for r in synthetic.synthetic_reads(reads_per_batch, READ_LEN, seed=1000 * rank + b)]).astype(np.float32)
                  for b in range(n_batches)]
         table = np.random.default_rng(0).dirichlet([0.3] * 4, size=4 ** 11)
+        soft = soft_head_weights()
         for key, kw in (("secondary_global_lm", dict(W=BEAM, table_order=11, context_len=11, hashed=False, logits="f32",
                                                      desc="BASELINE configs[3] geometry, one GPU: beam 10, k=11 LM table (4^11 x 4 f64, Dirichlet(0.3) seed 0), "
                                                           "sig/rna thresholds 0.5/0.5")),
+                        ("secondary_global_lm_soft_head", dict(W=BEAM, table_order=11, context_len=11, hashed=False, logits="f32", weights_flat=soft,
+                                                               desc="the same with the soft head (last Dense kernel x 0.05: ~1000 bases per read, the LM "
+                                                                    "gate fires on most steps)")),
                         ("secondary_cfg5_w25_ctx256_f16", dict(W=25, table_order=11, context_len=256, hashed=True, logits="f16",
                                                                desc="BASELINE configs[4] stress: beam 25, --context-len 256 (hashed synthetic LM over a 4^11-row "
                                                                     "table, 256-label ring per beam), f16 logits; no reference behaviour (SURVEY F7): parity vs the "
                                                                     "oracle's same definition, tests/test_gpu_cfg5.py"))):
+            note(key)
             try:
                 sec[key] = global_leg(device, norms, read_off, reads_per_batch, args.steps, table=table, **kw)
             except Exception as e:
                 print(f"[bench] {key} failed: {e}", file=sys.stderr)
-        del table
+        # the headline step on the soft-head model (same timed region as `value`)
+        note("secondary_soft_head")
+        try:
+            be.load_weights(soft)
+            el_soft = timed(submit)
+            sec["secondary_soft_head"] = {
+                "value": world * args.steps * samples_per_step / el_soft, "unit": "samples/s", "ms_per_step": el_soft / args.steps * 1e3,
+                "mean_bases_per_window": float(np.mean([ln.mean() for _, ln in out[: max(1, min(len(out), args.steps))]])),
+                "config": "the headline's step and timed region with the soft head (last Dense kernel x 0.05): the headline's He-normal "
+                          "rows are saturated (~5 bases per 1024-row window); here windows decode to ~200 bases with merges and re-entries "
+                          "every step"}
+        except Exception as e:
+            print(f"[bench] secondary_soft_head failed: {e}", file=sys.stderr)
+        finally:
+            be.load_weights(weights.synthetic_weights(seed=1234))
         if args.e2e_reads > 0:
-            try:
-                sec["secondary_e2e_raw"] = e2e_raw_leg(device, stitch_pool, args.e2e_reads, args.precision)
-            except Exception as e:
-                print(f"[bench] secondary_e2e_raw failed: {e}", file=sys.stderr)
+            w0 = weights.synthetic_weights(seed=1234)
+            chunk_cli = ["--decode-type", "chunk", "--step-size", str(STEP), "--chunk-len", str(CHUNK), "--beam-width", str(BEAM), "--rna-model", "None"]
+            legs = (
+                ("secondary_e2e_raw", chunk_cli, np.full(args.e2e_reads, READ_LEN, dtype=np.int64), w0, None,
+                 f"BASELINE configs[2] end to end: {args.e2e_reads} uniform reads x 4096 (every batch has the same plan)"),
+                ("secondary_e2e_raw_ragged", chunk_cli, ragged_lengths(args.e2e_reads // 2, 71), w0, None,
+                 "the same job on RAGGED reads (seeded log-normal lengths, median 9000, 1.5 k .. 60 k samples): every device batch "
+                 "builds and uploads its own plan"),
+                ("secondary_e2e_raw_soft_head", chunk_cli, np.full(args.e2e_reads // 2, READ_LEN, dtype=np.int64), soft, None,
+                 "configs[2] end to end with the soft head: ~200-base fragments per window through the difflib stitch"),
+                ("secondary_reference_defaults", ["--rna-threshold", "0.5"], ragged_lengths(args.e2e_reads // 2, 72), soft, (table, 11),
+                 "the reference's own defaults (basecall.py:24-35): --decode-type global, step 128, beam 6, 12-mer LM (4^11-row table), "
+                 "thresholds 0.5 / 0.5, on ragged reads with the soft head"),
+                ("secondary_long_reads", ["--rna-threshold", "0.5"], np.full(max(256, args.e2e_reads // 16), 100000, dtype=np.int64), soft, (table, 11),
+                 "reference defaults on LONG reads (100 000 samples each: one read's beam search is a 0.2-s serial chain)"),
+            )
+            for key, cli, lens, wf, lm, desc in legs:
+                note(key)
+                try:
+                    sec[key] = driver_leg(device, stitch_pool, cli, lens, 70002, wf, lm=lm, desc=desc)
+                except Exception as e:
+                    print(f"[bench] {key} failed: {e}", file=sys.stderr)
+        del table
     if stitch_pool is not None:
         stitch_pool.shutdown()
     halo = 252
@@ -590,6 +659,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cores = effective_cores()
             nr = args.cpu_reads or max(2, min(reads_per_batch, 4 * cores))   # ~10-20 s of CPU work, all usable cores busy
+            note(f"cpu_baseline: oracle on {nr} reads, {cores} threads")
             try:
                 cpu = cpu_baseline(batches[0][2], batches[0][1], nr, cores, max(1, min(8, nr)))
             except Exception as e:   # the oracle is test infrastructure: its absence must not cost the GPU line
@@ -608,7 +678,9 @@ def main():
                 "workload": "BASELINE configs[2]: synthetic Gaussian int16 reads x 4096 samples (round(N(500,80))), "
                             "MAD-normalised, chunk=1024 step=512 -> 8 windows/read; step = 512 windows (64 reads): "
                             "TCN forward fp32 + chunk-mode CTC beam search W=10 over every window (LM unused in chunk "
-                            "mode, reference basecall.py:110-121) + labels to host; random He-normal weights seed 1234",
+                            "mode, reference basecall.py:110-121) + labels to host; random He-normal weights seed 1234 -- whose "
+                            "softmax rows are SATURATED (~5 bases per 1024-row window: the beam search's easy case); "
+                            "secondary_soft_head / secondary_e2e_raw_soft_head run the same job on soft rows (~200 bases per window)",
                 "preheat_ms": args.preheat_ms,
                 "timed_region": "starts with MAD-normalised float32 reads resident in HBM; ends with every window's labels on the host. "
                                 "Excludes H2D of the raw signal, mad_normalise and the host string stitch -- those are inside "

@@ -100,6 +100,13 @@ int rd_set_logits(rd_ctx* ctx, int mode);
  * per launch (default: several waves per sequence while the launch leaves SIMDs idle, else two candidates per lane),
  * 1 = always several waves per sequence, 2 = always two candidates per lane.  For tests and measurements. */
 int rd_set_decode_form(rd_ctx* ctx, int form);
+/* Decode partition of the global-mode reads pipeline (rd_pipe_submit_reads_global / rd_pipe_submit_raw_global; no effect on
+ * results, no reference counterpart): cus_per_xcd CUs of each of the 8 XCDs are kept free of forward workgroups (the
+ * pipeline's forward streams are CU-masked to the others) and run the beam search.  A read's search is one serial chain of
+ * a time step per sample; a beam-search wave that shares its SIMD with conv waves issuing MFMAs back to back gets about one
+ * instruction issue per MFMA (17 us per step measured instead of 2).  -1 (default) = by beam width (3 / 5 / 8 CUs per XCD
+ * for W <= 12 / 25 / 51: 9 to 25 % of the chip), 0 = off (groups then grow until their forward rows cover the slow chain). */
+int rd_set_decode_partition(rd_ctx* ctx, int cus_per_xcd);
 /* Arithmetic of the beam search's log / logaddexp (decode.py:16-17,172-201 call math.log and np.logaddexp, i.e. the host's
  * libm): 1 (default) = the operation sequence of glibc 2.35's x86-64 FMA build (exp, log, log1p restated in
  * csrc/glibc_math.h): scores and labelings bit-identical to the reference's on such a host, including labelings that are

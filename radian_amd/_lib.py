@@ -33,6 +33,7 @@ SIGNATURES = {
     "rd_set_logits": (c_i, [c_vp, c_i]),
     "rd_set_decode_form": (c_i, [c_vp, c_i]),
     "rd_set_decode_math": (c_i, [c_vp, c_i]),
+    "rd_set_decode_partition": (c_i, [c_vp, c_i]),
     "rd_forward": (c_i, [c_vp, c_vp, c_i, c_i, c_vp]),
     "rd_assemble": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_i64, c_i64p, ctypes.POINTER(c_i)]),
     "rd_decode_batch": (c_i, [c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp, c_vp]),

@@ -140,6 +140,11 @@ class Backend:
         """'auto' (default), 'waves' or 'lanes': launch shape of the beam search for widths above 12 (rd_set_decode_form)."""
         self._check(self._L.rd_set_decode_form(self._h, {"auto": 0, "waves": 1, "lanes": 2}[form] if isinstance(form, str) else int(form)))
 
+    def set_decode_partition(self, cus_per_xcd):
+        """CUs per XCD reserved for the beam search of the global-mode reads pipeline (rd_set_decode_partition): -1 = by beam
+        width (default), 0 = off."""
+        self._check(self._L.rd_set_decode_partition(self._h, int(cus_per_xcd)))
+
     def set_decode_math(self, mode):
         """'glibc' (default: scores bit-identical to the reference's) or 'fast': arithmetic of the beam search's log / logaddexp
         (rd_set_decode_math)."""

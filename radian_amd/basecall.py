@@ -63,6 +63,9 @@ def build_parser():
                              "to the reference's on an x86-64 FMA host, including exactly tied labelings) or this library's faster routines "
                              "(within an ulp of libm's: labelings identical unless two labelings tie within a few ulp; 10-35 %% faster beam "
                              "search)")
+    parser.add_argument("--decode-partition", default=-1, type=int,
+                        help="global mode, pipelined: CUs of each XCD kept free of forward workgroups for the beam search (a read's "
+                             "search is one serial chain; beside conv waves a step runs ~8x slower).  -1: by beam width (3 / 5 / 8), 0: off")
     parser.add_argument("--lm-hashed-context", action="store_true",
                         help="global mode: accept a --context-len longer than the RNA model's k-mers (up to 256) by addressing the model's "
                              "table with a hash of the context (a synthetic long-context LM: no reference behaviour -- the reference raises "
@@ -309,7 +312,9 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
         k = n_submitted % len(backends)
         n_submitted += 1
         in_flight.append((dev_pools[k].submit(on_device, backends[k], batch), batch, batch_idx, k))
-        retire(len(backends) * (8 if pipelined else 1))
+        # pipelined: enough batches in flight that a global-mode group can gather the rows that cover its longest read's
+        # chain (the host side of a batch is a few MB)
+        retire(len(backends) * ((24 if args.decode_type == "global" else 8) if pipelined else 1))
         batch, batch_idx, n_win = [], [], 0
 
     def drain():
@@ -377,6 +382,8 @@ def apply_artifacts(args, be, art, clone_from=None):
     be.set_precision(getattr(args, "precision", "fp32"))
     be.set_logits(getattr(args, "logits", "f32"))
     be.set_decode_math(getattr(args, "decode_math", "glibc"))
+    if hasattr(be, "set_decode_partition"):
+        be.set_decode_partition(getattr(args, "decode_partition", -1))
     if clone_from is not None:
         be.clone_artifacts_from(clone_from)
         return

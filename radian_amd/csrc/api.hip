@@ -12,6 +12,8 @@
 #include <rccl/rccl.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <time.h>
+#include <stdlib.h>
 #include <string.h>
 
 using namespace rdi;
@@ -148,11 +150,12 @@ extern "C" int rd_destroy(rd_ctx* ctx)
     timer_free(ctx->timer_decode);
     timer_free(ctx->timer_head);
     timer_free(ctx->timer_in);
-    for (int i = 0; i < RD_MAX_LANES; i++) {
+    for (int i = 0; i < 2 * RD_MAX_LANES; i++) {
         FwdLane& L = ctx->lanes[i];
         if (i > 0 && L.st) {
             (void)hipStreamSynchronize(L.st);
-            (void)hipStreamDestroy(L.st);
+            if (i >= RD_MAX_LANES) rd_masked_stream_release(L.st);   // CU-masked streams are pooled, never destroyed (forward.hip)
+            else (void)hipStreamDestroy(L.st);
         }
         if (L.done) (void)hipEventDestroy(L.done);
         for (DevBuf& b : L.act) b.release();
@@ -542,6 +545,15 @@ extern "C" int rd_set_decode_form(rd_ctx* ctx, int form)
     RD_REQUIRE(ctx, "rd_set_decode_form: null context");
     RD_REQUIRE(form >= 0 && form <= 2, "rd_set_decode_form: form %d (0 = per launch, 1 = waves per sequence, 2 = candidates per lane)", form);
     ctx->decode_form = form;
+    return RD_OK;
+}
+
+extern "C" int rd_set_decode_partition(rd_ctx* ctx, int cus_per_xcd)
+{
+    RD_REQUIRE(ctx, "rd_set_decode_partition: null context");
+    RD_REQUIRE(cus_per_xcd >= -1 && cus_per_xcd <= 16, "rd_set_decode_partition: %d CUs per XCD (-1 = by beam width, 0 = off, 1..16)", cus_per_xcd);
+    RD_REQUIRE(rd_rpipe_idle(ctx), "rd_set_decode_partition: pipeline not empty (call rd_pipe_flush first)");
+    ctx->part_mode = cus_per_xcd;
     return RD_OK;
 }
 

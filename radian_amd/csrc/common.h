@@ -149,7 +149,14 @@ struct rd_ctx {
     // workspaces
     DevBuf ws_tiles, ws_raw;
     int tiles_nW = -1, tiles_T = -1;   // shape the cached uniform tile descriptors were built for
-    FwdLane lanes[RD_MAX_LANES];   // lanes[0].st == stream; lanes >= 1 are created on first use
+    // lanes[0].st == stream; lanes >= 1 are created on first use.  Lanes [RD_MAX_LANES, 2 RD_MAX_LANES) are the PARTITIONED
+    // twins of lanes [0, RD_MAX_LANES): their streams are CU-masked to everything but the decode partition (below)
+    FwdLane lanes[2 * RD_MAX_LANES];
+    // Decode partition (global-mode reads pipeline): part_cus CUs of every XCD are kept free of forward workgroups and run
+    // the beam search.  A beam-search wave that shares a SIMD with conv waves issuing MFMAs back to back gets about one
+    // instruction issue per MFMA (measured: 17 us per time step instead of 2), and a read's search is one serial chain.
+    int part_mode = -1;   // rd_set_decode_partition: -1 = chosen by beam width, 0 = off, k = k CUs per XCD
+    int part_cus = 0;     // CUs per XCD the existing masked streams were created for (0: none exist)
     DevBuf ws_in, ws_probs, ws_mat, ws_seq, ws_nodes_child, ws_nodes_back, ws_labels, ws_misc;
     // pinned host staging
     void* h_stage = nullptr;
@@ -168,6 +175,11 @@ int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_
 int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tiles, int64_t total_rows, void* d_probs, int lane = 0,
                          int probs_f16 = 0 /* 1: d_probs is _Float16 [rows][5] */);
 int rd_lane_get(rd_ctx* ctx, int lane, FwdLane** out);   // creates the lane's stream on first use
+constexpr int RD_XCDS = 8;                               // MI355X: 8 XCDs x 32 CUs; CU-mask bit i = CU i / 8 of XCD i % 8
+int rd_part_set(rd_ctx* ctx, int cus_per_xcd);           // (re)size the decode partition: drops the masked lane streams of another size
+// pooled CU-masked streams: on the first k CUs of every XCD (complement = false) or on all the others
+int rd_masked_stream_acquire(int device, int cus_per_xcd, bool complement, hipStream_t* out);
+void rd_masked_stream_release(hipStream_t st);   // waits for the stream, then hands it back (never destroyed)
 int rd_sync_lanes(rd_ctx* ctx);                          // every forward stream idle
 int rd_split3_dev(rd_ctx* ctx, const float* d_in, size_t n, uint16_t* d_out);   // fp32 -> [3][n] bf16 bit patterns (hi, mid, lo)
 int rd_model_halo(const rd_ctx* ctx);  // receptive field - 1 = (K-1) * 2 * sum(dilations)
@@ -176,7 +188,7 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype /* 0 f32, 1 f64, 2
                   const int64_t* d_node_off, const int64_t* d_label_off, int n_seq, int64_t total_nodes, int W, int use_lm,
                   double s_thr, double r_thr, uint8_t* d_labels, int32_t* d_label_len, double* d_best_score,
                   hipStream_t stream = nullptr /* default: ctx->stream */, const int64_t* d_seq_off2 = nullptr,
-                  const int32_t* d_seq_split = nullptr);
+                  const int32_t* d_seq_split = nullptr, int n_cu_avail = 0 /* CUs the stream may use (0: all) */);
 // preprocess.hip
 int rd_normalise_dev(rd_ctx* ctx, const int16_t* d_raw, const int64_t* d_read_off, int n_reads, int clip, float* d_out,
                      int32_t* d_status, hipStream_t stream = nullptr /* default: ctx->stream */);

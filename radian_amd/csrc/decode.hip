@@ -840,8 +840,9 @@ static int ensure_lm_gate(rd_ctx* ctx, double r_thr, hipStream_t st)
 int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_seq_off, const int32_t* d_seq_len,
                   const int64_t* d_node_off, const int64_t* d_label_off, int n_seq, int64_t total_nodes, int W, int use_lm,
                   double s_thr, double r_thr, uint8_t* d_labels, int32_t* d_label_len, double* d_best_score, hipStream_t stream,
-                  const int64_t* d_seq_off2, const int32_t* d_seq_split)
+                  const int64_t* d_seq_off2, const int32_t* d_seq_split, int n_cu_avail)
 {
+    const int n_simd = 4 * (n_cu_avail > 0 ? n_cu_avail : ctx->n_cu);
     hipStream_t st = stream ? stream : ctx->stream;
     RD_REQUIRE(W >= 1 && W <= kMaxW, "beam_width %d out of range [1,%d]", W, kMaxW);
     if (n_seq == 0) return RD_OK;
@@ -880,8 +881,8 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_
     a.best_score = d_best_score;
     KernelTimer& tm = ctx->timer_decode;
     if (tm.enabled && tm.used < tm.starts.size()) RD_HIP(hipEventRecord(tm.starts[tm.used], st));
-    int rc = ptype == 1 ? launch_pt<double>(st, a, n_seq, use_lm != 0, 4 * ctx->n_cu, ctx->decode_form)
-             : ptype == 2 ? launch_pt<_Float16>(st, a, n_seq, use_lm != 0, 4 * ctx->n_cu, ctx->decode_form) : launch_pt<float>(st, a, n_seq, use_lm != 0, 4 * ctx->n_cu, ctx->decode_form);
+    int rc = ptype == 1 ? launch_pt<double>(st, a, n_seq, use_lm != 0, n_simd, ctx->decode_form)
+             : ptype == 2 ? launch_pt<_Float16>(st, a, n_seq, use_lm != 0, n_simd, ctx->decode_form) : launch_pt<float>(st, a, n_seq, use_lm != 0, n_simd, ctx->decode_form);
     if (rc) return rc;
     if (tm.enabled && tm.used < tm.starts.size()) {
         RD_HIP(hipEventRecord(tm.stops[tm.used], st));

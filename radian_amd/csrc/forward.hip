@@ -28,6 +28,8 @@
 // into the epilogue.  The head reuses the same core with N = 128, then reduces 128 -> 5 and applies softmax from LDS.
 #include "common.h"
 
+#include <mutex>
+
 #include <stdint.h>
 #include <type_traits>
 
@@ -1440,26 +1442,93 @@ int rd_split3_dev(rd_ctx* ctx, const float* d_in, size_t n, uint16_t* d_out)
     return RD_OK;
 }
 
+// CU-mask bit i of a gfx950 device = CU i / 8 of XCD i % 8 (tools/probe/cumask_probe.hip): the first 8 k bits are k CUs of
+// every XCD.  (A mask that leaves an XCD without any CU enables that whole XCD: k stays within [1, 31].)
+// CU-masked streams are POOLED per process and never destroyed: on ROCm 7.2 hipStreamDestroy of a CU-masked stream can leave
+// the runtime hanging in the next call that waits for the device (hipFree / hipStreamDestroy of another stream; seen after
+// a run of a few hundred launches on the masked streams, tools/repro_refdefaults.py).  A context takes streams out of the
+// pool and hands them back, idle, when it is destroyed or resizes its partition.
+namespace {
+struct MaskedStream {
+    int device, cus;
+    bool complement, in_use;
+    hipStream_t st;
+};
+std::vector<MaskedStream> g_masked;
+std::mutex g_masked_mu;
+}  // namespace
+
+int rd_masked_stream_acquire(int device, int cus_per_xcd, bool complement, hipStream_t* out)
+{
+    std::lock_guard<std::mutex> lk(g_masked_mu);
+    for (MaskedStream& m : g_masked)
+        if (!m.in_use && m.device == device && m.cus == cus_per_xcd && m.complement == complement) {
+            m.in_use = true;
+            *out = m.st;
+            return RD_OK;
+        }
+    uint32_t mask[RD_XCDS] = {0};
+    const int nbits = RD_XCDS * 32, k = RD_XCDS * cus_per_xcd;
+    for (int i = 0; i < nbits; i++)
+        if ((i < k) != complement) mask[i / 32] |= 1u << (i % 32);
+    hipStream_t st = nullptr;
+    RD_HIP(hipExtStreamCreateWithCUMask(&st, RD_XCDS, mask));
+    g_masked.push_back({device, cus_per_xcd, complement, true, st});
+    *out = st;
+    return RD_OK;
+}
+
+void rd_masked_stream_release(hipStream_t st)
+{
+    if (!st) return;
+    (void)hipStreamSynchronize(st);
+    std::lock_guard<std::mutex> lk(g_masked_mu);
+    for (MaskedStream& m : g_masked)
+        if (m.st == st) m.in_use = false;
+}
+
 int rd_lane_get(rd_ctx* ctx, int lane, FwdLane** out)
 {
-    if (lane < 0 || lane >= RD_MAX_LANES) {
+    if (lane < 0 || lane >= 2 * RD_MAX_LANES) {
         rd_set_error("forward lane %d out of range", lane);
         return RD_ERR_ARG;
     }
     FwdLane& L = ctx->lanes[lane];
     if (!L.st) {
         if (lane == 0) L.st = ctx->stream;
-        else RD_HIP(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
+        else if (lane < RD_MAX_LANES) RD_HIP(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
+        else {
+            if (ctx->part_cus < 1 || ctx->part_cus > 31) {
+                rd_set_error("internal: partitioned lane %d without a decode partition", lane);
+                return RD_ERR_STATE;
+            }
+            int rc = rd_masked_stream_acquire(ctx->device, ctx->part_cus, true, &L.st);
+            if (rc) return rc;
+        }
     }
     if (!L.done) RD_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
     *out = &L;
     return RD_OK;
 }
 
+int rd_part_set(rd_ctx* ctx, int cus_per_xcd)
+{
+    if (ctx->part_cus == cus_per_xcd) return RD_OK;
+    for (int i = RD_MAX_LANES; i < 2 * RD_MAX_LANES; i++) {   // streams masked for another partition size (the caller has flushed)
+        FwdLane& L = ctx->lanes[i];
+        if (L.st) {
+            rd_masked_stream_release(L.st);   // (idle first; back to the process's pool)
+            L.st = nullptr;
+        }
+    }
+    ctx->part_cus = cus_per_xcd;
+    return RD_OK;
+}
+
 int rd_sync_lanes(rd_ctx* ctx)
 {
     RD_HIP(hipStreamSynchronize(ctx->stream));
-    for (int i = 1; i < RD_MAX_LANES; i++)
+    for (int i = 1; i < 2 * RD_MAX_LANES; i++)
         if (ctx->lanes[i].st) RD_HIP(hipStreamSynchronize(ctx->lanes[i].st));
     return RD_OK;
 }

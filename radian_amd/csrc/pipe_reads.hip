@@ -17,6 +17,9 @@
 #include "plan.h"
 #include "../../include/radian_hip.h"
 
+#include <stdio.h>
+#include <time.h>
+#include <stdlib.h>
 #include <string.h>
 
 using namespace rdi;
@@ -25,7 +28,31 @@ namespace {
 
 // forward rows a group must hold per beam-search step of its longest read before it may close early (global mode):
 // forward ~29 M rows/s = 34 ns per row; a step costs 1.6-2.0 us (W <= 12), 2.7-3.1 us (W <= 25), 4-6 us beyond
-inline int64_t chain_rows(int W) { return W <= 12 ? 96 : W <= 25 ? 140 : 260; }
+// Two regimes for the beam search of a global-mode group (a read's search is one serial chain of a step per sample):
+//  * FEW sequences (at most three waves per SIMD of the decode partition -- what its LDS keeps resident): on the partition's CUs, which the pipeline's
+//    forwards keep clear, a step costs 1.6-2.0 us (W <= 12), 2.7-3.1 us (W <= 25), 4-6 us beyond -- the group is worth
+//    closing as soon as its forward rows (34 ns each) cover the longest chain at that pace;
+//  * MANY sequences: the partition's few SIMDs would be the bottleneck (a saturated SIMD does ~0.15-0.45 M steps/s), so the
+//    search runs on the whole chip beside the next group's conv waves, where a wave gets about one instruction issue per
+//    MFMA -- 17 us per step measured at W = 10 (profiles/r03a_global_pipe_trace.txt) -- but hundreds of them run at once:
+//    the group keeps growing until its forward rows cover the longest chain at THAT pace.
+inline int64_t chain_rows(int W, bool on_partition)
+{
+    static const long env = getenv("RD_CHAIN_ROWS") ? atol(getenv("RD_CHAIN_ROWS")) : 0;   // (measurements only)
+    if (env > 0) return env;
+    if (!on_partition) return W <= 12 ? 560 : W <= 25 ? 900 : 1500;
+    return W <= 12 ? 96 : W <= 25 ? 140 : 260;
+}
+// sequences the partition decodes at chain pace: three waves per SIMD (a sequence is 1 / 2 / 4 waves for W <= 12 / 25 / 51;
+// ~12 KiB of LDS per sequence keeps 13 resident per CU).  Measured at W = 10 on 64 SIMDs: 128 / 256 sequences 28.2 / 27.8 M
+// samples/s, 512 sequences 22.1 M (tools/global_pipe_bench.py)
+inline int part_seq_limit(int part_cus, int W) { return RD_XCDS * part_cus * 4 * 3 / (W <= 12 ? 1 : W <= 25 ? 2 : 4); }
+constexpr int64_t kGroupRowsCap = 96ll << 20;   // rows a group may gather while it waits for coverage (~6 GB of probabilities + matrix)
+// CUs per XCD of the decode partition for a beam width (rd_set_decode_partition -1): enough SIMDs that the partition's
+// beam-search rate stays above the forward's ~29 M rows/s when a group holds many short reads (a saturated SIMD steps
+// ~0.45 M sequences-steps/s at W = 10: 16 CUs = 64 SIMDs would just match the forward; measured throughput is flat from
+// 1 to 4 CUs per XCD -- 27.7 / 28.2 / 28.2 M samples/s -- because the conv launches' tile rounds quantise either way)
+inline int auto_part_cus(int W) { return W <= 12 ? 3 : W <= 25 ? 5 : 8; }
 
 struct RSub {                 // one submitted batch inside a group
     int n_seq = 0, seq0 = 0;  // its decoded sequences (global: reads; chunk: windows) = [seq0, seq0 + n_seq) of the group
@@ -52,6 +79,8 @@ struct RSlot {                // a group
     hipEvent_t dec_done = nullptr;
     bool busy = false;        // beam search launched, results not yet delivered
     int64_t launch_seq = 0;   // order of the launches on the decode stream
+    hipStream_t dec_stream = nullptr;   // where this group's beam search runs / ran
+    int part = 0;             // CUs per XCD of the decode partition the group's forwards kept clear (0: none)
     // what makes a group homogeneous
     int mode = -1, W = 0, f16 = 0, use_lm = 0;
     double s_thr = 0.0, r_thr = 0.0;
@@ -87,11 +116,15 @@ struct RLane {                // per forward lane: staging + descriptors of the 
 
 struct ReadsPipe {
     hipStream_t s_dec = nullptr;
+    hipStream_t s_part = nullptr;   // the decode partition's stream (global mode), masked to part_cus CUs of every XCD
+    int part_cus = 0;
     RSlot slot[2];
     RLane lane[RD_MAX_LANES];
     int cur = 0;
     int next_lane = 0;
     int64_t submitted = 0, delivered = 0, launches = 0;
+    hipStream_t last_dec = nullptr;   // stream of the latest beam-search launch
+    hipEvent_t ev_switch = nullptr;
 };
 
 void slot_reset(RSlot& s)
@@ -114,6 +147,7 @@ int rpipe_get(rd_ctx* ctx, ReadsPipe** out)
         RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         RD_HIP(hipStreamCreateWithPriority(&p->s_dec, hipStreamNonBlocking, hi));
         for (int i = 0; i < 2; i++) RD_HIP(hipEventCreateWithFlags(&p->slot[i].dec_done, hipEventDisableTiming));
+        RD_HIP(hipEventCreateWithFlags(&p->ev_switch, hipEventDisableTiming));
     }
     *out = (ReadsPipe*)ctx->rpipe;
     return RD_OK;
@@ -192,9 +226,20 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
     s.status_off = ho_len + align_up(n * 4, 256);
     if ((rc = pinned_reserve(&s.h_out, &s.h_out_cap, s.status_off + (size_t)s.n_reads * 4 + 16))) return rc;
     if ((rc = rd_pipe_drain_decode_internal(ctx))) return rc;   // (beam searches of the chunk pipeline use the same trie workspace)
-    for (int l = 0; l < RD_MAX_LANES; l++)   // every forward / assembly that wrote into this group has finished
-        if (s.lane_mask & (1u << l)) RD_HIP(hipStreamWaitEvent(p->s_dec, ctx->lanes[l].done, 0));
-    RD_HIP(hipMemcpyAsync(s.meta.p, s.h_meta, o_llen, hipMemcpyHostToDevice, p->s_dec));
+    // the group's beam search runs on the decode partition when its forwards kept one clear and its sequences are few
+    // enough to run there at chain pace, else on the whole chip; the two streams share the trie workspace, so a launch on
+    // one waits for the other's latest
+    const bool on_part = s.part && (int)n <= part_seq_limit(s.part, s.W);
+    hipStream_t ds = on_part ? p->s_part : p->s_dec;
+    if (p->last_dec && p->last_dec != ds) {
+        RD_HIP(hipEventRecord(p->ev_switch, p->last_dec));
+        RD_HIP(hipStreamWaitEvent(ds, p->ev_switch, 0));
+    }
+    p->last_dec = ds;
+    s.dec_stream = ds;
+    for (int l = 0; l < 2 * RD_MAX_LANES; l++)   // every forward / assembly that wrote into this group has finished
+        if (s.lane_mask & (1u << l)) RD_HIP(hipStreamWaitEvent(ds, ctx->lanes[l].done, 0));
+    RD_HIP(hipMemcpyAsync(s.meta.p, s.h_meta, o_llen, hipMemcpyHostToDevice, ds));
     char* dm = (char*)s.meta.p;
     for (int pass = 0; pass < 2; pass++) {
         const int k0 = pass == 0 ? 0 : s.n64, k1 = pass == 0 ? s.n64 : (int)n;
@@ -204,15 +249,15 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
         const int ptype = pass == 0 ? 1 : (s.f16 ? 2 : 0);
         rc = rd_decode_dev(ctx, src, ptype, (const int64_t*)dm + k0, (const int32_t*)(dm + o_len) + k0, (const int64_t*)(dm + o_node) + k0,
                            (const int64_t*)(dm + o_lab) + k0, k1 - k0, nodes[pass], s.W, s.use_lm, s.s_thr, s.r_thr, s.labels.as<uint8_t>(),
-                           (int32_t*)(dm + o_llen) + k0, nullptr, p->s_dec, chunk ? (const int64_t*)(dm + o_off2) + k0 : nullptr,
-                           chunk ? (const int32_t*)(dm + o_split) + k0 : nullptr);
+                           (int32_t*)(dm + o_llen) + k0, nullptr, ds, chunk ? (const int64_t*)(dm + o_off2) + k0 : nullptr,
+                           chunk ? (const int32_t*)(dm + o_split) + k0 : nullptr, on_part ? RD_XCDS * s.part : 0);
         if (rc) return rc;
     }
-    RD_HIP(hipMemcpyAsync(s.h_out, s.labels.p, (size_t)s.labels_total, hipMemcpyDeviceToHost, p->s_dec));
-    RD_HIP(hipMemcpyAsync((char*)s.h_out + ho_len, dm + o_llen, n * 4, hipMemcpyDeviceToHost, p->s_dec));
+    RD_HIP(hipMemcpyAsync(s.h_out, s.labels.p, (size_t)s.labels_total, hipMemcpyDeviceToHost, ds));
+    RD_HIP(hipMemcpyAsync((char*)s.h_out + ho_len, dm + o_llen, n * 4, hipMemcpyDeviceToHost, ds));
     if (s.n_reads && s.status.p)
-        RD_HIP(hipMemcpyAsync((char*)s.h_out + s.status_off, s.status.p, (size_t)s.n_reads * 4, hipMemcpyDeviceToHost, p->s_dec));
-    RD_HIP(hipEventRecord(s.dec_done, p->s_dec));
+        RD_HIP(hipMemcpyAsync((char*)s.h_out + s.status_off, s.status.p, (size_t)s.n_reads * 4, hipMemcpyDeviceToHost, ds));
+    RD_HIP(hipEventRecord(s.dec_done, ds));
     s.busy = true;
     s.launch_seq = ++p->launches;
     return RD_OK;
@@ -227,11 +272,11 @@ int close_group(rd_ctx* ctx, ReadsPipe* p)
 }
 
 // a group that can take `rows` more probability rows with these decode parameters; closes / recycles groups as needed
-int open_slot(rd_ctx* ctx, ReadsPipe* p, int mode, int W, int f16, int use_lm, double s_thr, double r_thr, int64_t rows, RSlot** out)
+int open_slot(rd_ctx* ctx, ReadsPipe* p, int mode, int W, int f16, int use_lm, double s_thr, double r_thr, int part, int64_t rows, RSlot** out)
 {
     int rc;
     RSlot* s = &p->slot[p->cur];
-    const bool same = s->mode == mode && s->W == W && s->f16 == f16 && s->use_lm == use_lm && s->s_thr == s_thr && s->r_thr == r_thr;
+    const bool same = s->mode == mode && s->W == W && s->f16 == f16 && s->use_lm == use_lm && s->s_thr == s_thr && s->r_thr == r_thr && s->part == part;
     if (!s->seqs.empty() && (!same || s->rows + rows > s->cap_rows)) {
         if (same) s->grow_hint = 2 * (s->rows + rows);   // closed for lack of room: the slot grows when it is empty again
         if ((rc = close_group(ctx, p))) return rc;
@@ -248,6 +293,7 @@ int open_slot(rd_ctx* ctx, ReadsPipe* p, int mode, int W, int f16, int use_lm, d
         }
     }
     s->mode = mode;
+    s->part = part;
     s->W = W;
     s->f16 = f16;
     s->use_lm = use_lm;
@@ -343,9 +389,24 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
     ReadsPipe* p = nullptr;
     if ((rc = rpipe_get(ctx, &p))) return rc;
     const int n_lanes = ctx->pipe_lanes < 1 ? 1 : ctx->pipe_lanes;
+    // global mode: the forwards of this pipeline keep `part` CUs of every XCD clear and the beam search runs there
+    const int part = mode == 1 ? (ctx->part_mode < 0 ? auto_part_cus(W) : ctx->part_mode) : 0;
+    if (part && part != p->part_cus) {
+        // another partition size (first use, or the beam width's class changed): drain, then new masked streams
+        if ((rc = rd_rpipe_flush(ctx))) return rc;
+        if (p->s_part) {
+            rd_masked_stream_release(p->s_part);
+            p->s_part = nullptr;
+            if (p->last_dec != p->s_dec) p->last_dec = nullptr;
+        }
+        if ((rc = rd_part_set(ctx, part))) return rc;
+        if ((rc = rd_masked_stream_acquire(ctx->device, part, false, &p->s_part))) return rc;
+        p->part_cus = part;
+    }
     const int lane = p->next_lane % n_lanes;
+    const int plane = lane + (part ? RD_MAX_LANES : 0);   // the lane's partitioned twin: same staging, masked stream, own activations
     FwdLane* L = nullptr;
-    if ((rc = rd_lane_get(ctx, lane, &L))) return rc;
+    if ((rc = rd_lane_get(ctx, plane, &L))) return rc;
     RLane& R = p->lane[lane];
     const size_t n_samples = (size_t)read_off[n_reads];
     const int f16 = ctx->logits_f16;
@@ -390,7 +451,7 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
 
     // ---- the group this batch joins (may close / deliver earlier groups)
     RSlot* s = nullptr;
-    if ((rc = open_slot(ctx, p, mode, W, f16, use_lm, s_thr, r_thr, P.total_rows, &s))) return rc;
+    if ((rc = open_slot(ctx, p, mode, W, f16, use_lm, s_thr, r_thr, part, P.total_rows, &s))) return rc;
 
     // ---- its sequences (and, in global mode, the per-read assembly records), not yet part of the group
     RSub sb;
@@ -455,7 +516,7 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
         DevBuf nb;
         if (nb.reserve((size_t)(s->n_reads + n_reads) * 8 + 4096)) return RD_ERR_NOMEM;
         if (s->n_reads && s->status.p) {
-            for (int l = 0; l < RD_MAX_LANES; l++)
+            for (int l = 0; l < 2 * RD_MAX_LANES; l++)
                 if (s->lane_mask & (1u << l)) RD_HIP(hipStreamSynchronize(ctx->lanes[l].st));
             RD_HIP(hipMemcpy(nb.p, s->status.p, (size_t)s->n_reads * 4, hipMemcpyDeviceToDevice));
         }
@@ -485,7 +546,7 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
     RD_HIP(hipEventRecord(R.staged, L->st));   // the staging block is free once these copies are done
     R.staged_pending = true;
     const size_t rb = f16 ? 10 : 20;
-    if ((rc = rd_forward_tiles_dev(ctx, sig, R.lists, P.total_rows, (char*)s->probs.p + (size_t)s->rows * rb, lane, f16))) return rc;
+    if ((rc = rd_forward_tiles_dev(ctx, sig, R.lists, P.total_rows, (char*)s->probs.p + (size_t)s->rows * rb, plane, f16))) return rc;
     if (n64 && (rc = rd_assemble_batch_dev(L->st, s->probs.p, d_ar, n64, max_n, chunk_len, step, s->mat.as<double>(), R.streamed ? 1 : 0, f16)))
         return rc;
     if (raw)
@@ -496,16 +557,22 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
     s->seqs.insert(s->seqs.end(), seqs.begin(), seqs.end());
     s->rows64 = rows64;
     s->labels_total = labels_total;
-    s->lane_mask |= 1u << lane;
+    s->lane_mask |= 1u << plane;
     s->n_reads += n_reads;
     s->rows += P.total_rows;
     if (longest > s->longest) s->longest = longest;
     s->subs.push_back(std::move(sb));
     p->next_lane = (lane + 1) % n_lanes;
     p->submitted++;
-    const bool full = (int)s->subs.size() >= ctx->pipe_group;
-    const bool covered = mode == 1 && s->rows >= chain_rows(W) * s->longest;
-    if (full || covered) return close_group(ctx, p);
+    bool close;
+    if (mode == 1) {
+        // global mode: by coverage of the longest read's chain (see chain_rows), not by a batch count
+        const bool few = part && (int)s->seqs.size() <= part_seq_limit(part, W);
+        close = s->rows >= chain_rows(W, few) * s->longest || s->rows >= kGroupRowsCap;
+    } else {
+        close = (int)s->subs.size() >= ctx->pipe_group;
+    }
+    if (close) return close_group(ctx, p);
     return RD_OK;
 }
 
@@ -521,7 +588,10 @@ bool rd_rpipe_idle(const rd_ctx* ctx)
 int rd_rpipe_drain_decode(rd_ctx* ctx)
 {
     ReadsPipe* p = (ReadsPipe*)ctx->rpipe;
-    if (p && p->s_dec && (p->slot[0].busy || p->slot[1].busy)) RD_HIP(hipStreamSynchronize(p->s_dec));
+    if (p && (p->slot[0].busy || p->slot[1].busy)) {
+        if (p->s_dec) RD_HIP(hipStreamSynchronize(p->s_dec));
+        if (p->s_part) RD_HIP(hipStreamSynchronize(p->s_part));
+    }
     return RD_OK;
 }
 
@@ -541,7 +611,10 @@ void rd_rpipe_destroy(rd_ctx* ctx)
 {
     ReadsPipe* p = (ReadsPipe*)ctx->rpipe;
     if (!p) return;
+    (void)rd_sync_lanes(ctx);
     if (p->s_dec) (void)hipStreamSynchronize(p->s_dec);
+    rd_masked_stream_release(p->s_part);   // (CU-masked streams are pooled, never destroyed: forward.hip)
+    if (p->ev_switch) (void)hipEventDestroy(p->ev_switch);
     for (int i = 0; i < 2; i++) {
         RSlot& s = p->slot[i];
         s.probs.release();

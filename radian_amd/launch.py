@@ -283,6 +283,7 @@ def worker(scratch, argv):
         b.set_precision(args.precision)   # context state, not part of the broadcast images
         b.set_logits(args.logits)
         b.set_decode_math(args.decode_math)
+        b.set_decode_partition(args.decode_partition)
     args._lm_loaded = (args.rna_model != "None" and args.decode_type == "global" and os.path.exists(args.rna_model))
     with open(os.path.join(scratch, "files.json")) as f:
         sources = [fast5.Fast5Source(p) for p in json.load(f)]

@@ -1,0 +1,42 @@
+"""One-context pipelined global decode (rd_pipe_submit_reads_global) at the bench's 64-read steps: samples/s against the
+group size.  usage: python tools/global_pipe_bench.py [soft] [fast] [W] (RD_CHAIN_ROWS=<rows per chain step> overrides the early-close rule)"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import bench
+from radian_amd import Backend, synthetic, weights
+
+def main():
+    soft = "soft" in sys.argv
+    W = int([a for a in sys.argv[1:] if a.isdigit()][0]) if any(a.isdigit() for a in sys.argv[1:]) else 10
+    n, L = 64, 4096
+    be = Backend(0)
+    be.load_weights(bench.soft_head_weights() if soft else weights.synthetic_weights(seed=1234))
+    be.load_lm(np.random.default_rng(0).dirichlet([0.3] * 4, size=4 ** 11), 11)
+    if "fast" in sys.argv:
+        be.set_decode_math("fast")
+    for a in sys.argv[1:]:
+        if a.startswith("part"):
+            be.set_decode_partition(int(a[4:]))
+    bufs = []
+    for b in range(4):
+        norm = np.stack([synthetic.mad_normalise(r, 4) for r in synthetic.synthetic_reads(n, L, seed=1000 + b)]).astype(np.float32)
+        d = be.dev_alloc(norm.nbytes); be.h2d(d, norm); bufs.append(d)
+    off = np.arange(n + 1, dtype=np.int64) * L
+    lab_off = np.ascontiguousarray(off[:-1])
+    ring = [(np.zeros(n * L + 1, np.uint8), np.zeros(n, np.int32)) for _ in range(40)]
+    groups = [int(a[1:]) for a in sys.argv[1:] if a.startswith('g') and a[1:].isdigit()] or [1, 2, 3, 4, 6, 8, 16]
+    for group in groups:
+        be.pipe_flush(); be.pipe_config(group)
+        def run(k):
+            for i in range(k):
+                lab, ln = ring[i % len(ring)]
+                be.pipe_submit_reads_global(bufs[i % 4], off, n, 1024, 512, W, True, 0.5, 0.5, lab, lab_off, ln)
+                if i >= 32:
+                    be.pipe_progress(be.pipe_submitted() - 32)
+            be.pipe_flush(); be.sync()
+        run(8)
+        t0 = time.perf_counter(); run(64); dt = time.perf_counter() - t0
+        print(f"group {group:2d}: {64 * n * L / dt / 1e6:6.2f} M samples/s  ({dt / 64 * 1e3:.2f} ms per 64-read step)", flush=True)
+    be.close()
+main()
