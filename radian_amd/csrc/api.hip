@@ -584,6 +584,8 @@ int prepare_seq_meta(rd_ctx* ctx, const int64_t* seq_off, const int64_t* seq_off
     int64_t nodes = 0, labs = 0;
     for (int i = 0; i < n_seq; i++) {
         RD_REQUIRE(seq_len[i] >= 0, "decode: negative sequence length at %d", i);
+        RD_REQUIRE(rd_decode_len_ok(W, seq_len[i]), "decode: sequence %d has %d rows; beam width %d supports at most %lld (1 + W * rows < 2^29)", i,
+                   seq_len[i], W, (long long)((((int64_t)1 << 29) - 2) / W));
         node_off[i] = nodes;
         nodes += 1 + (int64_t)W * seq_len[i];
         lab_off[i] = labs;
@@ -729,6 +731,8 @@ extern "C" int rd_decode_batch(rd_ctx* ctx, const void* probs, int prob_is_f64, 
     int64_t rows = 0;
     for (int i = 0; i < n_seq; i++) {
         RD_REQUIRE(seq_len[i] >= 0 && seq_off[i] >= 0, "rd_decode_batch: bad sequence %d", i);
+        RD_REQUIRE(rd_decode_len_ok(beam_width, seq_len[i]), "rd_decode_batch: sequence %d has %d rows; beam width %d supports at most %lld (1 + W * rows < 2^29)",
+                   i, seq_len[i], beam_width, (long long)((((int64_t)1 << 29) - 2) / beam_width));
         if (seq_off[i] + seq_len[i] > rows) rows = seq_off[i] + seq_len[i];
     }
     RD_REQUIRE(rows == 0 || probs, "rd_decode_batch: null probs");
@@ -1136,6 +1140,7 @@ extern "C" int rd_pipe_submit(rd_ctx* ctx, const float* d_windows, int n_windows
     RD_REQUIRE(ctx && d_windows && valid_len && labels_out && label_len, "rd_pipe_submit: null argument");
     RD_REQUIRE(n_windows >= 1 && chunk_len >= 1, "rd_pipe_submit: bad shape");
     RD_REQUIRE(beam_width >= 1 && beam_width <= rd_decode_max_width(), "beam_width %d out of range", beam_width);
+    RD_REQUIRE(rd_decode_len_ok(beam_width, chunk_len), "rd_pipe_submit: chunk_len %d too long for beam width %d (1 + W * rows < 2^29)", chunk_len, beam_width);
     for (int i = 0; i < n_windows; i++)
         RD_REQUIRE(valid_len[i] >= 0 && valid_len[i] <= chunk_len, "valid_len[%d]=%d out of range", i, valid_len[i]);
     RD_HIP(hipSetDevice(ctx->device));
@@ -1483,6 +1488,7 @@ extern "C" int rd_pipe_submit_reads(rd_ctx* ctx, const float* d_signal, const in
     int rc = check_reads_args(ctx, d_signal, read_off, n_reads, chunk_len, step, beam_width);
     if (rc) return rc;
     RD_REQUIRE(labels_out && label_len, "rd_pipe_submit_reads: null output");
+    RD_REQUIRE(rd_decode_len_ok(beam_width, chunk_len), "rd_pipe_submit_reads: chunk_len %d too long for beam width %d (1 + W * rows < 2^29)", chunk_len, beam_width);
     RD_HIP(hipSetDevice(ctx->device));
     const ReadsPlan* P = nullptr;
     const TileLists* tl = nullptr;

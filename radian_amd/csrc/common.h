@@ -213,6 +213,11 @@ bool rd_rpipe_idle(const rd_ctx* ctx);
 int rd_rpipe_drain_decode(rd_ctx* ctx);   // wait for the pipeline's beam searches in flight (they share the trie workspace)
 void rd_rpipe_destroy(rd_ctx* ctx);
 
+// The beam search packs (parent node id << 2) | label into a 32-bit back-pointer and gives a sequence at most 1 + W * rows
+// trie nodes: a sequence must satisfy 1 + W * rows < 2^29 (W = 10: 53 M rows; W = 51: 10.5 M rows).  Host-side check of
+// every entry point that knows its sequence lengths (RD_ERR_ARG beyond, instead of a silently wrong traceback).
+inline bool rd_decode_len_ok(int W, int64_t rows) { return 1 + (int64_t)W * rows < ((int64_t)1 << 29); }
+
 extern "C" int rd_decode_max_width(void);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -340,24 +340,31 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
         if (NW == 1 || wv == 0) {
             const int t = t0 + lane;
             if (t < T) {
-                double p[5];
-#pragma unroll
-                for (int c = 0; c < 5; c++) p[c] = (double)probs[((t < split ? row_a : row_b) + t) * 5 + c];
-#pragma unroll
-                for (int c = 0; c < 5; c++) lp[lane][c] = safe_log<GX>(p[c]);
+                // (loops of one class each, NOT unrolled: one inlined copy of log per loop instead of nine -- the copies are
+                // what the compiler spills scalars around, and the prepass is 1/64 of the work)
+                const PT* __restrict__ prow = probs + ((t < split ? row_a : row_b) + t) * 5;
+                double s4 = 0.0;      // ((p0 + p1) + p2) + p3, the order normalise() adds in
+#pragma unroll 1
+                for (int c = 0; c < 5; c++) {
+                    const double pc = (double)prow[c];
+                    lp[lane][c] = safe_log<GX>(pc);
+                    if constexpr (LM) {
+                        praw[lane][c] = pc;
+                        if (c < 4) s4 = c == 0 ? pc : s4 + pc;
+                    }
+                }
                 if constexpr (LM) {
-#pragma unroll
-                    for (int c = 0; c < 5; c++) praw[lane][c] = p[c];
                     // normalise(): sum(dist) in float64 (numpy-1.19 semantics); float32 rows divide in float32
-                    double s = ((p[0] + p[1]) + p[2]) + p[3];
+                    const double s = s4;
                     double ent = 0.0;
                     bool any = false;
-#pragma unroll
+#pragma unroll 1
                     for (int c = 0; c < 4; c++) {
+                        const double pc = praw[lane][c];
                         double n;
-                        if (s == 0.0) n = p[c];
-                        else if constexpr (sizeof(PT) == 4) n = (double)((float)p[c] / (float)s);
-                        else n = p[c] / s;
+                        if (s == 0.0) n = pc;
+                        else if constexpr (sizeof(PT) == 4) n = (double)((float)pc / (float)s);
+                        else n = pc / s;
                         if (n > 0) {
                             double v = n * log_m<GX>(n);
                             ent = any ? ent + v : v;
@@ -748,19 +755,26 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
     }
 
     // ---------------- traceback of the best labeling (slot 0 = rank 0; decode.py:207-210) --------------------
-    if (tid == 0) {
+    int tid_end = tid;
+    asm volatile("" : "+v"(tid_end));   // (the lane mask of "tid == 0" is computed here, not carried in SGPRs from kernel entry)
+    if (tid_end == 0) {
         __builtin_amdgcn_s_waitcnt(0);
+        // The output pointers are only needed here.  Read through the kernarg segment behind an opaque copy of its address, they are
+        // loaded now instead of at kernel entry -- loaded there, the compiler parks them in spilled SGPRs for the whole time loop.
+        const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const DecodeArgs* ap = (const DecodeArgs*)ka;
         const Beam& fs = st[cur][0];
         int n = fs.node;
         const int len = fs.len;
-        uint8_t* out = a.labels + a.label_off[seq];
+        uint8_t* out = ap->labels + ap->label_off[seq];
         for (int p = len - 1; p >= 0; p--) {
             const int bp = __hip_atomic_load(&backptr[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out[p] = (uint8_t)(bp & 3);
             n = bp >> 2;
         }
-        a.label_len[seq] = len;
-        if (a.best_score) a.best_score[seq] = fs.ptot;
+        ap->label_len[seq] = len;
+        if (ap->best_score) ap->best_score[seq] = fs.ptot;
     }
 }
 

@@ -26,6 +26,29 @@
 #pragma clang fp contract(off)
 #endif
 
+// K(c): a polynomial / reduction constant materialised at its point of use (two s_mov_b32 into a scalar register pair) instead
+// of being hoisted to kernel scope.  Used in gm_log only: the beam search calls log once per probability in a per-tile
+// prepass (1/64 of the work), yet hoisted, its 20 constants hold 40 SGPRs through the whole time loop and the compiler spills
+// the loop's own scalars around them.  exp / log1p run twice per time step: their constants STAY hoisted -- materialised in
+// place they cost two scalar instructions each per use, +0.1 to +0.3 us on a 1.6-2.0 us step (measured).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <uint64_t BITS>
+__device__ __forceinline__ double gm_kbits()
+{
+    uint32_t lo, hi;   // (the asm statements have no inputs: nothing for the compiler to hoist; volatile: not hoisted themselves)
+    asm volatile("s_mov_b32 %0, %1" : "=s"(lo) : "n"((uint32_t)BITS));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "n"((uint32_t)(BITS >> 32)));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+#define gm_k(x) gm_kbits<__builtin_bit_cast(uint64_t, (double)(x))>()
+#define K(x) gm_k(x)
+#define GM_CONST constexpr
+#else
+#define gm_k(x) (x)
+#define K(x) (x)
+#define GM_CONST const
+#endif
+
 GM_FN double gm_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 GM_FN uint64_t gm_bits(double x)
 {
@@ -67,7 +90,7 @@ GM_FN double gm_exp_special(double tmp, uint64_t sbits, uint64_t ki)
 
 GM_FN double gm_exp(double x, const uint64_t* T)
 {
-    const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p52, NegLn2hiN = -0x1.62e42fefa0000p-8,
+    GM_CONST double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p52, NegLn2hiN = -0x1.62e42fefa0000p-8,
                  NegLn2loN = -0x1.cf79abc9e3b3ap-47, C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3,
                  C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
     const uint64_t ix = gm_bits(x);
@@ -108,10 +131,10 @@ GM_FN double gm_exp(double x, const uint64_t* T)
 // log x = k ln2 + logc + log1p(r).
 GM_FN double gm_log(double x, const uint64_t* TL)
 {
-    const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
-    const double A0 = -0x1.0000000000001p-1, A1 = 0x1.555555551305bp-2, A2 = -0x1.fffffffeb4590p-3, A3 = 0x1.999b324f10111p-3,
+    GM_CONST double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
+    GM_CONST double A0 = -0x1.0000000000001p-1, A1 = 0x1.555555551305bp-2, A2 = -0x1.fffffffeb4590p-3, A3 = 0x1.999b324f10111p-3,
                  A4 = -0x1.55575e506c89fp-3;
-    const double B0 = -0x1p-1, B1 = 0x1.5555555555577p-2, B2 = -0x1.ffffffffffdcbp-3, B3 = 0x1.999999995dd0cp-3,
+    GM_CONST double B0 = -0x1p-1, B1 = 0x1.5555555555577p-2, B2 = -0x1.ffffffffffdcbp-3, B3 = 0x1.999999995dd0cp-3,
                  B4 = -0x1.55555556745a7p-3, B5 = 0x1.24924a344de30p-3, B6 = -0x1.fffffa4423d65p-4, B7 = 0x1.c7184282ad6cap-4,
                  B8 = -0x1.999eb43b068ffp-4, B9 = 0x1.78182f7afd085p-4, B10 = -0x1.5521375d145cdp-4;
     uint64_t ix = gm_bits(x);
@@ -121,15 +144,15 @@ GM_FN double gm_log(double x, const uint64_t* TL)
         const double r = x - 1.0;
         const double r2 = r * r;
         const double r3 = r * r2;
-        const double q1 = gm_fma(r2, B3, gm_fma(B2, r, B1));     // B1 + r B2 + r2 B3
-        const double q4 = gm_fma(r2, B6, gm_fma(B5, r, B4));     // B4 + r B5 + r2 B6
-        double q7 = gm_fma(r2, B9, gm_fma(B8, r, B7));           // B7 + r B8 + r2 B9
-        q7 = gm_fma(r3, B10, q7);
+        const double q1 = gm_fma(r2, K(B3), gm_fma(K(B2), r, K(B1)));     // B1 + r B2 + r2 B3
+        const double q4 = gm_fma(r2, K(B6), gm_fma(K(B5), r, K(B4)));     // B4 + r B5 + r2 B6
+        double q7 = gm_fma(r2, K(B9), gm_fma(K(B8), r, K(B7)));           // B7 + r B8 + r2 B9
+        q7 = gm_fma(r3, K(B10), q7);
         double inner = gm_fma(q7, r3, q4);
         inner = gm_fma(inner, r3, q1);
         // r - r^2/2 in double-double: rhi = r rounded to 26 bits
-        const double rw = gm_fma(r, 0x1p27, r);                  // r + w, w = r 2^27 (fused)
-        const double rhi = gm_fma(-0x1p27, r, rw);               // (r + w) - w     (fused)
+        const double rw = gm_fma(r, K(0x1p27), r);               // r + w, w = r 2^27 (fused)
+        const double rhi = gm_fma(K(-0x1p27), r, rw);            // (r + w) - w     (fused)
         const double rhi2 = rhi * rhi;
         const double rlo = r - rhi;
         const double hi = gm_fma(rhi2, B0, r);                   // r + w', w' = rhi^2 B0 (fused)
@@ -153,15 +176,15 @@ GM_FN double gm_log(double x, const uint64_t* TL)
     const double z = gm_dbl(iz);
     const double r = gm_fma(z, invc, -1.0);
     const double kd = (double)k;
-    const double w = gm_fma(kd, Ln2hi, logc);
+    const double w = gm_fma(kd, K(Ln2hi), logc);
     const double hi = w + r;
     double lo = (w - hi) + r;
-    lo = gm_fma(kd, Ln2lo, lo);
+    lo = gm_fma(kd, K(Ln2lo), lo);
     const double r2 = r * r;
-    const double p12 = gm_fma(A2, r, A1);
+    const double p12 = gm_fma(K(A2), r, K(A1));
     const double rr2 = r * r2;
-    const double p34 = gm_fma(r, A4, A3);
-    lo = gm_fma(r2, A0, lo);
+    const double p34 = gm_fma(r, K(A4), K(A3));
+    lo = gm_fma(r2, K(A0), lo);
     const double p = gm_fma(p34, r2, p12);
     const double y = gm_fma(rr2, p, lo);
     return y + hi;
@@ -252,8 +275,8 @@ GM_FN double gm_log1p(double x)
 // argument is exp of a non-positive number.)
 GM_FN double gm_log1p_unit(double t)
 {
-    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-    const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
+    GM_CONST double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    GM_CONST double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
                  Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
                  Lp7 = 1.479819860511658591e-01;
     const uint32_t hx = (uint32_t)(gm_bits(t) >> 32);
@@ -304,6 +327,9 @@ GM_FN double gm_log1p_unit(double t)
     if (hx < 0x3e200000u) res = (hx < 0x3c900000u) ? t : t - (t * t) * 0.5;   // t < 2^-29 (< 2^-54: t)
     return res;
 }
+
+#undef K
+#undef GM_CONST
 
 #if defined(__clang__)
 #pragma clang fp contract(on)

@@ -370,7 +370,11 @@ int check_args(rd_ctx* ctx, const void* signal, const int64_t* read_off, int n_r
     RD_REQUIRE(step >= 1 && step <= chunk_len, "step %d must be in [1, chunk_len]", step);
     RD_REQUIRE(W >= 1 && W <= rd_decode_max_width(), "beam_width %d out of range", W);
     RD_REQUIRE(read_off[0] == 0, "read_off[0] must be 0");
-    for (int r = 0; r < n_reads; r++) RD_REQUIRE(read_off[r + 1] > read_off[r], "read %d is empty (the caller skips empty reads, basecall.py:77-82)", r);
+    for (int r = 0; r < n_reads; r++) {
+        RD_REQUIRE(read_off[r + 1] > read_off[r], "read %d is empty (the caller skips empty reads, basecall.py:77-82)", r);
+        RD_REQUIRE(rd_decode_len_ok(W, read_off[r + 1] - read_off[r]), "read %d has %lld samples; beam width %d supports at most %lld (1 + W * rows < 2^29)", r,
+                   (long long)(read_off[r + 1] - read_off[r]), W, (long long)((((int64_t)1 << 29) - 2) / W));
+    }
     if (!ctx->model.loaded) {
         rd_set_error("no weights loaded (rd_load_weights)");
         return RD_ERR_STATE;

@@ -214,3 +214,20 @@ def test_errors(be):
     with pytest.raises(RadianHipError):
         be.decode(m, 6, use_lm=True)  # no LM loaded
     assert be.decode(np.zeros((0, 5), dtype=np.float32), 6).tolist() == []
+
+
+def test_sequence_too_long_for_the_backpointer_packing_is_refused():
+    """(parent id << 2) | label lives in 32 bits and a sequence has up to 1 + W * rows trie nodes: 1 + W * rows >= 2^29 is
+    RD_ERR_ARG at the boundary (host-side check), not a silently wrong traceback.  W = 51: 10 527 375 rows is the limit."""
+    from radian_amd import Backend, RadianHipError
+    be = Backend(0)
+    try:
+        W = be.max_beam_width
+        lim = ((1 << 29) - 2) // W
+        probs = np.zeros((8, 5), dtype=np.float32)
+        probs[:, 4] = 1.0
+        with pytest.raises(RadianHipError, match="2\\^29"):
+            be.decode_batch(probs, [0], [lim + 1], W)        # (refused before any row is read)
+        assert be.decode_batch(probs, [0], [8], W)[0].size == 0
+    finally:
+        be.close()

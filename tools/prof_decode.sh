@@ -11,10 +11,10 @@ mkdir -p $OUT
 cd $R
 ARMS=${2:-"new old"}       # second argument: which arms to run ("new", "old" or both)
 for LIBTAG in $ARMS; do
-  if [ $LIBTAG = old ]; then export RADIAN_HIP_LIB=$R/tools/variants/libradian_hip_r1decode.so; else unset RADIAN_HIP_LIB; fi
+  if [ $LIBTAG = old ]; then export RADIAN_HIP_LIB=${OLD_LIB:-$R/tools/variants/libradian_hip_r1decode.so}; else unset RADIAN_HIP_LIB; fi
   CFGS=("512 10 0" "512 10 1" "4096 10 0" "512 25 1" "4096 25 1")
   # this round's decoder also in its default arithmetic (glibc's operation sequence; the five above run the fast routines)
-  if [ $LIBTAG = new ]; then CFGS+=("512 10 0 glibc" "512 10 1 glibc" "4096 10 0 glibc" "512 25 1 glibc"); fi
+  if [ $LIBTAG = new ] || [ -n "${OLD_HAS_GLIBC:-}" ]; then CFGS+=("512 10 0 glibc" "512 10 1 glibc" "4096 10 0 glibc" "512 25 1 glibc"); fi
   for CFG in "${CFGS[@]}"; do
     NAME=${LIBTAG}_$(echo $CFG | tr ' ' '_')
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$NAME -- python3 tools/decode_prof_run.py $CFG > $OUT/trace_$NAME.log 2>&1
