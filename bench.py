@@ -148,7 +148,7 @@ def total_note(lengths, dt):
 def driver_leg(device, pool, cli, lengths, seed, weights_flat, lm=None, warm_reads=256, desc=""):
     """A job through the product's driver loop (radian_amd.basecall.run = basecall.py:69-141) with the CLI flags `cli`:
     host int16 reads -> H2D -> MAD normalisation on the device -> streamed forward -> (assembly) -> beam search -> labels to
-    the host -> strings (chunk mode: simple_assembly in the stitch workers), results in input order; everything but fast5
+    the host -> strings (chunk mode: simple_assembly natively on host threads), results in input order; everything but fast5
     parsing and FASTA writing.  Device contexts / pipelining as the CLI defaults choose them."""
     import contextlib
     from radian_amd import Backend, basecall
@@ -183,7 +183,8 @@ def driver_leg(device, pool, cli, lengths, seed, weights_flat, lm=None, warm_rea
     return {"value": total / dt, "unit": "samples/s", "reads": int(len(lengths)), "samples": total, "seconds": dt,
             "mean_bases_per_read": mean_bases, "cli": " ".join(cli),
             "device_contexts": len(bes), "pipelined": not args.no_pipeline,
-            "stitch_workers": (pool._max_workers if pool is not None and args.decode_type == "chunk" else 0),
+            "stitch": ("native rd_stitch_chunk (simple_assembly + difflib restated in C++) on host threads" if args.decode_type == "chunk" and not args.no_pipeline
+                       else "none (global mode)" if args.decode_type != "chunk" else "pure-Python difflib in worker processes"),
             "path": desc + "; host int16 -> H2D -> on-device mad_normalise -> streamed forward -> beam search -> labels D2H -> strings, "
                            "through radian_amd.basecall.run; excludes fast5 parsing and FASTA writing"}
 
@@ -323,6 +324,8 @@ def main():
                     help="untimed cross-checks on batch 0: streamed labels == windowed labels == the oracle's; probabilities within 1e-4 of the oracle's")
     ap.add_argument("--decode-group", type=int, default=8, help="batches per beam-search launch in the two-stream pipeline")
     ap.add_argument("--lanes", type=int, default=2, help="forward streams the pipelined batches rotate over (1..4)")
+    ap.add_argument("--conv-shape", type=int, default=0, choices=[0, 1],
+                    help="fp32 conv workgroup shape: 0 = 128 x 256 tiles, two workgroups per CU (product); 1 = 256 x 256, one per CU (measurement)")
     ap.add_argument("--cpu-reads", type=int, default=0, help="reads in the CPU-baseline sample (0: sized to the usable core count)")
     ap.add_argument("--e2e-reads", type=int, default=8192, help="reads of the raw end-to-end secondary leg")
     args = ap.parse_args()
@@ -338,10 +341,7 @@ def main():
     from radian_amd.backend import RD_TIMER_CONV, RD_TIMER_DECODE, RD_TIMER_HEAD
 
     secondaries = world == 1 and not args.no_secondary and not args.windowed and args.precision == "fp32"
-    stitch_pool = None
-    if secondaries and args.e2e_reads > 0:
-        from radian_amd import basecall as _bc
-        stitch_pool = _bc.make_stitch_pool(min(4, max(1, effective_cores() // 4)))   # before this process touches the GPU
+    stitch_pool = None   # (the pipelined driver stitches natively on host threads: no worker processes to start)
 
     device = int(os.environ.get("RD_BENCH_DEVICE", local_rank))   # override only for rehearsals on a 1-GPU box
     be = Backend(device)
@@ -378,6 +378,7 @@ def main():
 
     be.set_precision(args.precision)
     be.set_decode_math(args.decode_math)
+    be.set_conv_shape(args.conv_shape)
 
     # ---- synthetic input, resident in HBM: 4 distinct batches of 64 reads per rank, cycled
     reads_per_batch = BATCH_WINDOWS // 8
@@ -634,7 +635,7 @@ def main():
                  "the same job on RAGGED reads (seeded log-normal lengths, median 9000, 1.5 k .. 60 k samples): every device batch "
                  "builds and uploads its own plan"),
                 ("secondary_e2e_raw_soft_head", chunk_cli, np.full(args.e2e_reads // 2, READ_LEN, dtype=np.int64), soft, None,
-                 "configs[2] end to end with the soft head: ~200-base fragments per window through the difflib stitch"),
+                 "configs[2] end to end with the soft head: ~200-base fragments per window through the stitch (difflib's placement rule)"),
                 ("secondary_reference_defaults", ["--rna-threshold", "0.5"], ragged_lengths(args.e2e_reads // 2, 72), soft, (table, 11),
                  "the reference's own defaults (basecall.py:24-35): --decode-type global, step 128, beam 6, 12-mer LM (4^11-row table), "
                  "thresholds 0.5 / 0.5, on ragged reads with the soft head"),

@@ -54,6 +54,10 @@ int rd_sync(rd_ctx* ctx);             /* wait for the context's stream */
  *     fp32's exponent range), the six cross products down to 2^-16 relative accumulated in fp32 on the bf16 matrix pipe;
  *     the dropped terms are below one fp32 rounding of the product. */
 int rd_set_precision(rd_ctx* ctx, int mode);
+/* Workgroup shape of the fp32 matrix-product kernels (no effect on results; for measurements): 0 (default) = 128 time steps x 256
+ * channels per 256-thread workgroup, two workgroups per CU; 1 = 256 x 256 per 512-thread workgroup, one per CU (the weight
+ * tile is shared by twice the rows: a third less LDS-DMA volume per FLOP, no second workgroup to run under an epilogue). */
+int rd_set_conv_shape(rd_ctx* ctx, int shape);
 /* Diagnostic of mode 2: split n fp32 values on the device exactly as the kernels do; terms_out[t * n + i] is the bf16 bit
  * pattern of term t (0 hi, 1 mid, 2 lo) of values[i]. */
 int rd_split3(rd_ctx* ctx, const float* values, size_t n, uint16_t* terms_out);
@@ -253,6 +257,16 @@ int rd_pipe_progress(rd_ctx* ctx, int64_t wait_for, int64_t* delivered);
 /* Batches submitted to the reads-level pipeline so far: right after a submit, the number rd_pipe_progress must reach for
  * that batch to have been delivered. */
 int rd_pipe_submitted(rd_ctx* ctx, int64_t* submitted);
+
+/* ---- the step after the hot path in chunk mode, on the HOST's cores: simple_assembly + argmax --
+ * radian/sequence_assembly.py:19-48, radian/basecall.py:122-123.  labels / label_len as the chunk-mode entry points return
+ * them (window w at labels + w * chunk_len); read r owns windows [read_win_off[r], read_win_off[r + 1]).  The consensus of
+ * read r (labels 0..3, not reversed) goes to seq_out + seq_off[r] (capacity >= the sum of its windows' label_len),
+ * seq_len[r] its length -- or -1 where the reference raises IndexError (its vote matrix grows at most once per fragment).
+ * Fragment placement restates difflib.SequenceMatcher (autojunk included) exactly; n_threads host threads share the
+ * reads.  No GPU is touched and no context is needed. */
+int rd_stitch_chunk(const uint8_t* labels, const int32_t* label_len, int chunk_len, const int32_t* read_win_off, int n_reads,
+                    uint8_t* seq_out, const int64_t* seq_off, int32_t* seq_len, int n_threads);
 
 /* ---- kernel timing on the launch stream (HIP events) --------------------------------------- */
 #define RD_TIMER_CONV 0   /* dilated conv 256->256 (MFMA), the dominant kernel */

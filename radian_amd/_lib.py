@@ -26,6 +26,7 @@ SIGNATURES = {
     "rd_destroy": (c_i, [c_vp]),
     "rd_sync": (c_i, [c_vp]),
     "rd_set_precision": (c_i, [c_vp, c_i]),
+    "rd_set_conv_shape": (c_i, [c_vp, c_i]),
     "rd_split3": (c_i, [c_vp, c_vp, c_sz, c_vp]),
     "rd_load_weights": (c_i, [c_vp, c_vp, c_sz]),
     "rd_load_lm": (c_i, [c_vp, c_vp, c_i]),
@@ -53,6 +54,7 @@ SIGNATURES = {
     "rd_normalise_reads": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_vp, c_vp]),
     "rd_basecall_raw_chunk": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
     "rd_basecall_raw_global": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp, c_vp]),
+    "rd_stitch_chunk": (c_i, [c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_i]),
     "rd_dev_alloc": (c_i, [c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "rd_dev_free": (c_i, [c_vp, c_vp]),
     "rd_memcpy_h2d": (c_i, [c_vp, c_vp, c_vp, c_sz]),

@@ -34,10 +34,19 @@ class PipeTicket:
     def done(self):
         return self.be.pipe_progress(0) >= self.seq
 
-    def result(self):
-        """(labels, status) as basecall_raw_global / basecall_raw_chunk return them; blocks until delivered"""
+    def wait(self):
         if self.be.pipe_progress(self.seq) < self.seq:
             raise RadianHipError("pipeline did not deliver the awaited batch")
+
+    def result_raw(self):
+        """chunk mode, blocks until delivered: (label matrix uint8 [n_windows, chunk_len], lengths int32 [n_windows], windows
+        per read, status) -- what radian_amd.sequence_assembly.consensus_batch takes, without a Python object per window"""
+        self.wait()
+        return self.labels, self.lens, self.nw, self.status
+
+    def result(self):
+        """(labels, status) as basecall_raw_global / basecall_raw_chunk return them; blocks until delivered"""
+        self.wait()
         if self.decode_type == "global":
             return [self.labels[self.off[r]: self.off[r] + self.lens[r]].copy() for r in range(self.n)], self.status
         out, w = [], 0
@@ -89,6 +98,10 @@ class Backend:
         bf16 split: every fp32 operand exact, six bf16 MFMAs per product)."""
         code = {"fp32": 0, "f16x3": 1, "bf16x3": 2}[mode] if isinstance(mode, str) else int(mode)
         self._check(self._L.rd_set_precision(self._h, code))
+
+    def set_conv_shape(self, shape):
+        """0 (default): 128-row tiles, two 256-thread workgroups per CU; 1: 256-row tiles, one 512-thread workgroup per CU (fp32 mode)."""
+        self._check(self._L.rd_set_conv_shape(self._h, int(shape)))
 
     def split3(self, values):
         """Device-side three-term bf16 split of float32 values -> uint16 [3, n] bit patterns (hi, mid, lo)."""

@@ -70,8 +70,9 @@ def build_parser():
                         help="global mode: accept a --context-len longer than the RNA model's k-mers (up to 256) by addressing the model's "
                              "table with a hash of the context (a synthetic long-context LM: no reference behaviour -- the reference raises "
                              "KeyError at decode.py:83)")
-    parser.add_argument("--stitch-workers", default=min(4, max(1, (os.cpu_count() or 2) // 4)), type=int,
-                        help="worker processes for the chunk-mode fragment stitch (0: stitch on the driver's host thread)")
+    parser.add_argument("--stitch-workers", default=None, type=int,
+                        help="chunk mode: host threads of the native fragment stitch (default: the usable cores - 2, at most 16); with "
+                             "--no-pipeline: worker processes of the pure-Python stitch (default min(4, cores / 4); 0: on the driver's thread)")
     parser.add_argument("--queue-block", default=256, type=int,
                         help="--gpus N: reads per claim of the per-node work queue (0: static round-robin by read index)")
     parser.add_argument("--gpu-batch-windows", default=None, type=int,
@@ -162,9 +163,12 @@ def _stitch_reads(frag_lists):
 
 
 def make_stitch_pool(n_workers):
-    """Process pool for the chunk-mode string stitch (pure Python difflib, the reference's own algorithm; one interpreter
-    cannot keep up with one GPU).  Must be created BEFORE the process touches the GPU: the workers are spawned fresh
+    """Process pool for the chunk-mode string stitch in pure Python (difflib, the reference's own code path; one interpreter
+    cannot keep up with one GPU) -- the --no-pipeline driver's host stage; the pipelined driver stitches natively
+    (sequence_assembly.consensus_batch).  Must be created BEFORE the process touches the GPU: the workers are spawned fresh
     interpreters that never load the HIP library."""
+    if n_workers is None:
+        n_workers = min(4, max(1, (os.cpu_count() or 2) // 4))
     if n_workers <= 0:
         return None
     import multiprocessing
@@ -249,7 +253,15 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
 
     def finish(b, b_idx, labels, status, dur):
         seqs = None
-        if stitch_pool is not None and args.decode_type == "chunk":
+        if isinstance(labels, tuple):
+            # pipelined chunk mode: the label matrix as the device left it -> consensus strings of every read in one native
+            # call (simple_assembly + argmax, sequence_assembly.py:19-48 / basecall.py:122-123, on host threads)
+            from .sequence_assembly import consensus_batch
+            lab2d, lens, nw = labels
+            allseq = consensus_batch(lab2d, lens, nw, threads=args.stitch_workers)
+            seqs = iter([sq for sq, st in zip(allseq, status) if st == 0])
+            labels = [None] * len(b)
+        elif stitch_pool is not None and args.decode_type == "chunk":
             # the reads of the batch in slices, one task each; results come back in order
             ok = [lab for lab, st in zip(labels, status) if st == 0]
             per = max(1, -(-len(ok) // (4 * stitch_pool._max_workers)))
@@ -277,7 +289,10 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
         return labels, status, (time() - t0) / len(b)
 
     def collect(ticket, t0, n):
-        labels, status = ticket.result()                # blocks until the batch's group has been decoded
+        if args.decode_type == "chunk":                 # blocks until the batch's group has been decoded
+            lab2d, lens, nw, status = ticket.result_raw()
+            return (lab2d, lens, nw), status, (time() - t0) / n
+        labels, status = ticket.result()
         return labels, status, (time() - t0) / n
 
     def retire(keep):
@@ -414,7 +429,7 @@ def main(argv=None):
     if args.gpus > 1:
         from .launch import run_multi_gpu
         return run_multi_gpu(args, argv if argv is not None else sys.argv[1:])
-    pool = make_stitch_pool(args.stitch_workers) if args.decode_type == "chunk" else None   # before the GPU is touched
+    pool = make_stitch_pool(args.stitch_workers) if args.decode_type == "chunk" and args.no_pipeline else None   # before the GPU is touched
     from .backend import Backend
     art = load_artifacts(args)
     bes = [Backend(args.device) for _ in range(n_contexts(args))]

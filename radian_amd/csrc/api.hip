@@ -548,6 +548,14 @@ extern "C" int rd_set_decode_form(rd_ctx* ctx, int form)
     return RD_OK;
 }
 
+extern "C" int rd_set_conv_shape(rd_ctx* ctx, int shape)
+{
+    RD_REQUIRE(ctx, "rd_set_conv_shape: null context");
+    RD_REQUIRE(shape == 0 || shape == 1, "rd_set_conv_shape: shape %d (0 = 128-row tiles, two workgroups per CU; 1 = 256-row tiles, one workgroup per CU)", shape);
+    ctx->conv_shape = shape;
+    return RD_OK;
+}
+
 extern "C" int rd_set_decode_partition(rd_ctx* ctx, int cus_per_xcd)
 {
     RD_REQUIRE(ctx, "rd_set_decode_partition: null context");

@@ -102,9 +102,15 @@ __device__ __forceinline__ void wait_dma_and_barrier()
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LEAVE) : "memory");
 }
 
-template <int NT, int TAPS, int EPI>
-__global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
+// WM = waves along M (64 time steps each): 2 -> the 256-thread, 128-row tile, two workgroups per CU (the product's shape);
+// 4 -> a 512-thread, 256-row tile, one workgroup per CU: the B (weight) tile is shared by twice the rows, so a CU moves
+// (256 + 256) x 64 B = 32 KiB per chunk by LDS-DMA instead of 2 x (128 + 256) x 64 B = 48 KiB for the same FLOPs
+// (measured, DESIGN.md 4.1: rd_set_conv_shape / tools/conv_shape.py).
+template <int NT, int TAPS, int EPI, int WM = 2>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(ConvArgs a)
 {
+    constexpr int BM = 64 * WM;           // time steps per workgroup tile (shadows the file-scope 128)
+    constexpr int NWAVE = 2 * WM;
     constexpr int BN = 2 * NT * 32;       // output channels per workgroup (2 waves along N)
     constexpr int NCHUNK = TAPS * (RD_C / BK);
     constexpr int STAGE_FLOATS = (BM + BN) * BK;   // one K-chunk of A and B
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
     constexpr int NSTAGE = 3;
     constexpr int SMEM_FLOATS = (EPI == EPI_HEAD && HEAD_FLOATS > NSTAGE * STAGE_FLOATS) ? HEAD_FLOATS : NSTAGE * STAGE_FLOATS;
 
-    __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];  // 2 x 24 KiB (conv) / 67 KiB (head)
+    __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];  // 3 x 24 KiB (conv, WM = 2) / 3 x 32 KiB (WM = 4) / 67 KiB (head)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
     // step, the segment length.  A segment is a window, a whole read, or the first rows of a window.
     // A workgroup tile is four independent 32-row sub-tiles (rows 32s .. 32s+31), each with its own descriptor: stream
     // tiles use four consecutive sub-tiles of one segment, short head segments are packed four to a tile.
-    const TileDesc* __restrict__ tds = a.tiles + (size_t)blockIdx.x * 4;
+    const TileDesc* __restrict__ tds = a.tiles + (size_t)blockIdx.x * NWAVE;   // one 32-row sub-tile descriptor per wave
     const TileDesc sdm[2] = {tds[wm * 2], tds[wm * 2 + 1]};           // this wave's two sub-tiles
     const bool mval[2] = {sdm[0].seg_len > sdm[0].t0, sdm[1].seg_len > sdm[1].t0};
 
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
 
     // one piece (wave-instruction) of a chunk's staging: pieces 0,1 = this wave's two 16-row pieces of A, 2.. = its
     // BN/64 consecutive 1-KiB pieces of B.  `tap` is the chunk's tap (a literal at every call site).
-    constexpr int PB = BN / 64;
+    constexpr int PB = BN / (16 * NWAVE);   // 1-KiB pieces (16 rows) of B per wave
     constexpr int NPIECE = 2 + PB;
     auto stage_piece = [&](int chunk, int tap, float* st, int pc) {
         // chunk order: input-channel slice outer, tap inner -> the three shifted reads of the same rows are adjacent in time
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
         // the first row's banks: 1.2-1.5 M conflict cycles per launch.)
         constexpr int TSTR = 64;
         float* ts = smem + wave * (32 * TSTR);
-        float4* sink4 = (float4*)a.sink + threadIdx.x;
+        float4* sink4 = (float4*)a.sink + (threadIdx.x & 255);   // (1024 floats; two lanes of a 512-thread workgroup may share a slot: nobody reads it)
         const int rrow = lane >> 4;                    // 0..3: row inside a 4-row store group
         const int c4 = (lane & 15) * 4;                // channel offset inside the 64-channel patch
 #pragma unroll
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_kernel(ConvArgs a)
                 }
         }
         float* w2s = smem + BM * LDH;  // [128*5 + 5]
-        for (int i = tid; i < RD_H * 5; i += 256) w2s[i] = a.w2[i];
+        for (int i = tid; i < RD_H * 5; i += 64 * NWAVE) w2s[i] = a.w2[i];
         if (tid < 5) w2s[RD_H * 5 + tid] = a.b2[tid];
         __syncthreads();
         if (tid < BM) {
@@ -1377,7 +1383,8 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
             h.b2 = m.b_d2;
             h.probs = d_probs;
             h.probs_f16 = probs_f16;
-            hipLaunchKernelGGL((tcn_gemm_kernel<2, 1, EPI_HEAD>), dim3(n), dim3(256), 0, st, h);
+            if (ctx->conv_shape == 1) hipLaunchKernelGGL((tcn_gemm_kernel<2, 1, EPI_HEAD, 4>), dim3(n / 2), dim3(512), 0, st, h);
+            else hipLaunchKernelGGL((tcn_gemm_kernel<2, 1, EPI_HEAD>), dim3(n), dim3(256), 0, st, h);
         }
         RD_HIP(hipGetLastError());
         return timer_end(st, ctx->timer_head, 2.0 * rows * (RD_C * RD_H + RD_H * 5), rows * (RD_C * 4.0 + 20.0));
@@ -1420,12 +1427,15 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
     if ((rc = timer_begin(st, ctx->timer_conv))) return rc;
     if (kind == 1) {
         if (split) hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RELU>), dim3(n), dim3(256), 0, st, sa);
+        else if (ctx->conv_shape == 1) hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RELU, 4>), dim3(n / 2), dim3(512), 0, st, a);
         else hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RELU>), dim3(n), dim3(256), 0, st, a);
     } else if (b == 0) {
         if (split) hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RES_MATCH>), dim3(n), dim3(256), 0, st, sa);
+        else if (ctx->conv_shape == 1) hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_MATCH, 4>), dim3(n / 2), dim3(512), 0, st, a);
         else hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_MATCH>), dim3(n), dim3(256), 0, st, a);
     } else {
         if (split) hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RES_IDENT>), dim3(n), dim3(256), 0, st, sa);
+        else if (ctx->conv_shape == 1) hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_IDENT, 4>), dim3(n / 2), dim3(512), 0, st, a);
         else hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_IDENT>), dim3(n), dim3(256), 0, st, a);
     }
     RD_HIP(hipGetLastError());

@@ -261,7 +261,7 @@ def worker(scratch, argv):
     from .dist import StartupFailed, connect, env_rank_world, uid_path
     args = build_parser().parse_args(argv)
     rank, local_rank, world = env_rank_world()
-    pool = make_stitch_pool(args.stitch_workers) if args.decode_type == "chunk" else None   # before the GPU is touched
+    pool = make_stitch_pool(args.stitch_workers) if args.decode_type == "chunk" and args.no_pipeline else None   # before the GPU is touched
     device = int(os.environ.get("RD_CLI_DEVICE", local_rank))   # override only for rehearsals on a 1-GPU box
     be = Backend(device)
     # every rank uses RCCL or none does (dist.connect); the rendezvous lives in the launcher's private scratch directory

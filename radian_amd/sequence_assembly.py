@@ -8,6 +8,7 @@ for fragments >= 200 characters), then all votes are counted in one `numpy.binco
 Behaviour is pinned by tests/golden/seq_assembly_cases.json (from the reference) and by the randomised comparison in tests/test_host_cpu.py.
 """
 import difflib
+import os
 
 import numpy as np
 
@@ -104,3 +105,48 @@ def consensus_sequence(fragments):
 
 def labels_to_str(labels):
     return index2base(labels)
+
+
+_ASCII = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def consensus_batch(labels, lens, windows_per_read, threads=None):
+    """consensus_sequence for a batch of reads straight from the device's output: labels uint8 [n_windows, chunk_len], lens
+    int32 [n_windows] (labels[w, :lens[w]] is window w's fragment), windows_per_read the number of windows of each read, in
+    order.  Runs the library's native restatement of simple_assembly + difflib (rd_stitch_chunk, csrc/stitch.hip) on
+    `threads` host threads -- the pure-Python stitch above costs ~4.5 ms per read once fragments are ~200 bases long.
+    A read for which the reference raises (its IndexError capacity rule) is handed to the Python path, which raises it."""
+    import ctypes
+    from . import _lib
+    L = _lib.load()
+    labels = np.ascontiguousarray(labels, dtype=np.uint8)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    nwin, chunk_len = labels.shape
+    nw = np.asarray(windows_per_read, dtype=np.int64)
+    n_reads = int(nw.shape[0])
+    win_off = np.zeros(n_reads + 1, dtype=np.int32)
+    win_off[1:] = np.cumsum(nw)
+    if int(win_off[-1]) != nwin or lens.shape[0] != nwin:
+        raise ValueError("windows_per_read does not add up to the label matrix")
+    csum = np.concatenate([[0], np.cumsum(lens, dtype=np.int64)])
+    cap = csum[win_off[1:]] - csum[win_off[:-1]]          # labels of the read's windows: its consensus cannot be longer
+    seq_off = np.zeros(n_reads, dtype=np.int64)
+    seq_off[1:] = np.cumsum(cap[:-1])
+    out = np.zeros(int(cap.sum()) + 1, dtype=np.uint8)
+    seq_len = np.zeros(n_reads, dtype=np.int32)
+    if threads is None:
+        threads = max(1, min(16, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2)) - 2))
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = L.rd_stitch_chunk(p(labels), p(lens), int(chunk_len), p(win_off), n_reads, p(out), p(seq_off), p(seq_len), int(threads))
+    if rc != 0:
+        raise RuntimeError(L.rd_last_error().decode("utf-8", "replace"))
+    text = _ASCII[out].tobytes().decode("ascii")
+    res = []
+    for r in range(n_reads):
+        if seq_len[r] < 0:   # the reference raises here: let the Python mirror do it
+            w0 = int(win_off[r])
+            res.append(consensus_sequence([labels_to_str(labels[w0 + i, : lens[w0 + i]]) for i in range(int(nw[r]))]))
+            continue
+        o = int(seq_off[r])
+        res.append(text[o: o + int(seq_len[r])])
+    return res

@@ -337,3 +337,52 @@ def test_bf16x3_streamed_equals_windowed_and_bench_labels(oracle):
         assert all(np.array_equal(a, e) for a, e in zip(frags, lab))
     finally:
         b.close()
+
+
+def test_configs1_batch256_forward_shape_vs_oracle(oracle):
+    """BASELINE configs[1] as it is worded: batch = 256 windows (32 reads x 4096, chunk 1024 / step 512), forward only (beam 1 =
+    greedy is decode-side, tests/test_gpu_baseline_configs.py): the whole batch's probabilities against the oracle forward,
+    |d softmax| <= 1e-4, through the window-level entry point and -- bit-identical to it -- the streamed reads-level forward."""
+    from radian_amd import Backend, synthetic, weights
+    w = weights.synthetic_weights(seed=1234)
+    raws = synthetic.synthetic_reads(32, 4096, seed=2)
+    norm = [np.asarray(oracle.mad_normalise(r, 4), dtype=np.float32) for r in raws]
+    win = np.concatenate([np.asarray(oracle.get_windows(n, 1024, 512)[0], dtype=np.float32) for n in norm])
+    assert win.shape == (256, 1024)
+    be = Backend(0)
+    try:
+        be.load_weights(w)
+        probs = be.forward(win)
+        ref = oracle.tcn_forward(w, win)
+        err = float(np.abs(probs - ref).max())
+        assert err <= 1e-4, err
+        # greedy (beam 1) labels of every window: the streamed chunk path equals the oracle's decode of these probabilities
+        got = be.basecall_reads_chunk(norm, 1024, 512, 1)
+        valid = np.full(256, 1024, dtype=np.int32)
+        valid[7::8] = 512
+        exp = oracle.beam_search_batch(probs.reshape(-1, 5), np.arange(256, dtype=np.int64) * 1024, valid, 1)
+        flat = [f for fr in got for f in fr]
+        assert all(np.array_equal(a, b) for a, b in zip(flat, exp))
+    finally:
+        be.close()
+
+
+def test_conv_workgroup_shapes_are_bit_identical():
+    """rd_set_conv_shape 1 (256 x 256 tiles, one 512-thread workgroup per CU; a measurement variant, profiles/r03b_conv_shape.txt)
+    runs the same MFMA sequence per output element as the product's 128 x 256 tiles: probabilities equal bit for bit, for uniform
+    windows and for ragged reads through the streamed forward (packed head tiles, empty sub-tiles)."""
+    from radian_amd import Backend, synthetic, weights
+    be = Backend(0)
+    try:
+        be.load_weights(weights.synthetic_weights(seed=3))
+        win = synthetic.reads_to_windows(synthetic.synthetic_reads(5, 3000, seed=4), 1024, 300)[0]
+        ragged = [synthetic.synthetic_reads(1, n, seed=n)[0] for n in (1, 31, 33, 700, 1024, 1500, 4097, 9000)]
+        res = []
+        for shape in (0, 1):
+            be.set_conv_shape(shape)
+            res.append((be.forward(win), be.basecall_raw_chunk(ragged, 4, 1024, 512, 10)[0], be.basecall_raw_global(ragged, 4, 1024, 128, 6, False)[0]))
+        assert np.array_equal(res[0][0], res[1][0])
+        assert all(np.array_equal(a, b) for x, y in zip(res[0][1], res[1][1]) for a, b in zip(x, y))
+        assert all(np.array_equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+    finally:
+        be.close()

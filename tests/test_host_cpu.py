@@ -293,3 +293,85 @@ def test_pure_python_hdf5_reader(tmp_path, golden_dir, monkeypatch):
     if os.path.exists(ref):
         got = [(r.read_id, r.get_raw_data()) for r in fast5.iter_reads(ref)]
         assert [g[0] for g in got] == ids and all(np.array_equal(a, sig[r]) for r, a in got)
+
+
+def _label_matrix(frag_lists, chunk_len):
+    nw = [len(c) for c in frag_lists]
+    lab = np.zeros((sum(nw), chunk_len), dtype=np.uint8)
+    lens = np.zeros(sum(nw), dtype=np.int32)
+    w = 0
+    for c in frag_lists:
+        for f in c:
+            lab[w, : len(f)] = f
+            lens[w] = len(f)
+            w += 1
+    return lab, lens, nw
+
+
+def test_native_stitch_matches_reference_goldens(golden_dir):
+    """rd_stitch_chunk (csrc/stitch.hip: simple_assembly + difflib restated in C++, the driver's chunk-mode host stage) on the
+    reference-generated cases whose fragments are plain upper-case ACGT (the device emits labels, which have no case): same
+    consensus strings; the cases on which the reference raises IndexError raise here too."""
+    from radian_amd import sequence_assembly as S
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    n_ok = n_err = 0
+    for name in ("seq_assembly_cases.json", "seq_assembly_random_cases.json"):
+        for c in json.load(open(os.path.join(golden_dir, name)))["cases"]:
+            if not all(set(f) <= set("ACGT") for f in c["fragments"]):
+                continue
+            frags = [np.array([code[ch] for ch in f], dtype=np.uint8) for f in c["fragments"]]
+            lab, lens, nw = _label_matrix([frags], max([1] + [len(f) for f in frags]))
+            if "error" in c:
+                with pytest.raises(IndexError):
+                    S.consensus_batch(lab, lens, nw, threads=1)
+                n_err += 1
+            else:
+                assert S.consensus_batch(lab, lens, nw, threads=1) == [c["seq"]]
+                n_ok += 1
+    assert n_ok >= 15, (n_ok, n_err)
+
+
+def test_native_stitch_equals_difflib_randomised():
+    """against the Python mirror (which calls difflib itself) over noisy overlapping fragments of a common sequence and
+    unrelated random ones: fragment lengths around difflib's autojunk threshold (199 / 200 / 201), skewed base
+    compositions (elements that stay below the "popular" count), empty fragments, single fragments, fragments past the
+    reference's 1000-column capacity rule (IndexError on both sides); several threads."""
+    from radian_amd import sequence_assembly as S
+    rng = np.random.default_rng(7)
+
+    def noisy_read(nfrag, L, overlap, err, p):
+        truth = rng.choice(4, size=int(L * (1 + (nfrag - 1) * (1 - overlap))) + 10, p=p)
+        out, pos = [], 0
+        for _ in range(nfrag):
+            n = min(1024, max(0, int(L + rng.integers(-L // 5 - 1, L // 5 + 1))))
+            f = truth[pos: pos + n].copy()
+            m = rng.random(f.size) < err
+            f[m] = rng.integers(0, 4, size=int(m.sum()))
+            out.append(f[rng.random(f.size) > err / 2].astype(np.uint8))
+            pos += int(L * (1 - overlap))
+        return out
+    reads = []
+    for L in (0, 1, 3, 10, 50, 150, 199, 200, 201, 260, 400, 700, 1020):
+        for nfrag in (1, 2, 3, 8):
+            for p in ([0.25] * 4, [0.7, 0.2, 0.08, 0.02], [0.97, 0.01, 0.01, 0.01]):
+                for _ in range(3):
+                    reads.append(noisy_read(nfrag, L, float(rng.choice([0.0, 0.5, 0.9])), float(rng.choice([0.0, 0.05, 0.3])), p))
+    for _ in range(200):
+        reads.append([rng.integers(0, 4, size=int(rng.integers(0, 300))).astype(np.uint8) for _ in range(int(rng.integers(1, 6)))])
+    exp = []
+    for fr in reads:
+        try:
+            exp.append(S.consensus_sequence([S.labels_to_str(f) for f in fr]))
+        except IndexError:
+            exp.append(IndexError)
+    assert exp.count(IndexError) >= 5 and sum(isinstance(e, str) and len(e) > 200 for e in exp) >= 50
+    ok = [i for i, e in enumerate(exp) if e is not IndexError]
+    lab, lens, nw = _label_matrix([reads[i] for i in ok], 1024)
+    got = S.consensus_batch(lab, lens, nw, threads=4)
+    bad = [i for i, g in zip(ok, got) if g != exp[i]]
+    assert not bad, (bad[:5], [len(f) for f in reads[bad[0]]])
+    for i, e in enumerate(exp):
+        if e is IndexError:
+            lab, lens, nw = _label_matrix([reads[i]], 1024)
+            with pytest.raises(IndexError):
+                S.consensus_batch(lab, lens, nw, threads=1)

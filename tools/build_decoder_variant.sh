@@ -19,10 +19,10 @@ if "n_cu_avail" not in s:
     s = s.replace("const int64_t* d_seq_off2, const int32_t* d_seq_split)\n{", "const int64_t* d_seq_off2, const int32_t* d_seq_split, int n_cu_avail)\n{", 1)
 open(p, "w").write(s)
 PY
-sed -i "s#\"../../include/radian_hip.h\"#\"$R/include/radian_hip.h\"#" "$T"/api.hip "$T"/pipe_reads.hip
+sed -i "s#\"../../include/radian_hip.h\"#\"$R/include/radian_hip.h\"#" "$T"/api.hip "$T"/pipe_reads.hip "$T"/stitch.hip
 cd "$T"
 OBJS=""
-for f in api plan pipe_reads forward decode assemble preprocess; do
+for f in api plan pipe_reads forward decode assemble preprocess stitch; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -I/opt/rocm/include -c $f.hip -o $f.o &
   OBJS="$OBJS $f.o"
 done
