@@ -196,6 +196,7 @@ int rd_basecall_raw_global(rd_ctx* ctx, const int16_t* raw, const int64_t* read_
 /* ---- device-resident form (inputs already in HBM; used by bench.py and by pipelined hosts) -- */
 int rd_dev_alloc(rd_ctx* ctx, size_t bytes, void** d_ptr);
 int rd_dev_free(rd_ctx* ctx, void* d_ptr);
+int rd_mem_info(rd_ctx* ctx, size_t* free_bytes, size_t* total_bytes);   /* hipMemGetInfo of the context's device (batch sizing) */
 int rd_memcpy_h2d(rd_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 int rd_memcpy_d2h(rd_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 /* same contract as rd_forward / rd_basecall_chunk with d_windows resident; d_probs may be NULL

@@ -56,6 +56,7 @@ SIGNATURES = {
     "rd_basecall_raw_global": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp, c_vp]),
     "rd_stitch_chunk": (c_i, [c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_i]),
     "rd_dev_alloc": (c_i, [c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "rd_mem_info": (c_i, [c_vp, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)]),
     "rd_dev_free": (c_i, [c_vp, c_vp]),
     "rd_memcpy_h2d": (c_i, [c_vp, c_vp, c_vp, c_sz]),
     "rd_memcpy_d2h": (c_i, [c_vp, c_vp, c_vp, c_sz]),

@@ -339,6 +339,12 @@ class Backend:
         self._check(self._L.rd_dev_alloc(self._h, int(nbytes), ctypes.byref(p)))
         return p
 
+    def mem_info(self):
+        """(free, total) bytes of the context's device"""
+        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self._check(self._L.rd_mem_info(self._h, ctypes.byref(f), ctypes.byref(t)))
+        return f.value, t.value
+
     def dev_free(self, p):
         self._check(self._L.rd_dev_free(self._h, p))
 

@@ -313,7 +313,24 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
     longest = 0
     chain_rows = 128 if args.beam_width <= 12 else 200 if args.beam_width <= 25 else 300
 
+    # A unit (chunk_len rows) costs three activation tensors of 1 KiB per row (1.5 KiB with bf16x3) per forward stream, plus
+    # probabilities / assembled matrix / trie; the automatic batch size never asks for more than a third of the device memory
+    # that is free now (a smaller-HBM part, other processes on the GPU) -- an explicit --gpu-batch-windows is taken as given.
+    mem_cap = None
+    if hasattr(backends[0], "mem_info"):
+        try:
+            free, _total = backends[0].mem_info()
+            per_unit = args.chunk_len * ((1536 if getattr(args, "precision", "fp32") == "bf16x3" else 1024) * 3 + 80 + 24 * max(1, args.beam_width))
+            streams = len(backends) * (2 if pipelined else 1)
+            mem_cap = max(64, int(free / 3 / (per_unit * streams)))
+        except Exception:
+            mem_cap = None
+
     def batch_limit(longest_read):
+        n = _batch_limit(longest_read)
+        return n if mem_cap is None or args.gpu_batch_windows is not None else min(n, mem_cap)
+
+    def _batch_limit(longest_read):
         if args.gpu_batch_windows is not None:
             return args.gpu_batch_windows
         if args.decode_type != "global" or pipelined:   # (the pipeline covers a long read's chain by grouping batches)
@@ -378,8 +395,8 @@ def load_artifacts(args):
             table, k = lm_mod.load_json(args.rna_model)
             if args.decode_type == "global":
                 if k != args.context_len and getattr(args, "lm_hashed_context", False):
-                    if not (1 <= args.context_len <= 256):
-                        raise ValueError("--lm-hashed-context: --context-len must be in [1, 256]")
+                    if not (k < args.context_len <= 256):   # (a shorter context has a dense table of its own: not what the flag is for)
+                        raise ValueError(f"--lm-hashed-context: --context-len must be longer than the RNA model's {k}-label contexts, at most 256")
                     art["lm_table"], art["lm_k"], art["lm_hashed_order"] = table, args.context_len, k
                     return art
                 if k != args.context_len:

@@ -164,7 +164,7 @@ extern "C" int rd_destroy(rd_ctx* ctx)
                       &ctx->ws_nodes_child, &ctx->ws_nodes_back, &ctx->ws_labels, &ctx->ws_misc, &ctx->model.storage,
                       &ctx->lm.storage, &ctx->lm.gate_storage};
     for (DevBuf* b : bufs) b->release();
-    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);   // (ctx->stream was synchronised at the top)
     if (ctx->stream_hi) {
         (void)hipStreamSynchronize(ctx->stream_hi);
         (void)hipStreamDestroy(ctx->stream_hi);
@@ -615,8 +615,13 @@ int prepare_seq_meta(rd_ctx* ctx, const int64_t* seq_off, const int64_t* seq_off
     sm.total_nodes = nodes;
     sm.total_labels = labs;
     // The metadata goes through the context's pinned staging block in ONE copy that needs no host-side wait: the block
-    // is only rewritten by the next call on this context, and every caller ends with a stream synchronisation
-    // (decode_and_fetch) before that can happen.
+    // is only rewritten by the next call on this context, and a caller that runs to completion ends with a stream
+    // synchronisation (decode_and_fetch) before that can happen.  A caller that left early on an error did not: then the
+    // copy may still be reading the block -- wait for it here before the block is rewritten (or freed).
+    if (ctx->h_stage_busy) {
+        RD_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->h_stage_busy = false;
+    }
     const size_t stage_bytes = 4 * a8 + 2 * a4;   // seq_off | seq_off2 | node_off | label_off | seq_len | split
     if (ctx->h_stage_cap < stage_bytes) {
         RD_HIP(hipStreamSynchronize(ctx->stream));
@@ -635,6 +640,7 @@ int prepare_seq_meta(rd_ctx* ctx, const int64_t* seq_off, const int64_t* seq_off
     memcpy(hs + 4 * a8, seq_len, n * 4);
     if (split) memcpy(hs + 4 * a8 + a4, split, n * 4);
     // device layout: 5 x a8 (seq_off, seq_off2, node_off, label_off, score) then 3 x a4 (seq_len, split, label_len)
+    ctx->h_stage_busy = true;
     RD_HIP(hipMemcpyAsync(sm.d_seq_off, hs, 4 * a8, hipMemcpyHostToDevice, ctx->stream));
     RD_HIP(hipMemcpyAsync(sm.d_seq_len, hs + 4 * a8, 2 * a4, hipMemcpyHostToDevice, ctx->stream));
     if (!seq_off2) {
@@ -674,6 +680,7 @@ int decode_and_fetch(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t
     RD_HIP(hipMemcpyAsync(label_len, sm.d_label_len, (size_t)n_seq * 4, hipMemcpyDeviceToHost, ds));
     if (best_score) RD_HIP(hipMemcpyAsync(best_score, sm.d_score, (size_t)n_seq * 8, hipMemcpyDeviceToHost, ds));
     RD_HIP(hipStreamSynchronize(ds));
+    ctx->h_stage_busy = false;   // (ds waited for ctx->stream's event: the metadata copy is done)
     for (int i = 0; i < n_seq; i++) {
         if (label_len[i] < 0 || label_len[i] > seq_len[i]) {
             rd_set_error("decode: sequence %d produced an impossible label length %d (rows %d)", i, label_len[i], seq_len[i]);
@@ -1534,6 +1541,13 @@ extern "C" int rd_dev_alloc(rd_ctx* ctx, size_t bytes, void** d_ptr)
     RD_REQUIRE(ctx && d_ptr, "rd_dev_alloc: null argument");
     RD_HIP(hipSetDevice(ctx->device));
     RD_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return RD_OK;
+}
+extern "C" int rd_mem_info(rd_ctx* ctx, size_t* free_bytes, size_t* total_bytes)
+{
+    RD_REQUIRE(ctx && free_bytes && total_bytes, "rd_mem_info: null argument");
+    RD_HIP(hipSetDevice(ctx->device));
+    RD_HIP(hipMemGetInfo(free_bytes, total_bytes));
     return RD_OK;
 }
 extern "C" int rd_dev_free(rd_ctx* ctx, void* d_ptr)

@@ -162,6 +162,7 @@ struct rd_ctx {
     // pinned host staging
     void* h_stage = nullptr;
     size_t h_stage_cap = 0;
+    bool h_stage_busy = false;   // an async copy out of h_stage was queued and the stream has not been synchronised since
     KernelTimer timer_conv, timer_decode, timer_head, timer_in;
     void* rccl = nullptr;  // RcclState*
     void* pipe = nullptr;  // Pipe* (two-stream forward/decode software pipeline over chunk-mode batches, api.hip)

@@ -817,6 +817,14 @@ __global__ __launch_bounds__(256) void tcn_in_split_kernel(const float* __restri
 // =====================================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// The RD_BF3_* switches below build ABLATION variants of the bf16x3 kernel (operands from registers instead of LDS, DMA or MFMA
+// or epilogue skipped: wrong results by design).  They exist for tools/variants.sh only: a product build that
+// defines one by accident stops here.
+#if (defined(RD_BF3_NOLDS) || defined(RD_BF3_NOMFMA) || defined(RD_BF3_SKIPALL) || defined(RD_BF3_SKIPA) || defined(RD_BF3_SKIPB) || \
+     defined(RD_BF3_NODMA) || defined(RD_BF3_NOA) || defined(RD_BF3_NOB) || defined(RD_BF3_NOEPI)) && !defined(RD_EXPERIMENTS)
+#error "RD_BF3_* ablation switches change results: build them with -DRD_EXPERIMENTS (tools/variants.sh), never into the product"
+#endif
+
 constexpr int ROW3 = 3 * RD_C;   // bf16 elements per activation row (768 = 1536 B)
 
 // fp32 -> (hi, mid, lo); exact: hi + mid + lo == v

@@ -378,14 +378,55 @@ class FileReadQueue:
         if self.block < 1:
             raise ValueError("work-queue block must be >= 1")
         self._fd = os.open(path, os.O_RDWR | os.O_CREAT, 0o600)
+        self._path = path
+        self._counts = {}
         self.claimed = []          # [(file, lo, hi)]
-        self.opened = set()        # files whose read count this rank had to look up
+        self.opened = set()        # files whose read count this rank looked up
+        self.prefetched = set()    # ... of which ahead of time (the file after one whose first block this rank took)
         self.on_claim = on_claim   # on_claim(file, lo, hi) as soon as a block is this rank's (the launcher's streaming merge)
+
+    # Read counts are looked up OUTSIDE the queue's lock (an HDF5 open + key listing) and shared between the ranks through
+    # small files beside the queue file, so that a file is counted once per node, by the rank that gets there first; the
+    # rank that takes the FIRST block of a file also counts the next file ahead of time, so that at a file boundary the
+    # count is already there and nobody waits.  (the lookup used to sit inside the lock.)
+    def _count_path(self, fi):
+        return f"{self._path}.count.{fi}"
+
+    def _known(self, fi):
+        n = self._counts.get(fi)
+        if n is None:
+            try:
+                with open(self._count_path(fi)) as f:
+                    n = self._counts[fi] = int(f.read())
+            except (OSError, ValueError):
+                return None
+        return n
+
+    def _lookup(self, sources, fi, keep_open):
+        if self._known(fi) is not None:
+            return
+        # one rank counts, the others that need the same count wait on the FILE's own lock (not on the queue's)
+        lk = os.open(self._count_path(fi) + ".lock", os.O_RDWR | os.O_CREAT, 0o600)
+        try:
+            self._fcntl.flock(lk, self._fcntl.LOCK_EX)
+            if self._known(fi) is not None:
+                return
+            self.opened.add(fi)
+            n = self._counts[fi] = sources[fi].n_reads()
+            if not keep_open or n == 0:
+                sources[fi].close()          # counted ahead of time (or empty): whoever claims from it opens it again
+            tmp = f"{self._count_path(fi)}.{os.getpid()}.tmp"
+            with open(tmp, "w") as f:
+                f.write(str(n))
+            os.replace(tmp, self._count_path(fi))
+        finally:
+            os.close(lk)                     # (closing the descriptor releases the lock)
 
     def claims(self, sources):
         """Generator of (file_index, lo, hi) blocks owned by this rank; sources[i].n_reads() gives a file's read count."""
         f = self._fcntl
         while True:
+            need = None
             f.flock(self._fd, f.LOCK_EX)
             try:
                 os.lseek(self._fd, 0, os.SEEK_SET)
@@ -393,8 +434,10 @@ class FileReadQueue:
                 fi, r0 = (int(raw[0]), int(raw[1])) if len(raw) >= 2 else (0, 0)
                 got = None
                 while fi < len(sources):
-                    self.opened.add(fi)
-                    n = sources[fi].n_reads()
+                    n = self._known(fi)
+                    if n is None:
+                        need = fi
+                        break
                     if r0 >= n:
                         fi, r0 = fi + 1, 0
                         continue
@@ -406,11 +449,17 @@ class FileReadQueue:
                 os.write(self._fd, b"%-31d %-31d\n" % (fi, r0))
             finally:
                 f.flock(self._fd, f.LOCK_UN)
+            if need is not None:
+                self._lookup(sources, need, keep_open=True)
+                continue
             if got is None:
                 return
             self.claimed.append(got)
             if self.on_claim is not None:
                 self.on_claim(*got)
+            if got[1] == 0 and got[0] + 1 < len(sources) and self._known(got[0] + 1) is None:
+                self.prefetched.add(got[0] + 1)
+                self._lookup(sources, got[0] + 1, keep_open=False)
             yield got
 
     def close(self):

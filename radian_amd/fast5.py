@@ -60,9 +60,10 @@ class Fast5Source:
         self._entries = None   # [(read_id or None, group path, signal path)]
 
     def _open(self):
+        if self._f is None:
+            self._f = h5.File(self.path, "r")     # (again, after a close(): the work queue may count a file's reads ahead of time)
         if self._entries is not None:
             return
-        self._f = h5.File(self.path, "r")
         f = self._f
         names = f.keys("/")
         multi = [n for n in names if n.startswith("read_")]

@@ -46,7 +46,7 @@ def main():
         finally:
             sys.stdout = so
     comm.close()
-    json.dump({"claimed": q.claimed, "opened": sorted(q.opened)}, open(os.path.join(scratch, f"queue{rank}.json"), "w"))
+    json.dump({"claimed": q.claimed, "opened": sorted(q.opened), "prefetched": sorted(q.prefetched)}, open(os.path.join(scratch, f"queue{rank}.json"), "w"))
 
 
 if __name__ == "__main__":
