@@ -29,13 +29,18 @@ namespace {
 // forward rows a group must hold per beam-search step of its longest read before it may close early (global mode):
 // forward ~29 M rows/s = 34 ns per row; a step costs 1.6-2.0 us (W <= 12), 2.7-3.1 us (W <= 25), 4-6 us beyond
 // Two regimes for the beam search of a global-mode group (a read's search is one serial chain of a step per sample):
-//  * FEW sequences (at most three waves per SIMD of the decode partition -- what its LDS keeps resident): on the partition's CUs, which the pipeline's
-//    forwards keep clear, a step costs 1.6-2.0 us (W <= 12), 2.7-3.1 us (W <= 25), 4-6 us beyond -- the group is worth
-//    closing as soon as its forward rows (34 ns each) cover the longest chain at that pace;
+//  * FEW sequences (at most three waves per SIMD of the decode partition -- what its LDS keeps resident): on the
+//    partition's CUs, which the group's forwards keep clear, a step costs 1.6-2.0 us (W <= 12), 2.7-3.1 us (W <= 25), 4-6 us
+//    beyond -- the group is worth closing as soon as its forward rows (34 ns each) cover the longest chain at that pace.
+//    Batches of few reads (long reads, small steps) are submitted to the partitioned forward lanes for this;
 //  * MANY sequences: the partition's few SIMDs would be the bottleneck (a saturated SIMD does ~0.15-0.45 M steps/s), so the
 //    search runs on the whole chip beside the next group's conv waves, where a wave gets about one instruction issue per
 //    MFMA -- 17 us per step measured at W = 10 (profiles/r03a_global_pipe_trace.txt) -- but hundreds of them run at once:
-//    the group keeps growing until its forward rows cover the longest chain at THAT pace.
+//    the group keeps growing until its forward rows cover the longest chain at THAT pace, and its forwards use every CU
+//    (batches of many reads go to the unpartitioned lanes).
+// Measured (tools/repro_refdefaults.py: 16 384 ragged reads, reference defaults + 12-mer LM, soft head): all on the whole
+// chip 25.0 M samples/s; the longest 288 reads of every group on the partition and the rest on the whole chip 18.8 M (the
+// partition becomes the bottleneck) -- hence no split inside a group, and no partition under batches of many reads.
 inline int64_t chain_rows(int W, bool on_partition)
 {
     static const long env = getenv("RD_CHAIN_ROWS") ? atol(getenv("RD_CHAIN_ROWS")) : 0;   // (measurements only)
@@ -393,9 +398,11 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
     ReadsPipe* p = nullptr;
     if ((rc = rpipe_get(ctx, &p))) return rc;
     const int n_lanes = ctx->pipe_lanes < 1 ? 1 : ctx->pipe_lanes;
-    // global mode: the forwards of this pipeline keep `part` CUs of every XCD clear and the beam search runs there
-    const int part = mode == 1 ? (ctx->part_mode < 0 ? auto_part_cus(W) : ctx->part_mode) : 0;
-    if (part && part != p->part_cus) {
+    // global mode, a batch of few reads (long reads, small steps): its forward keeps `part` CUs of every XCD clear and the
+    // group's beam search runs there at chain pace; a batch of many reads uses every CU (see chain_rows)
+    const int part_cus = mode == 1 ? (ctx->part_mode < 0 ? auto_part_cus(W) : ctx->part_mode) : 0;
+    const int part = part_cus && n_reads <= part_seq_limit(part_cus, W) / 2 ? part_cus : 0;
+    if (part && part != p->part_cus) {   // (part_cus of the pipe = the size its masked streams exist for)
         // another partition size (first use, or the beam width's class changed): drain, then new masked streams
         if ((rc = rd_rpipe_flush(ctx))) return rc;
         if (p->s_part) {
