@@ -124,7 +124,7 @@ struct ReadsPipe {
     hipStream_t s_part = nullptr;   // the decode partition's stream (global mode), masked to part_cus CUs of every XCD
     int part_cus = 0;
     RSlot slot[2];
-    RLane lane[RD_MAX_LANES];
+    RLane lane[2 * RD_MAX_LANES];   // per PHYSICAL lane: a lane and its partitioned twin are different streams, so each has its own staging / signal / descriptors
     int cur = 0;
     int next_lane = 0;
     int64_t submitted = 0, delivered = 0, launches = 0;
@@ -293,9 +293,11 @@ int open_slot(rd_ctx* ctx, ReadsPipe* p, int mode, int W, int f16, int use_lm, d
         if (want > s->cap_rows) {
             const int64_t cap = want + want / 4;
             // (nothing in flight reads this slot: its group was delivered)
-            if (s->probs.reserve((size_t)cap * 20) || (mode == 1 && s->mat.reserve((size_t)(cap + 1) * 40))) return RD_ERR_NOMEM;
+            if (s->probs.reserve((size_t)cap * 20)) return RD_ERR_NOMEM;
             s->cap_rows = cap;
         }
+        // the assembled matrix exists for global-mode groups only: sized when the first one arrives, whatever grew the slot before
+        if (mode == 1 && s->mat.reserve((size_t)(s->cap_rows + 1) * 40)) return RD_ERR_NOMEM;
     }
     s->mode = mode;
     s->part = part;
@@ -418,7 +420,7 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
     const int plane = lane + (part ? RD_MAX_LANES : 0);   // the lane's partitioned twin: same staging, masked stream, own activations
     FwdLane* L = nullptr;
     if ((rc = rd_lane_get(ctx, plane, &L))) return rc;
-    RLane& R = p->lane[lane];
+    RLane& R = p->lane[plane];
     const size_t n_samples = (size_t)read_off[n_reads];
     const int f16 = ctx->logits_f16;
 
@@ -521,6 +523,12 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
             sb.user_label_off.push_back((int64_t)w * chunk_len);
         }
         sb.n_seq = P.n_windows;
+    }
+    // (what the kernels below index: checked on the host before anything is launched)
+    if ((size_t)(s->rows + P.total_rows) * (f16 ? 10 : 20) > s->probs.cap || (n64 && (size_t)rows64 * 40 > s->mat.cap)) {
+        rd_set_error("internal: group buffers too small (%lld + %lld rows, %lld matrix rows; probs %zu B, matrix %zu B)", (long long)s->rows,
+                     (long long)P.total_rows, (long long)rows64, s->probs.cap, s->mat.cap);
+        return RD_ERR_STATE;
     }
     if (raw && (size_t)(s->n_reads + n_reads) * 4 > s->status.cap) {
         // growing moves the statuses already gathered for this group (few bytes; the lanes that wrote them must be done)
@@ -637,7 +645,7 @@ void rd_rpipe_destroy(rd_ctx* ctx)
         if (s.h_out) (void)hipHostFree(s.h_out);
         if (s.dec_done) (void)hipEventDestroy(s.dec_done);
     }
-    for (int i = 0; i < RD_MAX_LANES; i++) {
+    for (int i = 0; i < 2 * RD_MAX_LANES; i++) {
         RLane& R = p->lane[i];
         R.tiles.release();
         R.raw.release();

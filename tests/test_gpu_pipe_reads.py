@@ -212,3 +212,29 @@ def test_cli_driver_pipelined_equals_blocking(tmp_path):
                 for b in bes:
                     b.close()
         assert len(res[False]) == 90 and res[False] == res[True], mode
+
+
+def test_pipe_mode_and_partition_changes_between_batches(dev):
+    """Two bugs tests/fuzz_pipe.py found in the first version of the pipeline, as regression cases: (1) a group slot first grown by
+    a CHUNK-mode group had no assembled-matrix buffer when a GLOBAL-mode group used it next (out-of-bounds write of the assembly
+    kernel); (2) a batch of few reads (partitioned forward lane) and a batch of many reads (plain lane) of the same logical lane ran
+    on different streams but shared the lane's signal / descriptor buffers.  Alternating decode types and batch sizes, every
+    batch against the blocking call."""
+    rng = np.random.default_rng(99)
+    big = _ragged(rng, 200, lo=300, hi=1500)          # many reads: every CU, whole-chip beam search
+    small = _ragged(rng, 9, lo=2000, hi=9000)         # few reads: partitioned lane + partition decode
+    plan = [("chunk", big), ("global", small), ("global", big), ("global", small), ("chunk", small), ("global", big), ("global", small),
+            ("global", big)]
+    ref = [dev.basecall_raw_global(r, 4, CHUNK, 256, 6, False) if m == "global" else dev.basecall_raw_chunk(r, 4, CHUNK, 256, 6) for m, r in plan]
+    dev.pipe_flush()
+    dev.pipe_config(2)
+    dev.pipe_set_lanes(2)
+    tickets = [dev.pipe_submit_raw(m, r, 4, CHUNK, 256, 6, False) for m, r in plan]
+    for (m, r), t, (exp, st_exp) in zip(plan, tickets, ref):
+        got, st = t.result()
+        assert np.array_equal(st, st_exp)
+        if m == "global":
+            assert all(np.array_equal(a, b) for a, b in zip(got, exp))
+        else:
+            assert all(len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b)) for a, b in zip(got, exp))
+    dev.pipe_config(4)
