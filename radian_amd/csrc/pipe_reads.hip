@@ -402,7 +402,8 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
     const int n_lanes = ctx->pipe_lanes < 1 ? 1 : ctx->pipe_lanes;
     // global mode, a batch of few reads (long reads, small steps): its forward keeps `part` CUs of every XCD clear and the
     // group's beam search runs there at chain pace; a batch of many reads uses every CU (see chain_rows)
-    const int part_cus = mode == 1 ? (ctx->part_mode < 0 ? auto_part_cus(W) : ctx->part_mode) : 0;
+    // (the CU masks are laid out for 8 XCDs x 32 CUs: on any other device there is no partition)
+    const int part_cus = mode == 1 && ctx->n_cu == RD_XCDS * 32 ? (ctx->part_mode < 0 ? auto_part_cus(W) : ctx->part_mode) : 0;
     const int part = part_cus && n_reads <= part_seq_limit(part_cus, W) / 2 ? part_cus : 0;
     if (part && part != p->part_cus) {   // (part_cus of the pipe = the size its masked streams exist for)
         // another partition size (first use, or the beam width's class changed): drain, then new masked streams
