@@ -162,6 +162,9 @@ def driver_leg(device, pool, cli, lengths, seed, weights_flat, lm=None, warm_rea
             b.clone_artifacts_from(bes[0])
         for b in bes:
             b.set_decode_partition(args.decode_partition)
+            b.set_precision(args.precision)
+            b.set_logits(args.logits)
+            b.set_decode_math(args.decode_math)
         args._lm_loaded = lm is not None
         rng = np.random.default_rng(seed)
 
