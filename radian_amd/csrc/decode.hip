@@ -778,6 +778,395 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
     }
 }
 
+
+// ---- two sequences per wave (W <= 6) ------------------------------------------------------------------------------------
+// At the reference's default width (basecall.py:32: beam 6) a step has at most 30 candidates: half of a wave.  Here a wave
+// carries TWO sequences, lanes 0-31 and lanes 32-63 ("halves"), through the same step as beam_search_kernel<PT, 1, 1, ...>:
+// every phase is the one-wave kernel's with "wave-uniform" replaced by "uniform within the half" -- nb, next_id, the trie
+// pointers, the gate's signal side live in vector registers; ballots are taken per half; a branch is taken when either half
+// needs it and is a no-op for the lanes of the other; a half whose sequence has ended idles (valid = false everywhere) while
+// the other finishes.  Per issued instruction twice the sequences advance: the form for launches that are bound by
+// instruction issue (thousands of windows; waves beside a forward), not for a few long chains (a step is slower than the
+// one-sequence wave's).  No hashed contexts (the one-wave kernel takes those).
+template <typename PT, bool LM, bool GX>
+__global__ __launch_bounds__(64) void beam_search2_kernel(DecodeArgs a, int n_seq)
+{
+    // (117-129 VGPRs: beside two conv waves of 176-200 a SIMD has 112-160 left, so the wave fits next to the relu / match variants and
+    // waits for a slot next to two residual ones; capping it at 96 -- amdgpu_waves_per_eu -- puts spills into scratch memory)
+    constexpr int WM = 6;               // beams per sequence
+    constexpr int TS = 32;              // time steps per prepass tile: one lane of the half per step
+    constexpr int KG = 16;              // keys per pass of the ranking loop
+    constexpr int SEG = 32 + KG;        // doubles per key segment (<= 30 survivors + the padding of the last group)
+    constexpr int LOG_TN = 9, TN = 1 << LOG_TN;
+    const int lane = threadIdx.x;
+    const int h = lane >> 5;            // half = sequence slot of the wave
+    const int hl = lane & 31;           // lane inside the half = candidate index q
+    const int seq_raw = 2 * (int)blockIdx.x + h;
+    const bool have = seq_raw < n_seq;
+    const int seq = have ? seq_raw : n_seq - 1;          // (an odd last wave: the second half idles on valid addresses)
+    const int T = have ? a.seq_len[seq] : 0;
+    const PT* __restrict__ probs = (const PT*)a.probs;
+    const int64_t row_a = a.seq_off[seq];
+    const int64_t row_b = a.seq_off2 ? a.seq_off2[seq] : row_a;
+    const int split = a.seq_off2 ? a.seq_split[seq] : 0;
+    int4* __restrict__ childtab = a.childtab + a.node_off[seq];
+    int* __restrict__ backptr = a.backptr + a.node_off[seq];
+    const int W = a.W;
+    const unsigned ctx_mask = LM ? ((a.k >= 16) ? 0xffffffffu : ((1u << (2 * a.k)) - 1u)) : 0u;
+    const unsigned long long hmask = h ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+
+    __shared__ Beam st_[2][2][WM];
+    __shared__ __attribute__((aligned(16))) double scr_[2][5 * WM];      // cpy_pnb | cpy_pb | mb_v | mP | mQ
+    __shared__ __attribute__((aligned(16))) double keyC_[2][SEG];
+    __shared__ int mb_q_[2][WM], d_sel_[2][WM], newslot_[2][WM];
+    __shared__ unsigned claims_[2][WM];
+    __shared__ double lp_[2][TS][5];
+    __shared__ double praw_[LM ? 2 : 1][LM ? TS : 1][5];
+    __shared__ double sent_[LM ? 2 : 1][LM ? TS : 1];
+    __shared__ unsigned tab_[2][TN];
+    __shared__ uint64_t gx_lds[GX ? 256 : 1];
+    if constexpr (GX)
+        for (int i = lane; i < 256; i += 64) gx_lds[i] = g_gm_exp_tab[i];
+    const uint64_t* const gx_exp = gx_lds;
+
+    double* const cpy_pnb = scr_[h];
+    double* const cpy_pb = scr_[h] + WM;
+    double* const mb_v = scr_[h] + 2 * WM;
+    double* const mP = scr_[h] + 3 * WM;
+    double* const mQ = scr_[h] + 4 * WM;
+    double* const keyC = keyC_[h];
+    int* const mb_q = mb_q_[h];
+    int* const d_sel = d_sel_[h];
+    int* const newslot = newslot_[h];
+    unsigned* const claims = claims_[h];
+    unsigned* const tab = tab_[h];
+    double(*const lp)[5] = lp_[h];
+    double(*const praw)[5] = praw_[LM ? h : 0];
+    double* const sent = sent_[LM ? h : 0];
+
+    for (int i = hl; i < TN; i += 32) tab[i] = i == 0 ? 0u : 0xffffffffu;    // (the empty labeling: id 0 in slot 0)
+    if (hl == 0) {     // decode.py:128-132: the empty labeling with pr_blank = pr_total = log(1)
+        Beam& b = st_[h][0][0];
+        b.ptot = 0.0;
+        b.pb = 0.0;
+        b.pnb = -INFINITY;
+        b.last = -1;
+        b.len = 0;
+        b.node = 0;
+        b.hist = 0u;
+        b.hprev = 0u;
+        b.pad1 = 0;
+        for (int c = 0; c < 4; c++) b.child[c] = 0;
+        if (have) {
+            childtab[0] = make_int4(0, 0, 0, 0);
+            backptr[0] = 0;
+        }
+    }
+    int nb = 1;              // beams currently kept (uniform within the half)
+    int next_id = 1;         // next free trie node id of the half's sequence
+    int cur = 0;             // (both halves flip together; a half that has ended stops writing)
+    // the longer of the two sequences bounds the loop (wave-uniform)
+    const int T_other = __shfl_xor(T, 32);
+    const int Tmax = __builtin_amdgcn_readfirstlane(T > T_other ? T : T_other);
+    wave_sync();
+
+    for (int t0 = 0; t0 < Tmax; t0 += TS) {
+        // ---- per-tile prepass: one lane of the half per time step (decode.py:165,168,193,195; :135-138)
+        {
+            const int t = t0 + hl;
+            if (t < T) {
+                const PT* __restrict__ prow = probs + ((t < split ? row_a : row_b) + t) * 5;
+                double s4 = 0.0;
+#pragma unroll 1
+                for (int c = 0; c < 5; c++) {
+                    const double pc = (double)prow[c];
+                    lp[hl][c] = safe_log<GX>(pc);
+                    if constexpr (LM) {
+                        praw[hl][c] = pc;
+                        if (c < 4) s4 = c == 0 ? pc : s4 + pc;
+                    }
+                }
+                if constexpr (LM) {
+                    const double sN = s4;
+                    double ent = 0.0;
+                    bool any = false;
+#pragma unroll 1
+                    for (int c = 0; c < 4; c++) {
+                        const double pc = praw[hl][c];
+                        double n;
+                        if (sN == 0.0) n = pc;
+                        else if constexpr (sizeof(PT) == 4) n = (double)((float)pc / (float)sN);
+                        else n = pc / sN;
+                        if (n > 0) {
+                            double v = n * log_m<GX>(n);
+                            ent = any ? ent + v : v;
+                            any = true;
+                        }
+                    }
+                    sent[hl] = any ? -ent : 0.0;
+                }
+            }
+        }
+        wave_sync();
+
+        const int tend = (Tmax - t0) < TS ? (Tmax - t0) : TS;
+        for (int tt = 0; tt < tend; tt++) {
+            const bool live = t0 + tt < T;                  // this half's sequence still has a row (uniform within the half)
+            const Beam* __restrict__ os = st_[h][cur];
+            Beam* __restrict__ ns = st_[h][cur ^ 1];
+            const int ncand = live ? 5 * nb : 0;
+
+            // ---------------- Phase A (beam_search_kernel, Phase A: same reads, same selects)
+            const int q = hl;
+            bool valid = q < ncand;
+            const int bi = valid ? q / 5 : 0;
+            const int kk = q - 5 * (q / 5);
+            const bool is_copy = kk == 0;
+            const double lp_blank = lp[tt][4];
+            bool s_open = false;
+            if constexpr (LM) s_open = sent[tt] > a.s_thr;
+            const double ptot_last = os[nb - 1].ptot;
+            const int myn = os[hl < nb ? hl : 0].node;
+            const double2 pp = *(const double2*)&os[bi].ptot;
+            const double pnb_i = os[bi].pnb;
+            const int2 ll = *(const int2*)&os[bi].last;
+            int4 c4 = *(const int4*)&os[bi].child[0];
+            asm("" : "+v"(c4.x), "+v"(c4.y), "+v"(c4.z), "+v"(c4.w));
+            const int ci = (kk - 1) & 3;
+            const int c_lo = (ci & 1) ? c4.y : c4.x, c_hi = (ci & 1) ? c4.w : c4.z;
+            const int chx = (ci & 2) ? c_hi : c_lo;
+            if (hl < W) claims[hl] = 0u;
+            const unsigned my_e = tab[myn & (TN - 1)];
+            const int cc = is_copy ? ll.x : kk - 1;
+            double lpc = lp[tt][cc < 0 ? 0 : cc];
+            lpc = cc < 0 ? -INFINITY : lpc;
+            const int xch = (valid & !is_copy) ? chx : 0;
+            const unsigned p_e = tab[xch & (TN - 1)];
+            const bool self_bad = live & (hl < nb) & (my_e != ((((unsigned)myn >> LOG_TN) << 8) | (unsigned)hl));
+            const bool tab_ok = (__ballot(self_bad) & hmask) == 0ull;
+            const int last_i = ll.x;
+            if constexpr (LM) {
+                const int len_i = ll.y;
+                const int need = is_copy ? a.k + 1 : a.k;
+                if (s_open && valid && cc >= 0 && len_i >= need) {
+                    const unsigned hh = os[bi].hist;
+                    const unsigned ctx = (is_copy ? (hh >> 2) : hh) & ctx_mask;
+                    const bool gate = (a.lm_gate[ctx >> 5] >> (ctx & 31)) & 1u;
+                    if (gate) {
+                        const double r = a.lm_table[(size_t)ctx * 4 + cc];
+                        double val;
+                        if constexpr (sizeof(PT) == 4) {
+                            const float f0 = (float)praw[tt][0], f1 = (float)praw[tt][1], f2 = (float)praw[tt][2], f3 = (float)praw[tt][3];
+                            const float bp = ((f0 + f1) + f2) + f3;
+                            const float sb = (float)praw[tt][cc] / bp;
+                            val = ((r + (double)sb) / 2.0) * (double)bp;
+                        } else {
+                            const double bp = ((praw[tt][0] + praw[tt][1]) + praw[tt][2]) + praw[tt][3];
+                            const double sb = praw[tt][cc] / bp;
+                            val = ((r + sb) / 2.0) * bp;
+                        }
+                        lpc = safe_log<GX>(val);
+                    }
+                }
+            }
+            const double pnb_c = (last_i >= 0) ? pnb_i + lpc : -INFINITY;
+            const double pb_c = pp.x + lp_blank;
+            const double v = ((last_i == kk - 1) ? pp.y : pp.x) + lpc;
+            double c_pnb = is_copy ? pnb_c : v;
+            double c_pb = is_copy ? pb_c : -INFINITY;
+            double c_ptot = is_copy ? 0.0 : v;
+            int dcopy = is_copy ? bi : -1;
+            if (valid & is_copy) {
+                cpy_pnb[bi] = pnb_c;
+                cpy_pb[bi] = pb_c;
+                mb_q[bi] = -1;
+                newslot[bi] = -1;
+            }
+            int pj = (tab_ok & (xch != 0) & ((p_e >> 8) == ((unsigned)xch >> LOG_TN))) ? (int)(p_e & 0xffu) : -1;
+            if (__any(!tab_ok)) {    // two kept beams of a half share a table entry (rare): that half compares against every beam
+                for (int j = 0; j < WM; j++) {
+                    const int nj = os[j < nb ? j : 0].node;
+                    if (!tab_ok && j < nb && xch != 0 && nj == xch) pj = j;
+                }
+            }
+            const bool any_merge = __any(pj >= 0);          // in either half
+            wave_sync();
+
+            // ---------------- lae pass 1 / 2 (decode.py:174-175,199-201)
+            {
+                const bool mext = pj >= 0;
+                const double cp = cpy_pnb[mext ? pj : 0];
+                const double x = mext ? cp : c_pb;
+                const double y = mext ? c_ptot : c_pnb;
+                const double r = GX ? lae_gx(x, y, gx_exp) : lae(x, y);
+                c_ptot = is_copy ? r : c_ptot;
+                if (mext) {
+                    mb_q[pj] = q;
+                    mb_v[pj] = c_ptot;
+                    mQ[pj] = r;
+                }
+            }
+            if (any_merge) {
+                wave_sync();
+                {
+                    const int qe = mb_q[bi];
+                    const double mv = mb_v[bi];
+                    const bool m = valid & is_copy & (qe >= 0);
+                    const double r = GX ? lae_gx(c_ptot, m ? mv : -INFINITY, gx_exp) : lae(c_ptot, m ? mv : -INFINITY);
+                    if (m) mP[bi] = r;
+                }
+                wave_sync();
+                {
+                    const int j = is_copy ? bi : (pj >= 0 ? pj : 0);
+                    const int qe = mb_q[j];
+                    const double P = mP[j], Q = mQ[j], cb = cpy_pb[j];
+                    const bool merged = valid & (is_copy ? qe >= 0 : pj >= 0);
+                    const int qother = is_copy ? qe : 5 * j;
+                    const bool mk = merged & (q < qother);
+                    const bool mke = mk & !is_copy;
+                    c_ptot = mk ? P : c_ptot;
+                    c_pnb = mk ? Q : c_pnb;
+                    c_pb = mke ? cb : c_pb;
+                    dcopy = mke ? j : dcopy;
+                    valid = valid & (!merged | mk);
+                }
+            }
+
+            // ---------------- Phase D: rank by (pr_total desc, insertion order asc) among the candidates >= tau
+            const double key = valid ? c_ptot : __builtin_nan("");
+            const double tau = (nb == W) ? ptot_last + lp_blank : -INFINITY;
+            const bool surv = valid && key >= tau;
+            const unsigned mv32 = (unsigned)((__ballot(valid) & hmask) >> (32 * h));
+            const unsigned ms32 = (unsigned)((__ballot(surv) & hmask) >> (32 * h));
+            const int vcnt = __popc(mv32), scnt = __popc(ms32);
+            const int lidx = __popc(ms32 & ((1u << hl) - 1u));
+            // the whole tail of the segment is padding (the other half may have more survivors and sets the loop's trip count)
+            if (hl >= scnt) keyC[hl] = -INFINITY;
+            if (hl < KG) keyC[32 + hl] = -INFINITY;
+            wave_sync();
+            if (surv) keyC[lidx] = key;
+            wave_sync();
+            const int scnt_o = __shfl_xor(scnt, 32);
+            const int smax = __builtin_amdgcn_readfirstlane(scnt > scnt_o ? scnt : scnt_o);
+            int rank = 0;
+            for (int j = 0; j < smax; j += KG) {
+                double2 kq[KG / 2];
+#pragma unroll
+                for (int u = 0; u < KG / 2; u++) kq[u] = *(const double2*)&keyC[j + 2 * u];
+#pragma unroll
+                for (int u = 0; u < KG / 4; u++) rank = count4_gt(rank, kq[2 * u].x, kq[2 * u].y, kq[2 * u + 1].x, kq[2 * u + 1].y, key);
+            }
+            const int nb_new = vcnt < W ? vcnt : W;
+
+            // ---------------- Phase E: the kept candidates move to their new beam slot
+            auto scatter = [&](bool on) {
+                if (on && surv && rank < W) {
+                    const int r = rank;
+                    *(double2*)&ns[r].ptot = make_double2(c_ptot, c_pb);
+                    ns[r].pnb = c_pnb;
+                    d_sel[r] = (dcopy & 0xff) | (bi << 8) | (kk << 16);
+                    atomicAdd(&claims[r], 1u);
+                    if (dcopy >= 0) newslot[dcopy] = r;
+                }
+            };
+            scatter(true);
+            wave_sync();
+            const unsigned n_claims = claims[hl < nb_new ? hl : 0];
+            int sel = d_sel[hl < nb_new ? hl : 0];
+            int my_newslot = newslot[hl < nb ? hl : 0];
+            unsigned my_tn2 = tab[myn & (TN - 1)];
+            asm volatile("" : "+v"(sel), "+v"(my_newslot), "+v"(my_tn2));
+            const bool tie_h = ((__ballot((hl < nb_new) & (n_claims != 1u)) & hmask) != 0ull);
+            if (__any(tie_h)) {
+                // equal keys claimed one slot: redo the count with the insertion-order rule -- in the half that has the tie
+                int rank2 = 0;
+                for (int j = 0; j < smax; j++) {
+                    const double kv = keyC[j];
+                    rank2 += (j < scnt && ((kv > key) || (kv == key && j < lidx))) ? 1 : 0;
+                }
+                rank = tie_h ? rank2 : rank;
+                if (tie_h && hl < nb) newslot[hl] = -1;
+                wave_sync();
+                scatter(tie_h);
+                wave_sync();
+                sel = d_sel[hl < nb_new ? hl : 0];
+                my_newslot = newslot[hl < nb ? hl : 0];
+            }
+
+            // ---------------- Phase F: the new beam set: trie ids, labeling state
+            {
+                const bool act = live & (hl < nb_new);
+                const int j = act ? (sel & 0xff) : 0;
+                const int par = act ? (sel >> 8) & 0xff : 0;
+                const int cl = act ? (sel >> 16) - 1 : 0;
+                const bool is_ext = act && j == 0xff;
+                const int src = is_ext ? par : j;
+                const int4 meta = *(const int4*)&os[src].node;
+                const int2 sl2 = *(const int2*)&os[src].last;
+                const int4 chs = *(const int4*)&os[src].child[0];
+                const int nid_old = os[src].child[cl & 3];
+                const int ps = newslot[par];
+                if (live & (hl < nb) & (my_newslot < 0) & ((my_tn2 >> 8) == ((unsigned)myn >> LOG_TN))) tab[myn & (TN - 1)] = 0xffffffffu;
+                const bool fresh = is_ext && nid_old == 0;
+                const bool reload = is_ext && nid_old != 0;
+                const unsigned fm32 = (unsigned)((__ballot(fresh) & hmask) >> (32 * h));
+                const int my_node = fresh ? next_id + __popc(fm32 & ((1u << hl) - 1u)) : nid_old;
+                if (fresh) {
+                    backptr[my_node] = (meta.x << 2) | cl;
+                    ((int*)&childtab[meta.x])[cl] = my_node;
+                    childtab[my_node] = make_int4(0, 0, 0, 0);
+                }
+                next_id += __popc(fm32);
+                int4 ch = make_int4(0, 0, 0, 0);
+                if (__any(reload)) {
+                    __builtin_amdgcn_s_waitcnt(0);
+                    if (reload) {
+                        const int* cp = (const int*)&childtab[my_node];
+                        ch.x = __hip_atomic_load(cp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ch.y = __hip_atomic_load(cp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ch.z = __hip_atomic_load(cp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ch.w = __hip_atomic_load(cp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ch.x), "+v"(ch.y), "+v"(ch.z), "+v"(ch.w));
+                }
+                if (act) {
+                    const int new_node = is_ext ? my_node : meta.x;
+                    *(int2*)&ns[hl].last = make_int2(is_ext ? cl : sl2.x, is_ext ? sl2.y + 1 : sl2.y);
+                    const unsigned h_new = ((unsigned)meta.y << 2) | (unsigned)cl;
+                    *(int4*)&ns[hl].node = make_int4(new_node, is_ext ? (int)h_new : meta.y, meta.z, 0);
+                    *(int4*)&ns[hl].child[0] = make_int4(is_ext ? ch.x : chs.x, is_ext ? ch.y : chs.y, is_ext ? ch.z : chs.z, is_ext ? ch.w : chs.w);
+                    tab[new_node & (TN - 1)] = (((unsigned)new_node >> LOG_TN) << 8) | (unsigned)hl;
+                }
+                if (fresh && ps >= 0) ns[ps].child[cl] = my_node;
+            }
+            nb = live ? nb_new : nb;
+            cur ^= 1;
+            wave_sync();
+        }
+    }
+
+    // ---------------- traceback of each half's best labeling (decode.py:207-210)
+    int hl_end = hl;
+    asm volatile("" : "+v"(hl_end));
+    if (hl_end == 0 && have) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const DecodeArgs* ap = (const DecodeArgs*)ka;
+        const Beam& fs = st_[h][T & 1][0];              // (the half stopped writing after its T steps: buffer = parity of T)
+        int n = fs.node;
+        const int len = fs.len;
+        uint8_t* out = ap->labels + ap->label_off[seq];
+        for (int p = len - 1; p >= 0; p--) {
+            const int bp = __hip_atomic_load(&backptr[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out[p] = (uint8_t)(bp & 3);
+            n = bp >> 2;
+        }
+        ap->label_len[seq] = len;
+        if (ap->best_score) ap->best_score[seq] = fs.ptot;
+    }
+}
+
 // Launch shape.  W <= 12: one wave per sequence.  Wider beams have two forms: several waves per sequence (two for W <= 25,
 // four for W <= 51; one candidate per lane) -- the shortest time step, for launches that leave SIMDs idle (global decode of
 // a batch of reads) -- and fewer waves with two candidates per lane, which issues fewer instructions per sequence and keeps
@@ -806,8 +1195,29 @@ int launch_r(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
 }
 
 template <typename PT>
+int launch_two(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
+{
+    const dim3 grid((unsigned)((n_seq + 1) / 2));
+    if (lm) {
+        if (a.glibc_math) hipLaunchKernelGGL((beam_search2_kernel<PT, true, true>), grid, dim3(64), 0, st, a, n_seq);
+        else hipLaunchKernelGGL((beam_search2_kernel<PT, true, false>), grid, dim3(64), 0, st, a, n_seq);
+    } else {
+        if (a.glibc_math) hipLaunchKernelGGL((beam_search2_kernel<PT, false, true>), grid, dim3(64), 0, st, a, n_seq);
+        else hipLaunchKernelGGL((beam_search2_kernel<PT, false, false>), grid, dim3(64), 0, st, a, n_seq);
+    }
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+template <typename PT>
 int launch_pt(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm, int n_simd, int form)
 {
+    // W <= 6: two sequences per wave.  Measured (tools/decode_bench.py, 1024-row windows, W = 6): 4096 windows 1.23 -> 1.80 G time
+    // steps/s (glibc arithmetic 1.10 -> 1.55 G, soft rows 0.94 -> 1.32 G); 512 windows -- lone waves, the latency case -- 1.58 vs
+    // 1.60 ms per launch: a step of the two-sequence wave is as short as the one-sequence wave's, so there is no case for the
+    // latter (rd_set_decode_form 4 keeps it reachable for tests and A/B runs; 3 = the default's choice, spelled out)
+    (void)n_simd;
+    if (a.W <= 6 && !(lm && a.hashed) && form != 4 && n_seq >= 2) return launch_two<PT>(st, a, n_seq, lm);
     if (a.W <= Cfg<1, 1>::WM) return launch_r<PT, 1, 1>(st, a, n_seq, lm);
     // wide form while every wave still gets a SIMD of its own
     const bool mid = a.W <= Cfg<1, 2>::WM;

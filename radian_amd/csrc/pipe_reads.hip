@@ -45,13 +45,19 @@ inline int64_t chain_rows(int W, bool on_partition)
 {
     static const long env = getenv("RD_CHAIN_ROWS") ? atol(getenv("RD_CHAIN_ROWS")) : 0;   // (measurements only)
     if (env > 0) return env;
-    if (!on_partition) return W <= 12 ? 560 : W <= 25 ? 900 : 1500;
+    // (W <= 6: two sequences share a wave's instructions -- beam_search2_kernel -- so beside conv waves a sequence advances
+    // twice as fast per issued instruction)
+    if (!on_partition) return W <= 6 ? 300 : W <= 12 ? 560 : W <= 25 ? 900 : 1500;
     return W <= 12 ? 96 : W <= 25 ? 140 : 260;
 }
 // sequences the partition decodes at chain pace: three waves per SIMD (a sequence is 1 / 2 / 4 waves for W <= 12 / 25 / 51;
 // ~12 KiB of LDS per sequence keeps 13 resident per CU).  Measured at W = 10 on 64 SIMDs: 128 / 256 sequences 28.2 / 27.8 M
 // samples/s, 512 sequences 22.1 M (tools/global_pipe_bench.py)
-inline int part_seq_limit(int part_cus, int W) { return RD_XCDS * part_cus * 4 * 3 / (W <= 12 ? 1 : W <= 25 ? 2 : 4); }
+inline int part_seq_limit(int part_cus, int W)
+{
+    const int waves3 = RD_XCDS * part_cus * 4 * 3;      // three waves per SIMD
+    return W <= 6 ? 2 * waves3 : W <= 12 ? waves3 : W <= 25 ? waves3 / 2 : waves3 / 4;   // (W <= 6: two sequences per wave)
+}
 constexpr int64_t kGroupRowsCap = 96ll << 20;   // rows a group may gather while it waits for coverage (~6 GB of probabilities + matrix)
 // CUs per XCD of the decode partition for a beam width (rd_set_decode_partition -1): enough SIMDs that the partition's
 // beam-search rate stays above the forward's ~29 M rows/s when a group holds many short reads (a saturated SIMD steps

@@ -231,3 +231,76 @@ def test_sequence_too_long_for_the_backpointer_packing_is_refused():
         assert be.decode_batch(probs, [0], [8], W)[0].size == 0
     finally:
         be.close()
+
+
+def test_two_sequences_per_wave_form(be, golden_dir, oracle):
+    """W <= 6 as two sequences per wave (beam_search2_kernel; rd_set_decode_form 3): every golden case of those widths -- no-LM
+    incl. the exact-0 / duplicated-row matrices, LM with k in {1, 3, 5} -- with bit-exact winner scores in glibc arithmetic; then
+    batches against the oracle where the two halves of a wave carry sequences of different lengths (incl. empty ones and an odd
+    sequence count), float32 / float64 / exact-tie ("quant") rows, both arithmetics, with and without an LM."""
+    from test_gpu_decode_stress import _mats
+    be.set_decode_form("two")
+    try:
+        g = json.load(open(os.path.join(golden_dir, "beam_nolm_cases.json")))
+        mats = np.load(os.path.join(golden_dir, "beam_nolm_mats.npz"))
+        cases = [c for c in g["cases"] if c["W"] <= 6]
+        assert len(cases) >= 60
+        for math in ("glibc", "fast"):
+            be.set_decode_math(math)
+            # all cases of one width in ONE batch: neighbours share waves
+            for W in sorted({c["W"] for c in cases}):
+                cs = [c for c in cases if c["W"] == W]
+                rows = np.concatenate([mats[c["mat"]].reshape(-1, 5) for c in cs])
+                lens = np.array([mats[c["mat"]].shape[0] for c in cs], dtype=np.int32)
+                off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+                got, sc = be.decode_batch(rows, off, lens, W, with_scores=True)
+                for c, lab, s in zip(cs, got, sc):
+                    assert s_of(lab) == c["seq"], (math, c["mat"], W)
+                    if math == "glibc" and "final" in c:
+                        exp = fdec(c["final"][0]["pr_total"])
+                        assert s == exp or (np.isnan(exp) and np.isnan(s)), (c["mat"], W, float(s).hex(), c["final"][0]["pr_total"])
+        gl = json.load(open(os.path.join(golden_dir, "beam_lm_cases.json")))
+        ml = np.load(os.path.join(golden_dir, "beam_lm_mats.npz"))
+        be.set_decode_math("glibc")
+        cur, n_lm = None, 0
+        for c in gl["cases"]:
+            if c["W"] > 6:
+                continue
+            if cur != c["lm"]:
+                be.load_lm(ml[c["lm"]], c["k"])
+                cur = c["lm"]
+            mat = ml[c["mat"]]
+            # the same sequence in both halves of a wave and alone in a wave (odd count): three copies
+            rows = np.concatenate([mat.reshape(-1, 5)] * 3)
+            T = mat.shape[0]
+            got = be.decode_batch(rows, [0, T, 2 * T], [T, T, T], c["W"], use_lm=True, s_threshold=fdec(c["s_thr"]), r_threshold=fdec(c["r_thr"]))
+            assert all(s_of(x) == c["seq"] for x in got), (c["mat"], c["k"], c["W"])
+            n_lm += 1
+        assert n_lm >= 100
+        be.load_lm(None, 0)
+        # random batches against the oracle: ragged lengths, so the halves of a wave end at different steps
+        rng = np.random.default_rng(66)
+        table = rng.dirichlet([0.3] * 4, size=4 ** 3)
+        for kind in ("flat", "peaky", "blocky", "quant"):
+            for dt in (np.float32, np.float64):
+                for W in (1, 2, 3, 6):
+                    m, off, lens = _mats(rng, 301, 260, kind, dt)
+                    lens[::7] = 0
+                    lens[5] = 1
+                    for math in ("glibc", "fast"):
+                        if kind == "quant" and math == "fast":
+                            continue            # (exact ties are the glibc arithmetic's promise, DESIGN.md 2)
+                        be.set_decode_math(math)
+                        for lm in (False, True):
+                            if lm:
+                                be.load_lm(table, 3)
+                            exp = oracle.beam_search_batch(m, off, lens, W, table if lm else None, 0.4, 0.9, 3 if lm else 0)
+                            got = be.decode_batch(m, off, lens, W, use_lm=lm, s_threshold=0.4, r_threshold=0.9)
+                            bad = [i for i in range(len(lens)) if not np.array_equal(got[i], exp[i])]
+                            assert not bad, (kind, dt.__name__, W, math, lm, bad[:6], len(bad))
+                            if lm:
+                                be.load_lm(None, 0)
+    finally:
+        be.load_lm(None, 0)
+        be.set_decode_form("auto")
+        be.set_decode_math("glibc")

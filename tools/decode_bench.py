@@ -29,7 +29,7 @@ for name, scale in (("bench weights (saturated rows)", 1.0), ("soft head x0.05",
         valid = np.ascontiguousarray(valid_w, dtype=np.int32)
         labels = np.zeros((n, T), np.uint8)
         lens = np.zeros(n, np.int32)
-        for W, form, math in ((1, "auto", "fast"), (6, "auto", "fast"), (10, "auto", "fast"), (10, "auto", "glibc"), (25, "waves", "fast"),
+        for W, form, math in ((1, "one", "fast"), (1, "two", "fast"), (6, "one", "fast"), (6, "two", "fast"), (6, "one", "glibc"), (6, "two", "glibc"), (10, "auto", "fast"), (10, "auto", "glibc"), (25, "waves", "fast"),
                               (25, "lanes", "fast"), (25, "auto", "fast"), (25, "auto", "glibc")):
             be.set_decode_form(form)
             be.set_decode_math(math)

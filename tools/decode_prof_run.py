@@ -15,6 +15,8 @@ if soft:
 be.load_weights(w)
 if hasattr(be, "set_decode_math"):
     be.set_decode_math(sys.argv[4] if len(sys.argv) > 4 else "fast")   # profiles/r02d_*: the fast arithmetic (round 1's decoder has no other)
+if len(sys.argv) > 5 and hasattr(be, "set_decode_form"):
+    be.set_decode_form(sys.argv[5])        # "one" / "two": W <= 6 as one / two sequences per wave (round 3)
 reads = synthetic.synthetic_reads(n // 8, 4096, seed=5)
 win, valid = synthetic.reads_to_windows(reads, T, 512)[:2]
 win = np.ascontiguousarray(win, dtype=np.float32)
