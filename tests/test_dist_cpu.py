@@ -334,3 +334,72 @@ def test_connect_fails_fast_when_a_peer_fails_while_this_rank_is_inside_init(tmp
     rcs, _ = launch.run_ranks(3, [sys.executable, str(script)])
     assert rcs[0] == 3 or rcs[2] == 3, rcs       # a stuck rank left first; wait_all then stopped the rest
     assert all(rc != 0 for rc in rcs) and time.time() - t0 < 40, rcs
+
+
+def test_stream_merger_any_interleaving(tmp_path):
+    """launch.StreamMerger against adversarial timing: rank files that grow in random increments (partial lines included), claims
+    announced long before their records, claims whose reads are all skipped, ranks that end early, ranks without a queue (static
+    sharding: no claim marks).  Whatever the interleaving: every record once, in key order, and a record is never written before a
+    smaller key that some rank can still produce."""
+    import random
+    from radian_amd import launch
+    rnd = random.Random(5)
+    for trial in range(30):
+        world = rnd.randint(1, 6)
+        with_claims = rnd.random() < 0.7
+        # the job: files with reads; blocks handed to ranks in key order
+        blocks, fi = [], 0
+        for fi in range(rnd.randint(1, 5)):
+            n, lo = rnd.randint(0, 60), 0
+            while lo < n:
+                hi = min(n, lo + rnd.randint(1, 16))
+                blocks.append((fi, lo, hi))
+                lo = hi
+        owner = [rnd.randrange(world) for _ in blocks]
+        skipped = {(f, r) for (f, lo, hi) in blocks for r in range(lo, hi) if rnd.random() < 0.15}
+        lines = [[] for _ in range(world)]
+        for (f, lo, hi), o in zip(blocks, owner):
+            if with_claims:
+                lines[o].append(json.dumps({"claim": [f, lo, hi]}))
+            for r in range(lo, hi):
+                if (f, r) not in skipped:
+                    lines[o].append(json.dumps([[f, r], f"id{f}-{r}", "ACGT"[(f + r) % 4] * 3]))
+        if with_claims:      # a rank announces a claim as soon as it makes it: move the marks ahead of earlier records at random
+            for o in range(world):
+                ls, i = lines[o], 0
+                while i < len(ls):
+                    if ls[i].startswith('{"claim"') and i > 0 and rnd.random() < 0.5:
+                        j = rnd.randint(max(0, i - 20), i)
+                        # (never ahead of an EARLIER claim mark: claims are made in order)
+                        while j < i and any(x.startswith('{"claim"') for x in ls[j:i]):
+                            j += 1
+                        ls.insert(j, ls.pop(i))
+                    i += 1
+        data = [("\n".join(ls + [json.dumps({"end": True})]) + "\n").encode() for ls in lines]
+        scratch = tmp_path / f"s{trial}"
+        out = tmp_path / f"o{trial}"
+        scratch.mkdir()
+        out.mkdir()
+        pos = [0] * world
+        fhs = [open(scratch / f"rank{r}.jsonl", "wb") for r in range(world)]
+        m = launch.StreamMerger(str(scratch), world, str(out))
+        written = 0
+        while any(pos[r] < len(data[r]) for r in range(world)):
+            r = rnd.choice([x for x in range(world) if pos[x] < len(data[x])])
+            k = rnd.randint(1, 200)
+            fhs[r].write(data[r][pos[r]: pos[r] + k])
+            fhs[r].flush()
+            pos[r] += k
+            if rnd.random() < 0.5:
+                m.poll()
+                assert m.n >= written
+                written = m.n
+        for f in fhs:
+            f.close()
+        n = m.finish()
+        exp = [(f"id{f}-{r}", ("ACGT"[(f + r) % 4] * 3)[::-1]) for (f, lo, hi) in blocks for r in range(lo, hi) if (f, r) not in skipped]
+        got = []
+        for i in range(n // 1000 + 1):
+            ls = open(out / f"reads-{i}.fasta").read().split("\n")[:-1]
+            got += [(ls[j][1:], ls[j + 1]) for j in range(0, len(ls), 2)]
+        assert n == len(exp) and got == exp, (trial, world, with_claims)
