@@ -40,7 +40,8 @@ namespace {
 //    (batches of many reads go to the unpartitioned lanes).
 // Measured (tools/repro_refdefaults.py: 16 384 ragged reads, reference defaults + 12-mer LM, soft head): all on the whole
 // chip 25.0 M samples/s; the longest 288 reads of every group on the partition and the rest on the whole chip 18.8 M (the
-// partition becomes the bottleneck) -- hence no split inside a group, and no partition under batches of many reads.
+// partition becomes the bottleneck) -- hence no split inside a group, and no partition under batches of many reads (forced there
+// with two sequences per wave and longest-first order: 20.0 M at 3 or 4 CUs per XCD, 18.0 M at 6).
 inline int64_t chain_rows(int W, bool on_partition)
 {
     static const long env = getenv("RD_CHAIN_ROWS") ? atol(getenv("RD_CHAIN_ROWS")) : 0;   // (measurements only)
@@ -212,6 +213,12 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
     s.n64 = (int)s.order.size();
     for (size_t i = 0; i < n; i++)
         if (!s.seqs[i].is64) s.order.push_back((int)i);
+    // longest first inside each run: workgroups are dispatched in index order as slots free up, so the long chains start at once
+    // and the short ones fill in behind them (a launch then takes max(longest chain, work / rate) instead of rounds x longest), and
+    // the two sequences that share a wave at W <= 6 have similar lengths
+    auto by_len = [&](int x, int y) { return s.seqs[x].len != s.seqs[y].len ? s.seqs[x].len > s.seqs[y].len : x < y; };
+    std::sort(s.order.begin(), s.order.begin() + s.n64, by_len);
+    std::sort(s.order.begin() + s.n64, s.order.end(), by_len);
     const size_t a8 = align_up(n * 8, 256), a4 = align_up(n * 4, 256);
     const size_t o_off2 = a8, o_node = 2 * a8, o_lab = 3 * a8, o_len = 4 * a8, o_split = o_len + a4, o_llen = o_split + a4;
     const size_t meta_bytes = o_llen + a4;
