@@ -145,7 +145,7 @@ def total_note(lengths, dt):
     return f"{int(np.sum(lengths)) / dt / 1e6:.2f} M samples/s ({dt:.2f} s)"
 
 
-def driver_leg(device, pool, cli, lengths, seed, weights_flat, lm=None, warm_reads=256, desc=""):
+def driver_leg(device, pool, cli, lengths, seed, weights_flat, lm=None, warm_reads=1536, desc=""):
     """A job through the product's driver loop (radian_amd.basecall.run = basecall.py:69-141) with the CLI flags `cli`:
     host int16 reads -> H2D -> MAD normalisation on the device -> streamed forward -> (assembly) -> beam search -> labels to
     the host -> strings (chunk mode: simple_assembly natively on host threads), results in input order; everything but fast5
@@ -176,7 +176,7 @@ def driver_leg(device, pool, cli, lengths, seed, weights_flat, lm=None, warm_rea
                 dt = time.perf_counter() - t0
             assert len(res) == len(lens) and all(len(r[2]) > 0 for r in res)
             return dt, float(np.mean([len(r[2]) for r in res]))
-        go(lengths[:warm_reads])                  # warm-up: allocations, worker start
+        go(lengths[:warm_reads])                  # warm-up with full-size device batches on every forward lane: allocations happen here
         dt, mean_bases = go(lengths)
         note(f"  {total_note(lengths, dt)}")
     finally:
