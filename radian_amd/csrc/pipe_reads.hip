@@ -290,7 +290,8 @@ int close_group(rd_ctx* ctx, ReadsPipe* p)
 }
 
 // a group that can take `rows` more probability rows with these decode parameters; closes / recycles groups as needed
-int open_slot(rd_ctx* ctx, ReadsPipe* p, int mode, int W, int f16, int use_lm, double s_thr, double r_thr, int part, int64_t rows, RSlot** out)
+int open_slot(rd_ctx* ctx, ReadsPipe* p, int mode, int W, int f16, int use_lm, double s_thr, double r_thr, int part, int64_t rows,
+              int64_t expect_rows, RSlot** out)
 {
     int rc;
     RSlot* s = &p->slot[p->cur];
@@ -302,7 +303,10 @@ int open_slot(rd_ctx* ctx, ReadsPipe* p, int mode, int W, int f16, int use_lm, d
     }
     if (s->busy && (rc = slot_collect(p, *s))) return rc;   // the slot's previous group goes to its callers first
     if (s->seqs.empty()) {
-        const int64_t want = rows > s->grow_hint ? rows : s->grow_hint;
+        // room for the group this batch will probably become (expect_rows: what covers its longest read's chain), so that a
+        // group closes because it is covered, not because its slot happens to be small
+        int64_t want = rows > s->grow_hint ? rows : s->grow_hint;
+        if (expect_rows > want) want = expect_rows;
         if (want > s->cap_rows) {
             const int64_t cap = want + want / 4;
             // (nothing in flight reads this slot: its group was delivered)
@@ -478,7 +482,13 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
 
     // ---- the group this batch joins (may close / deliver earlier groups)
     RSlot* s = nullptr;
-    if ((rc = open_slot(ctx, p, mode, W, f16, use_lm, s_thr, r_thr, part, P.total_rows, &s))) return rc;
+    int64_t expect_rows = 0;
+    if (mode == 1) {
+        int64_t longest_b = 0;
+        for (int r = 0; r < n_reads; r++) longest_b = std::max<int64_t>(longest_b, read_off[r + 1] - read_off[r]);
+        expect_rows = std::min<int64_t>(kGroupRowsCap, chain_rows(W, part != 0) * longest_b + 2 * P.total_rows);
+    }
+    if ((rc = open_slot(ctx, p, mode, W, f16, use_lm, s_thr, r_thr, part, P.total_rows, expect_rows, &s))) return rc;
 
     // ---- its sequences (and, in global mode, the per-read assembly records), not yet part of the group
     RSub sb;
@@ -602,6 +612,9 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
         // global mode: by coverage of the longest read's chain (see chain_rows), not by a batch count
         const bool few = part && (int)s->seqs.size() <= part_seq_limit(part, W);
         close = s->rows >= chain_rows(W, few) * s->longest || s->rows >= kGroupRowsCap;
+        // (the very first group of a context closes with its first batch: nothing is decoding yet, and its chains start one
+        // group's forward time earlier -- a quarter of a second on a job of long reads)
+        close = close || p->launches == 0;
     } else {
         close = (int)s->subs.size() >= ctx->pipe_group;
     }
