@@ -102,6 +102,37 @@ __device__ __forceinline__ void wait_dma_and_barrier()
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LEAVE) : "memory");
 }
 
+// ReLU of an accumulator.  Written as `v > 0 ? v : 0` hipcc emits v_max v, v, v (quieting a possible signalling NaN) in front
+// of the v_max with 0: 128 extra vector instructions per wave in the epilogue.
+__device__ __forceinline__ float relu_raw(float v)
+{
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// 16-B global access at a wave-uniform base (kept in scalar registers: the asm is opaque to hipcc) + a per-lane BYTE offset:
+// `global_* v, voffset, s[base:base+1]`.  (Left alone, hipcc folds base + lane offset into one 64-bit vector address and then
+// spends two vector adds per further row of the tile; `zext(off) << 2` would not match the scalar-base form either.)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __attribute__((address_space(1))) char* sgpr_base(const void* p)
+{
+    uint64_t u = (uint64_t)p;
+    asm("" : "+s"(u));
+    return (__attribute__((address_space(1))) char*)u;
+}
+__device__ __forceinline__ float4 gload16(const void* sbase, unsigned byte_off)
+{
+    asm("" : "+v"(byte_off));   // (keeps the 32-bit offset's zero-extension in the block of the access, where the selector can see it)
+    const f32x4 v = *(const __attribute__((address_space(1))) f32x4*)(sgpr_base(sbase) + byte_off);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void gstore16(void* sbase, unsigned byte_off, float4 v)
+{
+    asm("" : "+v"(byte_off));
+    *(__attribute__((address_space(1))) f32x4*)(sgpr_base(sbase) + byte_off) = f32x4{v.x, v.y, v.z, v.w};
+}
+
 // WM = waves along M (64 time steps each): 2 -> the 256-thread, 128-row tile, two workgroups per CU (the product's shape);
 // 4 -> a 512-thread, 256-row tile, one workgroup per CU: the B (weight) tile is shared by twice the rows, so a CU moves
 // (256 + 256) x 64 B = 32 KiB per chunk by LDS-DMA instead of 2 x (128 + 256) x 64 B = 48 KiB for the same FLOPs
@@ -298,21 +329,58 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
             const float* __restrict__ resw = a.resid + (size_t)sd.seg_row * RD_C;      // block input (separate tensor)
             const float* __restrict__ resalt = a.resid + (size_t)sd.alt_row * RD_C;
             const bool interior = sd.t0 + 32 <= T;
-#pragma unroll
-            for (int np = 0; np < NT / 2; np++) {
-                // ---- accumulators (ReLU) -> LDS patch
+            // this lane's accumulators of N tiles 2 np, 2 np + 1 (ReLU) -> the wave's LDS patch
+            auto to_patch = [&](int np) {
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     const int n = 2 * np + j;
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
                         const int rl = (e & 3) + 8 * (e >> 2) + 4 * fh;
-                        const float v = acc[m][n][e];   // bias included since the start
-                        ts[rl * TSTR + j * 32 + fr] = v > 0.f ? v : 0.f;
+                        ts[rl * TSTR + j * 32 + fr] = relu_raw(acc[m][n][e]);   // bias included since the start
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+            };
+            // Fast path (every stream tile but a segment's last): the 32 rows are all inside the segment and on one side of the
+            // residual switch, so every address is a wave-uniform base + one per-lane offset -- no per-row selects or 64-bit
+            // vector adds.  That matters more than it looks: beside the CU partner's MFMA stream a vector instruction of this
+            // wave issues about once per MFMA (tools/probe/mfma_valu_probe.hip), so the epilogue's length IS its vector
+            // instruction count.  The block input added here is a previous block's output, i.e. already ReLU'd (>= +0): the sum
+            // with ReLU(acc) cannot be negative and the second ReLU of keras-tcn's block is the identity on it -- dropped.
+            const bool res_one = EPI != EPI_RES_IDENT || sd.t0 + 32 <= sd.alt_res || sd.t0 >= sd.alt_res;
+            if (EPI != EPI_RES_MATCH && interior && res_one) {
+                const unsigned lbyte = (rrow * RD_C + c4) * 4;
+                float* __restrict__ ob = outw + (size_t)sd.t0 * RD_C + wn * (NT * 32);
+                const float* __restrict__ rb = (sd.t0 < sd.alt_res ? resw : resalt) + (size_t)sd.t0 * RD_C + wn * (NT * 32);
+#pragma unroll
+                for (int np = 0; np < NT / 2; np++) {
+                    to_patch(np);
+#pragma unroll
+                    for (int ih = 0; ih < 8; ih += 4) {   // (four rows at a time: 16 residual registers live, not 32)
+                        float4 rv[4];
+                        if constexpr (EPI == EPI_RES_IDENT) {
+#pragma unroll
+                            for (int i = 0; i < 4; i++) rv[i] = gload16(rb + np * 64 + (ih + i) * 4 * RD_C, lbyte);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            float4 v = *(const float4*)(ts + ((ih + i) * 4 + rrow) * TSTR + c4);
+                            if constexpr (EPI == EPI_RES_IDENT) {
+                                v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
+                            }
+                            gstore16(ob + np * 64 + (ih + i) * 4 * RD_C, lbyte, v);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                continue;
+            }
+#pragma unroll
+            for (int np = 0; np < NT / 2; np++) {
+                to_patch(np);
                 // ---- LDS patch -> (residual) -> global, 16 B per lane
                 const int ch = wn * NT * 32 + np * 64 + c4;
                 float4 wm4 = make_float4(0.f, 0.f, 0.f, 0.f), bm4 = wm4;
@@ -320,35 +388,36 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
                     wm4 = *(const float4*)(a.wmatch + ch);
                     bm4 = *(const float4*)(a.bmatch + ch);
                 }
-                float4 rv[8];
-                int tt[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int t = sd.t0 + i * 4 + rrow;
-                    tt[i] = t;
-                    if constexpr (EPI == EPI_RES_IDENT) {
-                        const int tc = (interior || t < T) ? t : T - 1;
-                        rv[i] = *(const float4*)((tc < sd.alt_res ? resw : resalt) + (size_t)tc * RD_C + ch);
-                    }
-                }
+                for (int ih = 0; ih < 8; ih += 4) {   // four rows at a time (registers: see the fast path)
+                    float4 rv[4];
+                    int tt[4];
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    float4 v = *(const float4*)(ts + (i * 4 + rrow) * TSTR + c4);
-                    const int t = tt[i];
-                    const bool inb = interior || t < T;
-                    if constexpr (EPI == EPI_RES_IDENT) {
-                        v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
-                        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
-                        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-                    } else if constexpr (EPI == EPI_RES_MATCH) {
-                        const float xv = a.x[(size_t)sd.src_row + (inb ? t : T - 1)];
-                        v.x = (bm4.x + xv * wm4.x) + v.x; v.y = (bm4.y + xv * wm4.y) + v.y;
-                        v.z = (bm4.z + xv * wm4.z) + v.z; v.w = (bm4.w + xv * wm4.w) + v.w;
-                        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
-                        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                    for (int i = 0; i < 4; i++) {
+                        const int t = sd.t0 + (ih + i) * 4 + rrow;
+                        tt[i] = t;
+                        if constexpr (EPI == EPI_RES_IDENT) {
+                            const int tc = (interior || t < T) ? t : T - 1;
+                            rv[i] = *(const float4*)((tc < sd.alt_res ? resw : resalt) + (size_t)tc * RD_C + ch);
+                        }
                     }
-                    float4* dst = inb ? (float4*)(outw + (size_t)t * RD_C + ch) : sink4;
-                    *dst = v;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        float4 v = *(const float4*)(ts + ((ih + i) * 4 + rrow) * TSTR + c4);
+                        const int t = tt[i];
+                        const bool inb = interior || t < T;
+                        if constexpr (EPI == EPI_RES_IDENT) {
+                            v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;   // (>= +0: see the fast path)
+                        } else if constexpr (EPI == EPI_RES_MATCH) {
+                            const float xv = a.x[(size_t)sd.src_row + (inb ? t : T - 1)];
+                            v.x = (bm4.x + xv * wm4.x) + v.x; v.y = (bm4.y + xv * wm4.y) + v.y;
+                            v.z = (bm4.z + xv * wm4.z) + v.z; v.w = (bm4.w + xv * wm4.w) + v.w;
+                            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                            v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                        }
+                        float4* dst = inb ? (float4*)(outw + (size_t)t * RD_C + ch) : sink4;
+                        *dst = v;
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
