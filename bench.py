@@ -330,7 +330,9 @@ def main():
     ap.add_argument("--conv-shape", type=int, default=0, choices=[0, 1],
                     help="fp32 conv workgroup shape: 0 = 128 x 256 tiles, two workgroups per CU (product); 1 = 256 x 256, one per CU (measurement)")
     ap.add_argument("--cpu-reads", type=int, default=0, help="reads in the CPU-baseline sample (0: sized to the usable core count)")
-    ap.add_argument("--e2e-reads", type=int, default=8192, help="reads of the raw end-to-end secondary leg")
+    ap.add_argument("--e2e-reads", type=int, default=32768,
+                    help="reads of the raw end-to-end secondary leg (the other driver legs take a half or a sixteenth of it): jobs of a few "
+                         "seconds each, so that the fill and drain of the beam-search groups are a few per cent of a leg, as in a real run")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -641,7 +643,8 @@ def main():
                  "configs[2] end to end with the soft head: ~200-base fragments per window through the stitch (difflib's placement rule)"),
                 ("secondary_reference_defaults", ["--rna-threshold", "0.5"], ragged_lengths(args.e2e_reads // 2, 72), soft, (table, 11),
                  "the reference's own defaults (basecall.py:24-35): --decode-type global, step 128, beam 6, 12-mer LM (4^11-row table), "
-                 "thresholds 0.5 / 0.5, on ragged reads with the soft head"),
+                 "thresholds 0.5 / 0.5, on ragged reads with the soft head (a job of a few seconds: on a quarter of the reads the fill and "
+                 "drain of the beam-search groups were a third of the run and the figure 23 M)"),
                 ("secondary_long_reads", ["--rna-threshold", "0.5"], np.full(max(256, args.e2e_reads // 16), 100000, dtype=np.int64), soft, (table, 11),
                  "reference defaults on LONG reads (100 000 samples each: one read's beam search is a 0.2-s serial chain)"),
             )

@@ -16,8 +16,8 @@ rows = f"""| quantity (one MI355X, driver-timed: `profiles/r03_bench.json`) | ro
 | `secondary_e2e_raw`: host int16 → … → strings, {d['secondary_e2e_raw']['reads']} uniform reads, chunk W = 10 | 25.4 M (two contexts, 4 stitch processes) | {M('secondary_e2e_raw'):.1f} M (one context) |
 | `secondary_e2e_raw_ragged`: the same on log-normal read lengths (1.5 k … 60 k, median 9 k): a plan per batch | — | {M('secondary_e2e_raw_ragged'):.1f} M |
 | `secondary_e2e_raw_soft_head`: configs[2] end to end on soft rows | (3.6 M with the Python stitch, measured this round) | **{M('secondary_e2e_raw_soft_head'):.1f} M** (`rd_stitch_chunk`) |
-| `secondary_reference_defaults`: the reference's defaults (global, step 128, beam 6, 12-mer LM), {d['secondary_reference_defaults']['reads']} ragged reads, soft head, ~{d['secondary_reference_defaults']['mean_bases_per_read']:.0f} bases per read | — (builder-run 25 M on uniform reads, saturated rows) | {M('secondary_reference_defaults'):.1f} M in a {d['secondary_reference_defaults']['seconds']:.1f}-s job (fill and drain of the groups are a third of it; 17.5 M before the two-sequence wave and the table-lookup label strings); 24–25 M on 16 384 reads (`tools/repro_refdefaults.py`) |
-| `secondary_long_reads`: reference defaults, {d['secondary_long_reads']['reads']} reads × 100 000 samples | 19–26 M (builder-run, two contexts, 50 GB batches) | {M('secondary_long_reads'):.1f} M (4096-unit batches, groups on the decode partition) |
+| `secondary_reference_defaults`: the reference's defaults (global, step 128, beam 6, 12-mer LM), {d['secondary_reference_defaults']['reads']} ragged reads, soft head, ~{d['secondary_reference_defaults']['mean_bases_per_read']:.0f} bases per read | — (builder-run 25 M on uniform reads, saturated rows) | **{M('secondary_reference_defaults'):.1f} M** in a {d['secondary_reference_defaults']['seconds']:.1f}-s job (23.2 M on a quarter of the reads, a 2.1-s job of which the fill and drain of the groups were a third; 17.5 M there before the two-sequence wave and the table-lookup label strings) |
+| `secondary_long_reads`: reference defaults, {d['secondary_long_reads']['reads']} reads × 100 000 samples | 19–26 M (builder-run, two contexts, 50 GB batches) | **{M('secondary_long_reads'):.1f} M** in a {d['secondary_long_reads']['seconds']:.1f}-s job (4096-unit batches, groups on the decode partition; 22.0 M on a quarter of the reads: the last group's 0.2-s chains drain alone) |
 | `secondary_bf16x3` / `secondary_f16x3` | 33.9 / 58 M | {M('secondary_bf16x3'):.1f} / {M('secondary_f16x3'):.1f} M |
 | beam search alone, 512 windows, W = 10: `decode_timesteps_per_s` (glibc arithmetic) and `decode_hbm_frac` = × 20 B ÷ 8 TB/s | 243 M | {r['decode_timesteps_per_s']/1e6:.0f} M; {r['decode_hbm_frac']:.1e} of HBM — issue / latency bound, as SURVEY §8d predicted |
 | `cpu_baseline` (oracle port, {d['cpu_baseline']['cores']} threads / one thread) | 83 k / 5.3 k samples/s | {d['cpu_baseline']['value']/1e3:.0f} k / {d['cpu_baseline']['single_thread']['value']/1e3:.1f} k |
