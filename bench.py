@@ -224,14 +224,14 @@ def global_leg(device, batches_host, read_off, reads_per_batch, steps, W, table,
         nb_host = len(batches_host)
         # ---- one context, pipelined
         be = bes[0]
-        ring = [(np.zeros(reads_per_batch * READ_LEN + 1, dtype=np.uint8), np.full(reads_per_batch, -1, dtype=np.int32)) for _ in range(16)]
+        ring = [(np.zeros(reads_per_batch * READ_LEN + 1, dtype=np.uint8), np.full(reads_per_batch, -1, dtype=np.int32)) for _ in range(32)]
 
         def run_pipe(n):
             for i in range(n):
                 lab, ln = ring[i % len(ring)]
                 be.pipe_submit_reads_global(bufs[0][i % nb_host], read_off, reads_per_batch, CHUNK, STEP, W, True, 0.5, 0.5, lab, label_off, ln)
-                if i >= 8:
-                    be.pipe_progress(be.pipe_submitted() - 8)   # at most 8 steps' buffers in flight (as the driver loop keeps them)
+                if i >= 24:
+                    be.pipe_progress(be.pipe_submitted() - 24)   # at most 24 steps' buffers in flight (radian_amd.basecall.run's global-mode cap)
             be.pipe_flush()
             be.sync()
         run_pipe(warmup)
@@ -612,7 +612,8 @@ def main():
                                                                     "oracle's same definition, tests/test_gpu_cfg5.py"))):
             note(key)
             try:
-                sec[key] = global_leg(device, norms, read_off, reads_per_batch, args.steps, table=table, **kw)
+                # (3 x the headline's steps: the first and the last group's searches run alone, a tenth of a 20-step region)
+                sec[key] = global_leg(device, norms, read_off, reads_per_batch, 3 * args.steps, table=table, **kw)
             except Exception as e:
                 print(f"[bench] {key} failed: {e}", file=sys.stderr)
         # the headline step on the soft-head model (same timed region as `value`)

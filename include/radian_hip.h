@@ -109,8 +109,10 @@ int rd_set_decode_form(rd_ctx* ctx, int form);
  * results, no reference counterpart): cus_per_xcd CUs of each of the 8 XCDs are kept free of forward workgroups (the
  * pipeline's forward streams are CU-masked to the others) and run the beam search.  A read's search is one serial chain of
  * a time step per sample; a beam-search wave that shares its SIMD with conv waves issuing MFMAs back to back gets about one
- * instruction issue per MFMA (17 us per step measured instead of 2).  -1 (default) = by beam width (3 / 5 / 8 CUs per XCD
- * for W <= 12 / 25 / 51: 9 to 25 % of the chip), 0 = off (groups then grow until their forward rows cover the slow chain). */
+ * instruction issue per MFMA (17 us per step measured instead of 2).  -1 (default) = by beam width (4 CUs per XCD, 8 above
+ * W = 25: 12.5 or 25 % of the chip; a masked queue's CUs are dealt over the four shader engines of an XCD and the forward
+ * runs at the pace of the engine left with the fewest, so only multiples of four are worth setting), 0 = off (groups then
+ * grow until their forward rows cover the slow chain). */
 int rd_set_decode_partition(rd_ctx* ctx, int cus_per_xcd);
 /* Arithmetic of the beam search's log / logaddexp (decode.py:16-17,172-201 call math.log and np.logaddexp, i.e. the host's
  * libm): 1 (default) = the operation sequence of glibc 2.35's x86-64 FMA build (exp, log, log1p restated in

@@ -60,11 +60,14 @@ inline int part_seq_limit(int part_cus, int W)
     return W <= 6 ? 2 * waves3 : W <= 12 ? waves3 : W <= 25 ? waves3 / 2 : waves3 / 4;   // (W <= 6: two sequences per wave)
 }
 constexpr int64_t kGroupRowsCap = 96ll << 20;   // rows a group may gather while it waits for coverage (~6 GB of probabilities + matrix)
-// CUs per XCD of the decode partition for a beam width (rd_set_decode_partition -1): enough SIMDs that the partition's
-// beam-search rate stays above the forward's ~29 M rows/s when a group holds many short reads (a saturated SIMD steps
-// ~0.45 M sequences-steps/s at W = 10: 16 CUs = 64 SIMDs would just match the forward; measured throughput is flat from
-// 1 to 4 CUs per XCD -- 27.7 / 28.2 / 28.2 M samples/s -- because the conv launches' tile rounds quantise either way)
-inline int auto_part_cus(int W) { return W <= 12 ? 3 : W <= 25 ? 5 : 8; }
+// CUs per XCD of the decode partition for a beam width (rd_set_decode_partition -1).  ALWAYS A MULTIPLE OF FOUR: a CU-masked
+// queue's bits are dealt round over the four shader engines of an XCD (bit j of an XCD -> engine j mod 4), and the dispatcher
+// hands every engine the same share of a launch's workgroups, so the forward runs at the pace of the engine with the FEWEST
+// CUs left.  Measured (tools/global_pipe_bench.py 1 partK, 64-read steps, ms per step): K = 0: 8.72 | 1, 2, 3, 4: 9.15, 9.15,
+// 9.16, 9.17 | 5, 6, 7, 8: 10.58, 10.62, 10.61, 10.63 -- the fourth CU of a group of four is free, the fifth costs as much as
+// the eighth.  (Rounds 2-3 used 3 / 5 / 8; 5 was the worst choice on the table.)  32 CUs = 128 SIMDs step ~0.45 M
+// sequence-steps/s each at W = 10 (twice the forward's ~29 M rows/s) and keep up at W = 25; wider beams take a second four.
+inline int auto_part_cus(int W) { return W <= 25 ? 4 : 8; }
 
 struct RSub {                 // one submitted batch inside a group
     int n_seq = 0, seq0 = 0;  // its decoded sequences (global: reads; chunk: windows) = [seq0, seq0 + n_seq) of the group

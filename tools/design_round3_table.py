@@ -10,9 +10,9 @@ rows = f"""| quantity (one MI355X, driver-timed: `profiles/r03_bench.json`) | ro
 |---|---|---|
 | headline, exact fp32, chunk W = 10, 64-read steps | 26.4 M samples/s | **{d['value']/1e6:.1f} M** ({d['ms_per_step']:.2f} ms per step); `roofline.frac` {r['frac']:.3f} ({r['avg_launch_ms']:.4f} ms per conv launch), `pipeline_frac` {r['pipeline_frac']:.3f} |
 | `secondary_soft_head`: the headline's step on soft rows (~{d['secondary_soft_head']['mean_bases_per_window']:.0f} bases per window instead of ~5) | — | {M('secondary_soft_head'):.1f} M |
-| `secondary_global_lm`: configs[3] geometry, W = 10, 4^11-row LM, 64-read steps | 19.5 M (two contexts on two host threads) | **{M('secondary_global_lm'):.1f} M in ONE context** (`rd_pipe_submit_reads_global`, groups of two steps on the decode partition); two contexts unpipelined {d['secondary_global_lm']['two_contexts_unpipelined']/1e6:.1f} M |
+| `secondary_global_lm`: configs[3] geometry, W = 10, 4^11-row LM, 64-read steps | 19.5 M (two contexts on two host threads) | **{M('secondary_global_lm'):.1f} M in ONE context** (`rd_pipe_submit_reads_global`, groups of two steps on the decode partition, 4 CUs per XCD); two contexts unpipelined {d['secondary_global_lm']['two_contexts_unpipelined']/1e6:.1f} M |
 | `secondary_global_lm_soft_head`: the same with the soft head (~{d['secondary_global_lm_soft_head']['mean_bases_per_read']:.0f} bases per read, the gate fires) | — | {M('secondary_global_lm_soft_head'):.1f} M ({d['secondary_global_lm_soft_head']['two_contexts_unpipelined']/1e6:.1f} M) |
-| `secondary_cfg5_w25_ctx256_f16` (configs[4]) | 15.8 M | {M('secondary_cfg5_w25_ctx256_f16'):.1f} M |
+| `secondary_cfg5_w25_ctx256_f16` (configs[4]) | 15.8 M | {M('secondary_cfg5_w25_ctx256_f16'):.1f} M (21.2 M with a partition of 5 CUs per XCD: §4.11) |
 | `secondary_e2e_raw`: host int16 → … → strings, {d['secondary_e2e_raw']['reads']} uniform reads, chunk W = 10 | 25.4 M (two contexts, 4 stitch processes) | {M('secondary_e2e_raw'):.1f} M (one context) |
 | `secondary_e2e_raw_ragged`: the same on log-normal read lengths (1.5 k … 60 k, median 9 k): a plan per batch | — | {M('secondary_e2e_raw_ragged'):.1f} M |
 | `secondary_e2e_raw_soft_head`: configs[2] end to end on soft rows | (3.6 M with the Python stitch, measured this round) | **{M('secondary_e2e_raw_soft_head'):.1f} M** (`rd_stitch_chunk`) |

@@ -1,5 +1,5 @@
 """One-context pipelined global decode (rd_pipe_submit_reads_global) at the bench's 64-read steps: samples/s against the
-group size.  usage: python tools/global_pipe_bench.py [soft] [fast] [W] (RD_CHAIN_ROWS=<rows per chain step> overrides the early-close rule)"""
+group size.  usage: python tools/global_pipe_bench.py [soft] [fast] [hashed] [f16] [partK] [gN ...] [W] (RD_CHAIN_ROWS=<rows per chain step> overrides the early-close rule)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -12,7 +12,13 @@ def main():
     n, L = 64, 4096
     be = Backend(0)
     be.load_weights(bench.soft_head_weights() if soft else weights.synthetic_weights(seed=1234))
-    be.load_lm(np.random.default_rng(0).dirichlet([0.3] * 4, size=4 ** 11), 11)
+    table = np.random.default_rng(0).dirichlet([0.3] * 4, size=4 ** 11)
+    if "hashed" in sys.argv:
+        be.load_lm_hashed(table, 11, 256)      # configs[4]: --context-len 256 over a 4^11-row table
+    else:
+        be.load_lm(table, 11)
+    if "f16" in sys.argv:
+        be.set_logits("f16")
     if "fast" in sys.argv:
         be.set_decode_math("fast")
     for a in sys.argv[1:]:
