@@ -28,6 +28,8 @@
 // into the epilogue.  The head reuses the same core with N = 128, then reduces 128 -> 5 and applies softmax from LDS.
 #include "common.h"
 
+#include <algorithm>
+#include <vector>
 #include <mutex>
 
 #include <stdint.h>
@@ -102,6 +104,38 @@ __device__ __forceinline__ void wait_dma_and_barrier()
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LEAVE) : "memory");
 }
 
+// Diagnostic build only (-DRD_CLOCK_STAMPS, tools/conv_clock.py): every conv workgroup stamps the shader clock and the 100-MHz
+// wall clock at its start and end; rd_debug_conv_clock() reports the clock the chip actually held inside the kernel
+// (MI355X_MICROARCH.md, "DVFS give-back" (6): sysfs / rocm-smi read up to 10 % above it).  The stamps go to a buffer of their
+// own; no output depends on them.
+#ifdef RD_CLOCK_STAMPS
+// a ring of the last 131 072 conv workgroups x {wall start, wall end, shader-clock ticks, xcc << 32 | HW_ID}
+__device__ unsigned long long g_clock_stamps[32 * 4096 * 4];
+__device__ unsigned g_launch_seq;
+#define RD_STAMP_BEGIN()                                                                                              \
+    unsigned long long ck0_ = 0, rt0_ = 0;                                                                            \
+    unsigned seq_ = 0;                                                                                                \
+    if (threadIdx.x == 0 && EPI != EPI_HEAD) {                                                                        \
+        seq_ = atomicAdd(&g_launch_seq, 1u);   /* (a ring position per workgroup) */                                  \
+        ck0_ = __builtin_amdgcn_s_memtime();                                                                          \
+        rt0_ = __builtin_amdgcn_s_memrealtime();                                                                      \
+    }
+#define RD_STAMP_END()                                                                                                \
+    if (threadIdx.x == 0 && EPI != EPI_HEAD) {                                                                        \
+        unsigned xcc_, hw_;                                                                                           \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                           \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                             \
+        unsigned long long* o_ = g_clock_stamps + (size_t)(seq_ & (32 * 4096 - 1)) * 4;                               \
+        o_[0] = rt0_;                                                                                                 \
+        o_[1] = __builtin_amdgcn_s_memrealtime();                                                                     \
+        o_[2] = __builtin_amdgcn_s_memtime() - ck0_;                                                                  \
+        o_[3] = (unsigned long long)(xcc_ & 0xf) << 32 | hw_;                                                         \
+    }
+#else
+#define RD_STAMP_BEGIN()
+#define RD_STAMP_END()
+#endif
+
 // ReLU of an accumulator.  Written as `v > 0 ? v : 0` hipcc emits v_max v, v, v (quieting a possible signalling NaN) in front
 // of the v_max with 0: 128 extra vector instructions per wave in the epilogue.
 __device__ __forceinline__ float relu_raw(float v)
@@ -117,7 +151,10 @@ __device__ __forceinline__ float relu_raw(float v)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __attribute__((address_space(1))) char* sgpr_base(const void* p)
 {
-    uint64_t u = (uint64_t)p;
+    // (readfirstlane: free on a value that already lives in scalar registers, and keeps the statement legal when register
+    // pressure made hipcc park the wave-uniform descriptor fields in vector registers)
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)p >> 32));
+    uint64_t u = (uint64_t)hi << 32 | lo;
     asm("" : "+s"(u));
     return (__attribute__((address_space(1))) char*)u;
 }
@@ -151,6 +188,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
 
     __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];  // 3 x 24 KiB (conv, WM = 2) / 3 x 32 KiB (WM = 4) / 67 KiB (head)
 
+    RD_STAMP_BEGIN()
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -477,6 +515,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
             }
         }
     }
+    RD_STAMP_END()
 }
 
 // Block 0, first conv: C_in = 1 (VALU; memory-bound 1 KiB write per time step), fused bias + ReLU.
@@ -1713,3 +1752,12 @@ int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_
     if (rc) return rc;
     return rd_forward_tiles_dev(ctx, d_windows, tl, (int64_t)nW * T, d_probs, lane);
 }
+
+#ifdef RD_CLOCK_STAMPS
+// copies the stamp ring (32 launches x 4096 workgroups x 4 values) to the host: tools/conv_clock.py does the arithmetic
+extern "C" int rd_debug_conv_stamps(unsigned long long* out /* [32 * 4096 * 4] */)
+{
+    RD_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_stamps), sizeof(unsigned long long) * 32 * 4096 * 4));
+    return RD_OK;
+}
+#endif

@@ -1,5 +1,5 @@
 """One-context pipelined global decode (rd_pipe_submit_reads_global) at the bench's 64-read steps: samples/s against the
-group size.  usage: python tools/global_pipe_bench.py [soft] [fast] [hashed] [f16] [partK] [gN ...] [W] (RD_CHAIN_ROWS=<rows per chain step> overrides the early-close rule)"""
+group size.  usage: python tools/global_pipe_bench.py [soft] [fast] [hashed] [f16] [partK] [nREADS] [gN ...] [W] (RD_CHAIN_ROWS=<rows per chain step> overrides the early-close rule)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -10,6 +10,9 @@ def main():
     soft = "soft" in sys.argv
     W = int([a for a in sys.argv[1:] if a.isdigit()][0]) if any(a.isdigit() for a in sys.argv[1:]) else 10
     n, L = 64, 4096
+    for a in sys.argv[1:]:
+        if a.startswith('n') and a[1:].isdigit():
+            n = int(a[1:])      # reads per step (default 64)
     be = Backend(0)
     be.load_weights(bench.soft_head_weights() if soft else weights.synthetic_weights(seed=1234))
     table = np.random.default_rng(0).dirichlet([0.3] * 4, size=4 ** 11)
@@ -43,6 +46,6 @@ def main():
             be.pipe_flush(); be.sync()
         run(8)
         t0 = time.perf_counter(); run(64); dt = time.perf_counter() - t0
-        print(f"group {group:2d}: {64 * n * L / dt / 1e6:6.2f} M samples/s  ({dt / 64 * 1e3:.2f} ms per 64-read step)", flush=True)
+        print(f"group {group:2d}: {64 * n * L / dt / 1e6:6.2f} M samples/s  ({dt / 64 * 1e3:.2f} ms per {n}-read step, {dt / 64 / (n * L) * 1e9:.2f} ns per row)", flush=True)
     be.close()
 main()
