@@ -76,6 +76,11 @@ def main():
                     k = 0 if slot_end[0] is None or (slot_end[1] is not None and slot_end[0] <= slot_end[1]) else 1
                 slot_end[k] = b[i]
         gaps = np.array(gaps) if gaps else np.zeros(1)
+        if "gantt" in sys.argv:      # one CU's workgroups over 4 ms: (start, duration) in us from the window's start
+            for key in np.unique(cu_key)[[0, 77]]:
+                m = (cu_key == key) & (t0s >= lo) & (t0s < lo + 400000)
+                o = np.argsort(t0s[m])
+                print(f"  CU {key:#x}: " + " ".join(f"{(a - lo) / 100:.0f}+{(b - a) / 100:.0f}" for a, b in zip(t0s[m][o], t1s[m][o])))
         if "gaps" in sys.argv:
             g = np.sort(gaps)
             tot = g.sum()
