@@ -129,7 +129,8 @@ __device__ unsigned g_launch_seq;
         o_[0] = rt0_;                                                                                                 \
         o_[1] = __builtin_amdgcn_s_memrealtime();                                                                     \
         o_[2] = __builtin_amdgcn_s_memtime() - ck0_;                                                                  \
-        o_[3] = (unsigned long long)(xcc_ & 0xf) << 32 | hw_;                                                         \
+        o_[3] = ((unsigned long long)(uintptr_t)a.out >> 12 & 0xffff) << 48 | (unsigned long long)(a.dil & 0xff) << 40 | \
+                (unsigned long long)EPI << 36 | (unsigned long long)(xcc_ & 0xf) << 32 | hw_;   /* (out, dil, EPI: which launch) */ \
     }
 #else
 #define RD_STAMP_BEGIN()
@@ -518,12 +519,29 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
     RD_STAMP_END()
 }
 
+// The zero rows of a forward's three activation tensors (the source of the causal left padding, one row behind the batch's last).
+// The first kernel of a forward clears them with its workgroup 0 -- nothing reads them before the second kernel, nothing ever
+// writes them, and their place moves with the batch's row count.  (They were three hipMemsetAsync launches in front of every
+// forward: on a lane of the two-lane pipeline every launch boundary costs 0.1-0.35 ms before the next kernel's first
+// workgroup runs -- profiles/r03h_conv_slots.txt -- so three empty launches were ~0.6 ms of lane time per step.)
+struct ZeroRows {
+    uint4* row[3];
+    int n16;   // 16-byte pieces per row
+};
+__device__ __forceinline__ void clear_zero_rows(const ZeroRows& z)
+{
+    if (blockIdx.x != 0) return;
+    for (int r = 0; r < 3; r++)
+        for (int i = threadIdx.x; i < z.n16; i += blockDim.x) z.row[r][i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // Block 0, first conv: C_in = 1 (VALU; memory-bound 1 KiB write per time step), fused bias + ReLU.
 // One workgroup per tile descriptor: 4 rows per pass (64 lanes x float4 = one 1 KiB row per wave).
 __global__ __launch_bounds__(256) void tcn_in_kernel(const float* __restrict__ x, const float* __restrict__ w /*[3][256]*/,
                                                       const float* __restrict__ b, float* __restrict__ out,
-                                                      const TileDesc* __restrict__ tiles, int dil)
+                                                      const TileDesc* __restrict__ tiles, int dil, ZeroRows zr)
 {
+    clear_zero_rows(zr);
     const TileDesc td = tiles[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];   // wave w owns sub-tile w: one row per pass
     const int c4 = (threadIdx.x & 63) * 4;
     const float4 w0 = *(const float4*)(w + c4), w1 = *(const float4*)(w + 256 + c4), w2 = *(const float4*)(w + 512 + c4);
@@ -874,8 +892,9 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
 
 // Block 0, first conv (C_in = 1) writing split-f16 rows.
 __global__ __launch_bounds__(256) void tcn_in_split_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                                                            _Float16* __restrict__ out, const TileDesc* __restrict__ tiles, int dil)
+                                                            _Float16* __restrict__ out, const TileDesc* __restrict__ tiles, int dil, ZeroRows zr)
 {
+    clear_zero_rows(zr);
     const TileDesc td = tiles[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];   // wave w owns sub-tile w
     const int c4 = (threadIdx.x & 63) * 4;
     const float4 w0 = *(const float4*)(w + c4), w1 = *(const float4*)(w + 256 + c4), w2 = *(const float4*)(w + 512 + c4);
@@ -1337,8 +1356,9 @@ __global__ __launch_bounds__(512, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
 
 // Block 0, first conv (C_in = 1) writing three-term bf16 rows.
 __global__ __launch_bounds__(256) void tcn_in_bf3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                                                          __bf16* __restrict__ out, const TileDesc* __restrict__ tiles, int dil)
+                                                          __bf16* __restrict__ out, const TileDesc* __restrict__ tiles, int dil, ZeroRows zr)
 {
+    clear_zero_rows(zr);
     const TileDesc td = tiles[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];   // wave w owns sub-tile w
     const int c4 = (threadIdx.x & 63) * 4;
     const float4 w0 = *(const float4*)(w + c4), w1 = *(const float4*)(w + 256 + c4), w2 = *(const float4*)(w + 512 + c4);
@@ -1416,6 +1436,14 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
     const bool split = ctx->precision == 1;
     const bool bf3 = ctx->precision == 2;
     int rc;
+    ZeroRows zr = {};
+    if (kind == 0) {
+        const size_t row_bytes = (size_t)RD_C * (bf3 ? 6 : 4);
+        zr.n16 = (int)(row_bytes / 16);
+        zr.row[0] = (uint4*)((char*)Xin + (size_t)zero_row * row_bytes);
+        zr.row[1] = (uint4*)((char*)Xout + (size_t)zero_row * row_bytes);
+        zr.row[2] = (uint4*)((char*)MID + (size_t)zero_row * row_bytes);
+    }
     if (bf3) {
         Bf3Args h = {};
         h.zero_row = zero_row;
@@ -1423,7 +1451,7 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
         h.tiles = tiles;
         if (kind == 0) {
             if ((rc = timer_begin(st, ctx->timer_in))) return rc;
-            hipLaunchKernelGGL(tcn_in_bf3_kernel, dim3(n), dim3(256), 0, st, d_signal, m.w_in, m.b_in, (__bf16*)MID, tiles, m.dil[0]);
+            hipLaunchKernelGGL(tcn_in_bf3_kernel, dim3(n), dim3(256), 0, st, d_signal, m.w_in, m.b_in, (__bf16*)MID, tiles, m.dil[0], zr);
             RD_HIP(hipGetLastError());
             return timer_end(st, ctx->timer_in, 2.0 * rows * RD_C * RD_K, rows * (RD_C * 6.0 + 4.0));
         }
@@ -1465,9 +1493,9 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
     if (kind == 0) {
         if ((rc = timer_begin(st, ctx->timer_in))) return rc;
         if (split)
-            hipLaunchKernelGGL(tcn_in_split_kernel, dim3(n), dim3(256), 0, st, d_signal, m.w_in, m.b_in, (_Float16*)MID, tiles, m.dil[0]);
+            hipLaunchKernelGGL(tcn_in_split_kernel, dim3(n), dim3(256), 0, st, d_signal, m.w_in, m.b_in, (_Float16*)MID, tiles, m.dil[0], zr);
         else
-            hipLaunchKernelGGL(tcn_in_kernel, dim3(n), dim3(256), 0, st, d_signal, m.w_in, m.b_in, MID, tiles, m.dil[0]);
+            hipLaunchKernelGGL(tcn_in_kernel, dim3(n), dim3(256), 0, st, d_signal, m.w_in, m.b_in, MID, tiles, m.dil[0], zr);
         RD_HIP(hipGetLastError());
         return timer_end(st, ctx->timer_in, 2.0 * rows * RD_C * RD_K, rows * (RD_C * 4.0 + 4.0));
     }
@@ -1682,9 +1710,7 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl
     float* Xout = L->act[1].as<float>();
     float* MID = L->act[2].as<float>();
     const int zero_row = (int)total_rows;
-    RD_HIP(hipMemsetAsync((char*)Xin + (size_t)zero_row * row_bytes, 0, row_bytes, L->st));
-    RD_HIP(hipMemsetAsync((char*)Xout + (size_t)zero_row * row_bytes, 0, row_bytes, L->st));
-    RD_HIP(hipMemsetAsync((char*)MID + (size_t)zero_row * row_bytes, 0, row_bytes, L->st));
+    // (the three tensors' zero rows are cleared by the forward's first kernel: clear_zero_rows)
     const int nl = 2 * m.nblocks + 1;
     for (int li = 0; li < nl; li++) {
         const int b = li == nl - 1 ? m.nblocks : li / 2;

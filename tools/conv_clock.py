@@ -11,6 +11,7 @@ from radian_amd import Backend, synthetic, weights, _lib
 def main():
     n, L, W = 64, 4096, 1
     lib = ctypes.CDLL(_lib.LIB_PATH)
+    stamped = hasattr(lib, "rd_debug_conv_stamps")     # (without the diagnostic build: just the loop, e.g. under rocprofv3)
     be = Backend(0)
     be.load_weights(weights.synthetic_weights(seed=1234))
     be.load_lm(np.random.default_rng(0).dirichlet([0.3] * 4, size=4 ** 5), 5)
@@ -47,15 +48,20 @@ def main():
             be.pipe_flush(); be.sync()
         run(8)
         t0 = time.perf_counter(); run(300); dt = time.perf_counter() - t0     # ~3 s of back-to-back launches
+        if not stamped:
+            print(f"partition {part}: {300 * n * L / dt / 1e6:6.2f} M samples/s (no stamps in this build)")
+            continue
         st = np.zeros(32 * 4096 * 4, dtype=np.uint64)
         rc = lib.rd_debug_conv_stamps(st.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)))
         st = st.reshape(-1, 4)
+        if "dump" in sys.argv:
+            np.save(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", f"conv_stamps_part{part}.npy"), st)
         st = st[(st[:, 0] > 0) & (st[:, 1] > st[:, 0])]
         t0s, t1s, clk, where = st[:, 0].astype(np.int64), st[:, 1].astype(np.int64), st[:, 2].astype(np.float64), st[:, 3]
         dur = (t1s - t0s).astype(np.float64)          # 100-MHz ticks
         lo, hi = np.percentile(t0s, 30), np.percentile(t1s, 70)      # a window the ring covers completely (every launch that overlaps it is in it)
         hw = (where & np.uint64(0xffffffff)).astype(np.int64)
-        cu_key = ((where >> np.uint64(32)).astype(np.int64) << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
+        cu_key = (((where >> np.uint64(32)) & np.uint64(0xf)).astype(np.int64) << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
         occ, gaps = [], []
         for key in np.unique(cu_key):
             m = cu_key == key
@@ -76,6 +82,26 @@ def main():
                     k = 0 if slot_end[0] is None or (slot_end[1] is not None and slot_end[0] <= slot_end[1]) else 1
                 slot_end[k] = b[i]
         gaps = np.array(gaps) if gaps else np.zeros(1)
+        if "launches" in sys.argv:   # per launch (output buffer, dilation, epilogue) inside 5 ms of the window: when its workgroups started and ended
+            tag = (where >> np.uint64(36)).astype(np.int64)
+            m = (t0s >= lo) & (t0s < lo + 500000)
+            rows = []
+            for tg in np.unique(tag[m]):
+                mm = m & (tag == tg)
+                a, b = np.sort(t0s[mm]), t1s[mm]
+                # the same layer of the same lane comes back every step: split at pauses of > 1 ms between starts
+                cuts = np.flatnonzero(np.diff(a) > 100000)
+                for seg in np.split(np.arange(len(a)), cuts + 1):
+                    st = a[seg]
+                    en = np.sort(t1s[mm][np.argsort(t0s[mm])][seg])
+                    rows.append((st[0], tg, len(seg), st[0], st[-1], en[-1], en[len(en) // 2]))
+            rows.sort()
+            print("  lane(out)  dil epi   wgs   first_start  last_start  last_end (us from the window's start)   dispatch_span  tail")
+            for _, tg, nw, f, l, e, _ in rows:
+                print(f"  {tg >> 12 & 0xffff:#06x} {tg >> 4 & 0xff:4d} {tg & 0xf:3d} {nw:6d} {(f - lo) / 100:12.0f} {(l - lo) / 100:11.0f} {(e - lo) / 100:9.0f} {(l - f) / 100:30.0f} {(e - l) / 100:6.0f}")
+            ts = lo + np.arange(250) * 2000
+            act = [(int(((t0s <= t) & (t1s > t)).sum())) for t in ts]
+            print("  in flight every 20 us from the window's start:", " ".join(str(x) for x in act))
         if "gantt" in sys.argv:      # one CU's workgroups over 4 ms: (start, duration) in us from the window's start
             for key in np.unique(cu_key)[[0, 77]]:
                 m = (cu_key == key) & (t0s >= lo) & (t0s < lo + 400000)
