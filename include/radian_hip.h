@@ -33,6 +33,10 @@ extern "C" {
 #define RD_ERR_STATE (-3) /* call order (e.g. forward before weights) */
 #define RD_ERR_NOMEM (-4) /* device allocation failed */
 #define RD_ERR_RCCL (-5)  /* RCCL error / librccl not loadable */
+/* Not an error code: the value of label_len[i] for a sequence whose beam search looked up a context that a SPARSE RNA model
+ * does not hold (rd_load_lm, rows of NaN).  The reference raises KeyError at radian/decode.py:83 on such a read; the caller
+ * does the same when it reaches that read (radian_amd/basecall.py).  The sequence's labels are not written. */
+#define RD_LEN_MISSING_CONTEXT (-1)
 
 typedef struct rd_ctx rd_ctx;
 
@@ -87,6 +91,10 @@ int rd_load_weights(rd_ctx* ctx, const void* blob, size_t nbytes);
 /* Replaces the RNA-model dict built at radian/basecall.py:48-57 and read at decode.py:83.
  * table[ctx][4] doubles, ctx = base-4 number of the k context labels, oldest label most
  * significant (the JSON key string read left to right).  k = --context-len, 1..13.
+ * A row of NaNs marks a context the model does NOT hold (a sparse JSON): the reference's dict lookup raises KeyError
+ * when -- and only when -- the search of a read keeps a labeling that ends in such a context (decode.py:83, looked up
+ * for every kept labeling of >= k labels at every time step, whatever the gate says); here that read's label_len comes
+ * back as RD_LEN_MISSING_CONTEXT and every other read is unaffected.
  * Passing table == NULL unloads the LM. */
 int rd_load_lm(rd_ctx* ctx, const double* table, int k);
 /* Long contexts (--context-len up to 256; BASELINE configs[4]).  NO reference behaviour: the reference needs one dict

@@ -86,6 +86,9 @@ def beam_search_labels(mat, beam_width, lm_table=None, s_threshold=0.0, r_thresh
         _ptr(fl) if max_final else None, _ptr(fb) if max_final else None)
     if rc != 0:
         raise RuntimeError("ro_beam_search failed")
+    if out_len.value < 0:
+        # sparse model (rows of NaN = absent contexts): the search looked one up -- the reference's KeyError, decode.py:83
+        raise KeyError("the RNA model holds no entry for a context of the beam search (radian/decode.py:83)")
     labels = out[: out_len.value].copy()
     final = None
     if max_final:
@@ -130,7 +133,9 @@ def beam_search_batch(mats, seq_off, seq_len, beam_width, lm_table=None, s_thres
         ctypes.c_double(r_threshold), _ptr(labels), _ptr(label_off), _ptr(lens), ctypes.c_int(nthreads))
     if rc != 0:
         raise RuntimeError("ro_beam_search_batch failed")
-    return [labels[label_off[i]: label_off[i] + lens[i]].copy() for i in range(n)]
+    # a sequence whose search looked up a context that a sparse table (rows of NaN) does not hold: None (the reference raises
+    # KeyError at decode.py:83)
+    return [labels[label_off[i]: label_off[i] + lens[i]].copy() if lens[i] >= 0 else None for i in range(n)]
 
 
 def row_entropy(row):

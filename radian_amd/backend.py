@@ -21,6 +21,18 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
+MISSING_CONTEXT = -1   # RD_LEN_MISSING_CONTEXT (include/radian_hip.h)
+
+
+def _labels_of(labels, off, n):
+    """one sequence's labels out of the flat label buffer -- or None where the library reports RD_LEN_MISSING_CONTEXT: the
+    read's beam search looked up a context that the sparse RNA model does not hold (the reference raises KeyError there,
+    radian/decode.py:83; radian_amd.basecall does when it reaches the read)"""
+    if n == MISSING_CONTEXT:
+        return None
+    return labels[off: off + n].copy()
+
+
 class PipeTicket:
     """One batch queued on a Backend's reads-level pipeline (Backend.pipe_submit_raw).  The arrays the library writes into
     live here until the batch is delivered."""
@@ -48,7 +60,7 @@ class PipeTicket:
         """(labels, status) as basecall_raw_global / basecall_raw_chunk return them; blocks until delivered"""
         self.wait()
         if self.decode_type == "global":
-            return [self.labels[self.off[r]: self.off[r] + self.lens[r]].copy() for r in range(self.n)], self.status
+            return [_labels_of(self.labels, self.off[r], self.lens[r]) for r in range(self.n)], self.status
         out, w = [], 0
         for n in self.nw:
             out.append([self.labels[w + i, : self.lens[w + i]].copy() for i in range(n)])
@@ -67,6 +79,10 @@ class Backend:
         self._h = h
         self.device_id = device_id
         self.lm_k = None
+        # undelivered PipeTickets by submit number: the library writes a batch's labels / lengths / status into the ticket's
+        # arrays when it DELIVERS the batch (rd_pipe_progress / rd_pipe_flush, possibly on behalf of another ticket's wait),
+        # so the arrays must outlive a ticket the caller dropped
+        self._tickets = {}
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
@@ -75,8 +91,9 @@ class Backend:
 
     def close(self):
         if self._h is not None:
-            self._L.rd_destroy(self._h)
+            self._L.rd_destroy(self._h)      # (does not deliver: nothing is written into ticket arrays after this)
             self._h = None
+        self._tickets.clear()
 
     def __del__(self):
         try:
@@ -125,7 +142,8 @@ class Backend:
         self._check(self._L.rd_load_weights(self._h, ctypes.cast(buf, ctypes.c_void_p), len(blob)))
 
     def load_lm(self, table, k):
-        """Dense LM table [4^k,4] float64 (radian/basecall.py:48-57); None unloads."""
+        """LM table [4^k,4] float64 (radian/basecall.py:48-57); rows of NaN mark contexts a sparse model does not hold
+        (lm.table_from_dict); None unloads."""
         if table is None:
             self._check(self._L.rd_load_lm(self._h, None, 0))
             self.lm_k = None
@@ -207,7 +225,7 @@ class Backend:
         self._check(self._L.rd_decode_batch(self._h, _p(mats), 1 if mats.dtype == np.float64 else 0, _p(seq_off), _p(seq_len), n,
                                             int(beam_width), 1 if use_lm else 0, float(s_threshold), float(r_threshold),
                                             _p(labels), _p(label_off), _p(lens), _p(scores)))
-        out = [labels[label_off[i]: label_off[i] + lens[i]].copy() for i in range(n)]
+        out = [_labels_of(labels, label_off[i], lens[i]) for i in range(n)]
         return (out, scores) if with_scores else out
 
     def decode(self, mat, beam_width, use_lm=False, s_threshold=0.0, r_threshold=0.0):
@@ -241,7 +259,7 @@ class Backend:
         self._check(self._L.rd_basecall_global(self._h, _p(windows), T, int(step), _p(read_win_off), _p(pads), n_reads,
                                                int(beam_width), 1 if use_lm else 0, float(s_threshold), float(r_threshold),
                                                _p(labels), _p(label_off), _p(lens)))
-        return [labels[label_off[r]: label_off[r] + lens[r]].copy() for r in range(n_reads)]
+        return [_labels_of(labels, label_off[r], lens[r]) for r in range(n_reads)]
 
     # ------------------------------------------------------------------ reads-level fused paths
     def count_windows(self, n_samples, chunk_len, step):
@@ -283,7 +301,7 @@ class Backend:
         self._check(self._L.rd_basecall_reads_global(self._h, _p(flat), _p(off), n, int(chunk_len), int(step), int(beam_width),
                                                      1 if use_lm else 0, float(s_threshold), float(r_threshold), _p(labels),
                                                      _p(label_off), _p(lens)))
-        return [labels[off[r]: off[r] + lens[r]].copy() for r in range(n)]
+        return [_labels_of(labels, off[r], lens[r]) for r in range(n)]
 
     # ------------------------------------------------------------------ raw int16 reads (normalisation on the device)
     STATUS_MESSAGES = {1: "MAD is zero, issue with signal.", 2: "Signal must not be empty to normalise"}  # preprocess.py:25-26,47-48
@@ -332,7 +350,7 @@ class Backend:
         self._check(self._L.rd_basecall_raw_global(self._h, _p(flat), _p(off), n, int(outlier_clip), int(chunk_len), int(step),
                                                    int(beam_width), 1 if use_lm else 0, float(s_threshold), float(r_threshold),
                                                    _p(labels), _p(label_off), _p(lens), _p(status)))
-        return [labels[off[r]: off[r] + lens[r]].copy() for r in range(n)], status
+        return [_labels_of(labels, off[r], lens[r]) for r in range(n)], status
 
     # ------------------------------------------------------------------ device-resident (bench)
     def dev_alloc(self, nbytes):
@@ -399,7 +417,12 @@ class Backend:
         life) are delivered when wait_for > 0.  -> number of submits delivered so far."""
         n = ctypes.c_int64(0)
         self._check(self._L.rd_pipe_progress(self._h, int(wait_for), ctypes.byref(n)))
+        self._release_tickets(n.value)
         return n.value
+
+    def _release_tickets(self, delivered):
+        for seq in [q for q in self._tickets if q <= delivered]:
+            del self._tickets[seq]
 
     def pipe_submit_raw(self, decode_type, raws, outlier_clip, chunk_len, step, beam_width, use_lm=False, s_threshold=0.0,
                         r_threshold=0.0):
@@ -423,6 +446,7 @@ class Backend:
             self._check(self._L.rd_pipe_submit_raw_chunk(self._h, _p(flat), _p(off), n, int(outlier_clip), int(chunk_len), int(step),
                                                          int(beam_width), _p(t.labels), _p(t.lens), _p(t.status)))
         t.seq = self.pipe_submitted()
+        self._tickets[t.seq] = t
         return t
 
     def pipe_submitted(self):
@@ -440,6 +464,7 @@ class Backend:
 
     def pipe_flush(self):
         self._check(self._L.rd_pipe_flush(self._h))
+        self._release_tickets(self.pipe_submitted())
 
     def timer_enable(self, which, max_launches):
         self._check(self._L.rd_timer_enable(self._h, which, max_launches))

@@ -9,7 +9,8 @@ Flags, defaults, read order, FASTA naming/rotation and the stdout lines follow r
 What differs (results do not): reads are batched ACROSS reads for the GPU (the forward is batch independent,
 SURVEY F10), so `--batch-size` no longer sizes anything (`--gpu-batch-windows` bounds a device batch); windows are formed on the
 device and every time step is evaluated once (bit-identical to evaluating all windows, DESIGN.md section 4.6);
-`--rna-model None` disables the LM in global mode instead of crashing at decode.py:83; `--sig-model` also
+`--rna-model None` disables the LM in global mode instead of crashing at decode.py:83; an RNA model that lacks some contexts
+loads, and a read whose beam search reaches an absent one raises the reference's KeyError when the driver gets to it; `--sig-model` also
 accepts `synthetic[:seed]` (seeded He-normal weights: the reference's sig2seq.h5 is not distributed with
 the source tree) and packed `.rdnw` blobs; extra flags `--device`, `--gpus`.
 """
@@ -251,7 +252,18 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
     in_flight, finishing = [], []
     n_submitted = 0
 
+    failed = []     # the host stage stopped at a read (the reference's KeyError): nothing after that read may come out
+
     def finish(b, b_idx, labels, status, dur):
+        if failed:
+            return
+        try:
+            _finish(b, b_idx, labels, status, dur)
+        except BaseException as e:
+            failed.append(e)
+            raise
+
+    def _finish(b, b_idx, labels, status, dur):
         seqs = None
         if isinstance(labels, tuple):
             # pipelined chunk mode: the label matrix as the device left it -> consensus strings of every read in one native
@@ -271,6 +283,10 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
             if st != 0:
                 report_skipped(rid, st)
                 continue
+            if lab is None and seqs is None:
+                # sparse RNA model: this read's beam search kept a labeling whose context the model does not hold -- the
+                # reference dies here with KeyError (decode.py:83, uncaught in basecall.py:70-141); the reads before it are out
+                raise KeyError(f"read {rid}: the RNA model holds no entry for a context of the beam search (radian/decode.py:83)")
             seq = next(seqs) if seqs is not None else host_finish(lab, args)
             if writer is not None:
                 writer.write(rid, seq)
@@ -384,10 +400,30 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
     return results
 
 
-def load_artifacts(args):
+ARTIFACT_CACHE = "artifacts.npz"
+
+
+def save_artifacts(art, directory):
+    """the parsed artefacts for the ranks of a multi-GPU job (launch.run_multi_gpu): parsing the real RNA model -- 4^11 keys,
+    ~400 MB of JSON -- takes ~25 s (tools/lm_load_bench.py); the launcher has done it to validate the arguments, so the rank that
+    feeds the broadcast reads the arrays back instead of parsing again"""
+    np.savez(os.path.join(directory, ARTIFACT_CACHE), dilations=np.asarray(art["dilations"], dtype=np.int64), weights=art["weights"],
+             lm_table=art["lm_table"] if art["lm_table"] is not None else np.zeros((0, 4)), lm_k=art["lm_k"],
+             lm_hashed_order=art.get("lm_hashed_order", 0))
+
+
+def load_artifacts(args, cache_dir=None):
     """Host-only half of basecall.py:47-62: parse / validate the signal model and (global mode) the RNA model.
     Returns {"dilations", "weights", "lm_table", "lm_k"}; raises what the reference would (KeyError for a context
-    length that does not match the RNA model, FileNotFoundError for a missing file) before any GPU is touched."""
+    length that does not match the RNA model, FileNotFoundError for a missing file) before any GPU is touched.
+    cache_dir: where the launcher left its parse of the same arguments (save_artifacts)."""
+    if cache_dir is not None and os.path.exists(os.path.join(cache_dir, ARTIFACT_CACHE)):
+        with np.load(os.path.join(cache_dir, ARTIFACT_CACHE)) as z:
+            art = {"dilations": tuple(int(d) for d in z["dilations"]), "weights": z["weights"],
+                   "lm_table": z["lm_table"] if z["lm_table"].shape[0] else None, "lm_k": int(z["lm_k"])}
+            if int(z["lm_hashed_order"]):
+                art["lm_hashed_order"] = int(z["lm_hashed_order"])
+        return art
     dil = load_dilations(args.sig_config)
     art = {"dilations": dil, "weights": load_sig_model(args.sig_model, dil), "lm_table": None, "lm_k": 0}
     if args.rna_model != "None":

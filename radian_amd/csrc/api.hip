@@ -476,11 +476,19 @@ int rd_model_halo(const rd_ctx* ctx)
 }
 
 // --------------------------------------------------------------------------------------------- LM
+// doubles of the LM image: table [n][4], entropies [n], then one bit per context ("absent from a sparse model"), padded to doubles
+static size_t lm_image_doubles(int table_order)
+{
+    const size_t n = (size_t)1 << (2 * table_order);
+    return n * 5 + (n + 63) / 64;
+}
+
 static void lm_bind(LM& lm)
 {
     const size_t n = (size_t)1 << (2 * lm.table_order);
     lm.table = lm.storage.as<double>();
     lm.d_entropy = lm.table + n * 4;
+    lm.d_missing = (uint32_t*)(lm.table + n * 5);
 }
 
 static int load_lm_table(rd_ctx* ctx, const double* table, int table_order, int context_len, int hashed)
@@ -492,7 +500,21 @@ static int load_lm_table(rd_ctx* ctx, const double* table, int table_order, int 
     RD_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)1 << (2 * table_order);
     // per-context entropy, decode.py:73-76,85-90 (math.log == glibc log; python sum is left-assoc)
+    // A row of NaNs marks a context that the (sparse) model does not hold: the reference's dict lookup raises KeyError when the
+    // search reaches it (decode.py:83).  Such rows are zeroed on the device, their gate stays closed (entropy +inf) and their bit
+    // is set in the "absent" mask, which the beam search checks for every labeling that enters the beam.
     std::vector<double> ent(n);
+    std::vector<uint32_t> missing(((n + 63) / 64) * 2, 0u);
+    std::vector<double> patched;
+    size_t n_missing = 0;
+    for (size_t c = 0; c < n && !hashed; c++)
+        if (table[c * 4] != table[c * 4]) {
+            if (patched.empty()) patched.assign(table, table + n * 4);
+            for (int i = 0; i < 4; i++) patched[c * 4 + i] = 0.0;
+            missing[c >> 5] |= 1u << (c & 31);
+            n_missing++;
+        }
+    if (n_missing) table = patched.data();
     for (size_t c = 0; c < n; c++) {
         const double* d = table + c * 4;
         double s = 0.0;
@@ -504,14 +526,17 @@ static int load_lm_table(rd_ctx* ctx, const double* table, int table_order, int 
                 any = true;
             }
         ent[c] = any ? -s : 0.0;
+        if (n_missing && ((missing[c >> 5] >> (c & 31)) & 1u)) ent[c] = INFINITY;
     }
     lm.k = context_len;
     lm.table_order = table_order;
     lm.hashed = hashed;
-    if (lm.storage.reserve(n * 5 * sizeof(double))) return RD_ERR_NOMEM;
+    lm.sparse = n_missing ? 1 : 0;
+    if (lm.storage.reserve(lm_image_doubles(table_order) * sizeof(double))) return RD_ERR_NOMEM;
     lm_bind(lm);
     RD_HIP(hipMemcpy(lm.table, table, n * 4 * sizeof(double), hipMemcpyHostToDevice));
     RD_HIP(hipMemcpy(lm.d_entropy, ent.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    RD_HIP(hipMemcpy(lm.d_missing, missing.data(), missing.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     lm.loaded = true;
     return RD_OK;
 }
@@ -683,6 +708,7 @@ int decode_and_fetch(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t
     RD_HIP(hipStreamSynchronize(ds));
     ctx->h_stage_busy = false;   // (ds waited for ctx->stream's event: the metadata copy is done)
     for (int i = 0; i < n_seq; i++) {
+        if (label_len[i] == RD_LEN_MISSING_CONTEXT && use_lm) continue;   // sparse LM: the search reached an absent context (the caller raises KeyError)
         if (label_len[i] < 0 || label_len[i] > seq_len[i]) {
             rd_set_error("decode: sequence %d produced an impossible label length %d (rows %d)", i, label_len[i], seq_len[i]);
             return RD_ERR_STATE;
@@ -1702,7 +1728,7 @@ struct RcclState {
 
 struct BcastHeader {
     int32_t model_loaded, nblocks, dil[RD_MAX_BLOCKS];
-    int32_t lm_loaded, lm_k, lm_order, lm_hashed;
+    int32_t lm_loaded, lm_k, lm_order, lm_hashed, lm_sparse;
     int64_t model_floats, lm_doubles;
     float inv_scale[2 * RD_MAX_BLOCKS], inv_scale_d1;
 };
@@ -1771,7 +1797,8 @@ static void artifacts_header(const rd_ctx* ctx, BcastHeader& hd)
     hd.lm_k = ctx->lm.k;
     hd.lm_order = ctx->lm.table_order;
     hd.lm_hashed = ctx->lm.hashed;
-    hd.lm_doubles = ctx->lm.loaded ? (int64_t)5 << (2 * ctx->lm.table_order) : 0;
+    hd.lm_sparse = ctx->lm.sparse;
+    hd.lm_doubles = ctx->lm.loaded ? (int64_t)lm_image_doubles(ctx->lm.table_order) : 0;
 }
 
 // The receiver's side: geometry and scales from the header, storage reserved and bound; the images are not there yet
@@ -1791,11 +1818,12 @@ static int artifacts_prepare(rd_ctx* ctx, const BcastHeader& hd)
     ctx->lm.loaded = false;
     ctx->lm.gate_valid = false;
     if (hd.lm_loaded) {
-        RD_REQUIRE(hd.lm_order >= 1 && hd.lm_order <= 13 && hd.lm_doubles == ((int64_t)5 << (2 * hd.lm_order)),
+        RD_REQUIRE(hd.lm_order >= 1 && hd.lm_order <= 13 && hd.lm_doubles == (int64_t)lm_image_doubles(hd.lm_order),
                    "artefact header: LM table of order %d with %lld doubles", hd.lm_order, (long long)hd.lm_doubles);
         ctx->lm.k = hd.lm_k;
         ctx->lm.table_order = hd.lm_order;
         ctx->lm.hashed = hd.lm_hashed;
+        ctx->lm.sparse = hd.lm_sparse;
         if (ctx->lm.storage.reserve((size_t)hd.lm_doubles * 8)) return RD_ERR_NOMEM;
         lm_bind(ctx->lm);
     }

@@ -77,12 +77,18 @@ int rd_assemble_batch_dev(hipStream_t st, const void* d_probs, const AsmRead* d_
 {
     if (n_reads <= 0 || max_n <= 0) return RD_OK;
     const int threads = 256;
-    const dim3 grid((unsigned)((max_n + threads - 1) / threads), (unsigned)n_reads);
-    if (in_f16)
-        hipLaunchKernelGGL(assemble_batch_kernel<_Float16>, grid, dim3(threads), 0, st, (const _Float16*)d_probs, d_reads, T, step, d_out, streamed);
-    else
-        hipLaunchKernelGGL(assemble_batch_kernel<float>, grid, dim3(threads), 0, st, (const float*)d_probs, d_reads, T, step, d_out, streamed);
-    RD_HIP(hipGetLastError());
+    // grid.y is capped at 65535 by HIP: a batch of more reads (many short multi-window reads under a large
+    // --gpu-batch-windows) goes out in slices of the record array
+    for (int r0 = 0; r0 < n_reads; r0 += 65535) {
+        const int nr = n_reads - r0 < 65535 ? n_reads - r0 : 65535;
+        const dim3 grid((unsigned)((max_n + threads - 1) / threads), (unsigned)nr);
+        if (in_f16)
+            hipLaunchKernelGGL(assemble_batch_kernel<_Float16>, grid, dim3(threads), 0, st, (const _Float16*)d_probs, d_reads + r0, T, step, d_out,
+                               streamed);
+        else
+            hipLaunchKernelGGL(assemble_batch_kernel<float>, grid, dim3(threads), 0, st, (const float*)d_probs, d_reads + r0, T, step, d_out, streamed);
+        RD_HIP(hipGetLastError());
+    }
     return RD_OK;
 }
 

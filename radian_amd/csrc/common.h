@@ -82,10 +82,12 @@ struct LM {
     int hashed = 0;                 // 1: long-context mode, row = hash(context) (decode.hip)
     double* table = nullptr;        // [4^table_order][4] device
     double* d_entropy = nullptr;    // [4^k] device: entropy of each context's distribution (glibc log, computed at load)
+    int sparse = 0;                 // 1: some contexts are absent (rows of NaN at rd_load_lm): d_missing has their bits
+    uint32_t* d_missing = nullptr;  // bit ctx: the model does not hold this context (decode.py:83 raises KeyError on it)
     uint32_t* gate_bits = nullptr;  // bit ctx: d_entropy[ctx] < gate_r_thr
     double gate_r_thr = 0.0;
     bool gate_valid = false;
-    DevBuf storage, gate_storage;   // storage = table followed by d_entropy (one RCCL broadcast)
+    DevBuf storage, gate_storage;   // storage = table, d_entropy, d_missing (one RCCL broadcast)
 };
 
 // One 32-row SUB-TILE of the forward: rows [t0, t0+32) of a segment whose time step 0 is global row seg_row; a

@@ -209,6 +209,11 @@ struct DecodeArgs {
     // LM
     const double* lm_table;
     const uint32_t* lm_gate;
+    // sparse models (nullable): bit ctx = the model holds no entry for this context.  The reference looks model[context] up for
+    // every kept labeling of at least k labels at every time step, gate or no gate (decode.py:83,161,182), and raises KeyError on
+    // an absent one; a labeling's context changes only when it is created, so each labeling that ENTERS the beam before the last
+    // time step is checked once, and a hit is reported as label_len = -1 for the sequence.
+    const uint32_t* lm_missing;
     int k;                // context length: labels per LM context (decode.py:42-49)
     // long contexts (k > 13, a mode of this library with no reference behaviour -- the reference needs a dict entry per
     // context, decode.py:83): the table row of a context is H(context) & tmask with the polynomial hash
@@ -331,6 +336,7 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
     int nb = 1;              // beams currently kept (workgroup-uniform)
     int next_id = 1;         // next free trie node id (wave 0)
     int cur = 0;
+    bool missed = false;     // sparse LM: a labeling this lane built has a context the model does not hold
     seq_sync<NW>();
 
     for (int t0 = 0; t0 < T; t0 += 64) {
@@ -741,6 +747,12 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
                         h_new = (unsigned)meta.y * kHashB + (unsigned)cl - lout * a.bk;
                         hp_new = is_ext ? (unsigned)meta.y : (unsigned)meta.z;
                     }
+                    if constexpr (LM && !HC) {
+                        if (a.lm_missing && is_ext && sl2.y + 1 >= a.k && t0 + tt + 1 < T) {
+                            const unsigned cx = h_new & ctx_mask;
+                            missed |= ((a.lm_missing[cx >> 5] >> (cx & 31)) & 1u) != 0u;
+                        }
+                    }
                     *(int4*)&ns[lane].node = make_int4(new_node, is_ext ? (int)h_new : meta.y, (int)hp_new, 0);
                     *(int4*)&ns[lane].child[0] = make_int4(is_ext ? ch.x : chs.x, is_ext ? ch.y : chs.y, is_ext ? ch.z : chs.z, is_ext ? ch.w : chs.w);
                     tab[new_node & (TN - 1)] = (((unsigned)new_node >> LOG_TN) << 8) | (unsigned)lane;
@@ -757,6 +769,7 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
     // ---------------- traceback of the best labeling (slot 0 = rank 0; decode.py:207-210) --------------------
     int tid_end = tid;
     asm volatile("" : "+v"(tid_end));   // (the lane mask of "tid == 0" is computed here, not carried in SGPRs from kernel entry)
+    const bool any_missed = LM && __any(missed);     // (Phase F runs on wave 0, which also holds thread 0)
     if (tid_end == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         // The output pointers are only needed here.  Read through the kernarg segment behind an opaque copy of its address, they are
@@ -773,7 +786,7 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
             out[p] = (uint8_t)(bp & 3);
             n = bp >> 2;
         }
-        ap->label_len[seq] = len;
+        ap->label_len[seq] = any_missed ? -1 : len;
         if (ap->best_score) ap->best_score[seq] = fs.ptot;
     }
 }
@@ -865,6 +878,7 @@ __global__ __launch_bounds__(64) void beam_search2_kernel(DecodeArgs a, int n_se
     int nb = 1;              // beams currently kept (uniform within the half)
     int next_id = 1;         // next free trie node id of the half's sequence
     int cur = 0;             // (both halves flip together; a half that has ended stops writing)
+    bool missed = false;     // sparse LM: see beam_search_kernel
     // the longer of the two sequences bounds the loop (wave-uniform)
     const int T_other = __shfl_xor(T, 32);
     const int Tmax = __builtin_amdgcn_readfirstlane(T > T_other ? T : T_other);
@@ -1133,6 +1147,12 @@ __global__ __launch_bounds__(64) void beam_search2_kernel(DecodeArgs a, int n_se
                     const int new_node = is_ext ? my_node : meta.x;
                     *(int2*)&ns[hl].last = make_int2(is_ext ? cl : sl2.x, is_ext ? sl2.y + 1 : sl2.y);
                     const unsigned h_new = ((unsigned)meta.y << 2) | (unsigned)cl;
+                    if constexpr (LM) {
+                        if (a.lm_missing && is_ext && sl2.y + 1 >= a.k && t0 + tt + 1 < T) {
+                            const unsigned cx = h_new & ctx_mask;
+                            missed |= ((a.lm_missing[cx >> 5] >> (cx & 31)) & 1u) != 0u;
+                        }
+                    }
                     *(int4*)&ns[hl].node = make_int4(new_node, is_ext ? (int)h_new : meta.y, meta.z, 0);
                     *(int4*)&ns[hl].child[0] = make_int4(is_ext ? ch.x : chs.x, is_ext ? ch.y : chs.y, is_ext ? ch.z : chs.z, is_ext ? ch.w : chs.w);
                     tab[new_node & (TN - 1)] = (((unsigned)new_node >> LOG_TN) << 8) | (unsigned)hl;
@@ -1148,6 +1168,7 @@ __global__ __launch_bounds__(64) void beam_search2_kernel(DecodeArgs a, int n_se
     // ---------------- traceback of each half's best labeling (decode.py:207-210)
     int hl_end = hl;
     asm volatile("" : "+v"(hl_end));
+    const bool any_missed = LM && (__ballot(missed) & hmask) != 0ull;
     if (hl_end == 0 && have) {
         __builtin_amdgcn_s_waitcnt(0);
         const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1162,7 +1183,7 @@ __global__ __launch_bounds__(64) void beam_search2_kernel(DecodeArgs a, int n_se
             out[p] = (uint8_t)(bp & 3);
             n = bp >> 2;
         }
-        ap->label_len[seq] = len;
+        ap->label_len[seq] = any_missed ? -1 : len;
         if (ap->best_score) ap->best_score[seq] = fs.ptot;
     }
 }
@@ -1292,6 +1313,7 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_
     a.glibc_math = ctx->decode_math;
     a.lm_table = use_lm ? ctx->lm.table : nullptr;
     a.lm_gate = use_lm ? ctx->lm.gate_bits : nullptr;
+    a.lm_missing = (use_lm && ctx->lm.sparse && !ctx->lm.hashed) ? ctx->lm.d_missing : nullptr;
     a.k = use_lm ? ctx->lm.k : 0;
     a.hashed = use_lm ? ctx->lm.hashed : 0;
     a.tmask = use_lm ? (unsigned)(((size_t)1 << (2 * ctx->lm.table_order)) - 1) : 0u;

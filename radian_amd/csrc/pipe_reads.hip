@@ -186,6 +186,10 @@ int slot_collect(ReadsPipe* p, RSlot& s)
         for (int i = 0; i < sb.n_seq; i++) {
             const RSeq& q = s.seqs[sb.seq0 + i];
             const int32_t n = len_of[sb.seq0 + i];
+            if (n == RD_LEN_MISSING_CONTEXT) {   // sparse LM: the search reached an absent context (the caller raises KeyError)
+                sb.user_lens[i] = n;
+                continue;
+            }
             if (n < 0 || n > q.len) {
                 rd_set_error("pipeline: sequence %d produced an impossible label length %d (rows %d)", sb.seq0 + i, n, q.len);
                 rc = RD_ERR_STATE;

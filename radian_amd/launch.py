@@ -25,7 +25,10 @@ class StreamMerger:
     key: a rank with parsed-but-unwritten records is represented by the first of them; one without is bounded from below
     by the first key it may still produce -- the next expected read of its oldest unfinished claim (a claim is finished
     when a record of a later claim, or the end mark, shows up: skipped reads leave no record), else its latest key.
-    One record per rank is all the merge needs in memory beyond what it has parsed and not yet been allowed to write."""
+    One record per rank is all the merge needs in memory beyond what it has parsed and not yet been allowed to write.
+
+    The FASTA files are written under a hidden directory inside fasta_dir and moved into place by finish(): a job that fails
+    (one rank down stops all) leaves no valid-looking partial reads-*.fasta behind -- abort() removes what was written."""
 
     INF = (float("inf"),)
 
@@ -40,7 +43,9 @@ class StreamMerger:
         self.claims = [deque() for _ in range(world)]    # [file, next expected read, hi] of unfinished claims, oldest first
         self.last = [(-1,)] * world                      # latest key seen from the rank
         self.ended = [False] * world
-        self.writer = FastaWriter(fasta_dir)
+        self.fasta_dir = fasta_dir
+        self.partial = tempfile.mkdtemp(prefix=".radian_partial_", dir=fasta_dir)   # same filesystem: finish() renames
+        self.writer = FastaWriter(self.partial)
         self.n = 0
 
     def _read(self, r):
@@ -81,8 +86,11 @@ class StreamMerger:
             return self.recs[r][0][0]
         if self.ended[r]:
             return self.INF
-        if self.claims[r]:
-            return (self.claims[r][0][0], self.claims[r][0][1])
+        cl = self.claims[r]
+        while len(cl) > 1 and cl[0][1] >= cl[0][2]:
+            cl.popleft()     # its last read has reported and a newer claim is known: the bound moves on to that claim's first read
+        if cl:
+            return (cl[0][0], cl[0][1])
         return self.last[r]
 
     def poll(self):
@@ -110,8 +118,13 @@ class StreamMerger:
                 self.claims[r].clear()
             self.poll()
             assert not any(self.recs), "internal: records left after the final merge pass"
-        finally:
-            self.close()
+        except BaseException:
+            self.abort()
+            raise
+        self.close()
+        for name in sorted(os.listdir(self.partial)):
+            os.replace(os.path.join(self.partial, name), os.path.join(self.fasta_dir, name))
+        os.rmdir(self.partial)
         return self.n
 
     def close(self):
@@ -119,6 +132,11 @@ class StreamMerger:
         for f in self.fh:
             if f is not None:
                 f.close()
+
+    def abort(self):
+        """the job failed: close and delete what has been written so far"""
+        self.close()
+        shutil.rmtree(self.partial, ignore_errors=True)
 
 
 def _key(k):
@@ -183,12 +201,14 @@ def run_ranks(world, cmd, env_extra=None, capture_rank0=False, on_poll=None):
 
 def run_multi_gpu(args, argv):
     from . import fast5
-    from .basecall import load_artifacts
+    from .basecall import load_artifacts, save_artifacts
     world = args.gpus
-    load_artifacts(args)   # host-only validation: raises here, in the parent, exactly what a single-GPU run would raise
+    art = load_artifacts(args)   # host-only validation: raises here, in the parent, exactly what a single-GPU run would raise
     scratch = tempfile.mkdtemp(prefix="radian_mgpu_")
     merger = None
     try:
+        save_artifacts(art, scratch)   # (the rank that feeds the broadcast reads this back instead of parsing again)
+        del art
         with open(os.path.join(scratch, "files.json"), "w") as f:
             json.dump(fast5.list_files(args.fast5_dir), f)   # one enumeration: every rank sees the same file order
         merger = StreamMerger(scratch, world, args.fasta_dir)
@@ -205,7 +225,7 @@ def run_multi_gpu(args, argv):
         return {"records": n, "ranks": ranks}   # what each rank ran with: device, device contexts, agreed transport
     finally:
         if merger is not None:
-            merger.close()
+            merger.abort()
         shutil.rmtree(scratch, ignore_errors=True)
 
 
@@ -273,7 +293,7 @@ def worker(scratch, argv):
         os._exit(3)   # a helper thread is stuck inside ncclCommInitRank; the parent stops the other ranks
     # rank 0 parses / repacks the artefacts; everyone gets the device images by one broadcast (file transport: each
     # rank loads them itself).  The parent has validated them already, so rank 0 cannot fail here for a bad argument.
-    comm.bcast_artifacts(be, lambda b: apply_artifacts(args, b, load_artifacts(args)))
+    comm.bcast_artifacts(be, lambda b: apply_artifacts(args, b, load_artifacts(args, cache_dir=scratch)))
     # the rank's further device contexts (--device-contexts, as in a single-GPU run: one context's forward overlaps the
     # other's beam search) take the images from the one that received the broadcast -- a device copy, no second parse
     backends = [be] + [Backend(device) for _ in range(n_contexts(args) - 1)]

@@ -1,13 +1,23 @@
-"""RNA k-mer language model: JSON -> dense table for rd_load_lm.
+"""RNA k-mer language model: JSON -> table for rd_load_lm.
 
 The reference loads `{ "ACGT..."(k chars): [pA, pC, pG, pT] }` and re-keys it by tuples of label indices
-(radian/basecall.py:48-57); decode.py:83 looks a context up by its tuple.  The dense table is indexed by
-the base-4 number of the context, first (oldest) character most significant."""
+(radian/basecall.py:48-57); decode.py:83 looks a context up by its tuple.  The table is indexed by the base-4 number of
+the context, first (oldest) character most significant.
+
+A model that does not hold every one of the 4^k contexts (a sparse JSON) loads like in the reference: the rows of absent
+contexts are NaN, which rd_load_lm turns into the "absent" mask the beam search checks; a read whose search reaches one
+fails with the reference's KeyError (decode.py:83) -- and only such a read.
+
+The real model has 4^11 = 4 194 304 keys: the keys are converted to table rows in one vectorised pass (the JSON parse itself
+is the standard library's)."""
 import json
 
 import numpy as np
 
 _IDX = {"A": 0, "C": 1, "G": 2, "T": 3}
+_CODE = np.full(256, 255, dtype=np.uint8)
+for _c, _i in _IDX.items():
+    _CODE[ord(_c)] = _i
 
 
 def context_index(context):
@@ -18,26 +28,56 @@ def context_index(context):
     return i
 
 
+def _indices_of_str_keys(keys, k):
+    """base-4 row numbers of n k-character keys in one pass over their bytes"""
+    raw = "".join(keys).encode("ascii")                       # (a non-ASCII key raises here: not an ACGT string)
+    if len(raw) != len(keys) * k:
+        raise ValueError("RNA model contexts have mixed lengths")
+    codes = _CODE[np.frombuffer(raw, dtype=np.uint8)].reshape(len(keys), k)
+    if (codes == 255).any():
+        bad = keys[int(np.argmax((codes == 255).any(axis=1)))]
+        raise ValueError(f"{bad!r} is not in list")            # bases.index(b) at basecall.py:56 raises ValueError on a non-ACGT character
+    weights = (np.int64(4) ** np.arange(k - 1, -1, -1, dtype=np.int64))
+    return codes.astype(np.int64) @ weights
+
+
 def table_from_dict(model):
-    """dict {context str | tuple: [4 probs]} -> (table float64 [4^k,4], k).  Every context must be present
-    (the reference raises KeyError on a missing one, decode.py:83; a dense table cannot represent that)."""
+    """dict {context str | tuple of label ints: [4 probs]} -> (table float64 [4^k,4], k).  Contexts the dict does not hold
+    become rows of NaN (sparse model: module docstring).  Keys must share one length."""
     if not model:
         raise ValueError("empty RNA model")
-    k = len(next(iter(model)))
+    keys = list(model.keys())
+    k = len(keys[0])
+    if not (1 <= k <= 13):
+        raise ValueError(f"RNA model contexts of {k} labels: a table of 4^{k} rows is out of range (1..13)")
     n = 4 ** k
-    if len(model) != n:
-        raise ValueError(f"RNA model has {len(model)} contexts of length {k}; a dense table needs all {n}")
-    table = np.empty((n, 4), dtype=np.float64)
-    seen = np.zeros(n, dtype=bool)
-    for ctx, dist in model.items():
-        if len(ctx) != k:
+    if isinstance(keys[0], str):
+        if any(len(c) != k for c in keys):
             raise ValueError("RNA model contexts have mixed lengths")
-        i = context_index(ctx)
-        table[i] = dist
-        seen[i] = True
-    if not seen.all():
-        raise ValueError("RNA model has duplicate / missing contexts")
+        idx = _indices_of_str_keys(keys, k)
+    else:
+        arr = np.asarray(keys, dtype=np.int64)
+        if arr.ndim != 2 or arr.shape[1] != k:
+            raise ValueError("RNA model contexts have mixed lengths")
+        if ((arr < 0) | (arr > 3)).any():
+            raise ValueError("RNA model context labels must be 0..3")
+        idx = arr @ (np.int64(4) ** np.arange(k - 1, -1, -1, dtype=np.int64))
+    try:
+        vals = np.asarray(list(model.values()), dtype=np.float64)
+    except ValueError as e:
+        raise ValueError("RNA model distributions must be four probabilities each") from e
+    if vals.shape != (len(keys), 4):
+        raise ValueError("RNA model distributions must be four probabilities each")
+    if np.isnan(vals).any():
+        raise ValueError("RNA model holds NaN probabilities")
+    table = np.full((n, 4), np.nan, dtype=np.float64) if len(keys) < n else np.empty((n, 4), dtype=np.float64)
+    table[idx] = vals          # (JSON object keys are unique after json.load: a repeated key keeps its last value, as in the reference)
     return table, k
+
+
+def n_missing(table):
+    """contexts a (sparse) table does not hold"""
+    return int(np.isnan(table[:, 0]).sum())
 
 
 def load_json(path):

@@ -43,8 +43,11 @@ class OracleBackend:
         out = []
         for r in range(len(pads)):
             m = orc.assemble_matrices(probs[read_win_off[r]:read_win_off[r + 1]], int(pads[r]), step)
-            lab, _ = orc.beam_search_labels(m, beam_width, self.lm if use_lm else None, s_threshold, r_threshold,
-                                            self.k if use_lm else 0)
+            try:
+                lab, _ = orc.beam_search_labels(m, beam_width, self.lm if use_lm else None, s_threshold, r_threshold,
+                                                self.k if use_lm else 0)
+            except KeyError:
+                lab = None    # (what radian_amd.Backend returns for RD_LEN_MISSING_CONTEXT: a sparse LM's absent context was reached)
             out.append(lab)
         return out
 

@@ -10,26 +10,6 @@ R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.ab
 sys.path.insert(0, R)
 from radian_amd import Backend, synthetic, weights
 
-rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-rng = np.random.default_rng(seed)
-be = Backend(0)
-w = weights.synthetic_weights(seed=1234).copy()
-w[-645:-5] *= np.float32(0.05)
-be.load_weights(w)
-be.load_lm(rng.dirichlet([0.3] * 4, size=4 ** 3), 3)
-
-
-def read_set(chunk, step):
-    n = int(rng.integers(1, 30))
-    out = []
-    for _ in range(n):
-        L = int(rng.choice([1, 2, chunk - 1, chunk, chunk + 1, chunk + step, 3 * step, int(rng.integers(1, 9000))]))
-        if rng.random() < 0.05:
-            out.append(np.full(max(L, 2), 7, dtype=np.int16))
-        else:
-            out.append(synthetic.synthetic_reads(1, L, seed=int(rng.integers(1 << 30)))[0])
-    return out
 
 
 def same(mode, a, b, status):
@@ -38,56 +18,82 @@ def same(mode, a, b, status):
     return all(st != 0 or (len(x) == len(y) and all(np.array_equal(p, q) for p, q in zip(x, y))) for x, y, st in zip(a, b, status))
 
 
-t0 = time.time()
-n_fail = n_batches = 0
-for rd in range(rounds):
-    be.pipe_flush()
-    be.pipe_config(int(rng.integers(1, 7)))
-    be.pipe_set_lanes(int(rng.integers(1, 5)))
-    be.set_decode_partition(int(rng.choice([-1, 0, 1, 4])))
-    be.set_logits("f16" if rng.random() < 0.2 else "f32")
-    be.set_precision("bf16x3" if rng.random() < 0.15 else "fp32")
-    chunk = int(rng.choice([256, 512, 1024]))
-    plan = []
-    for _ in range(int(rng.integers(2, 9))):
-        mode = "chunk" if rng.random() < 0.4 else "global"
-        step = int(rng.choice([chunk, chunk // 2, chunk // 4, max(1, chunk - 252), max(1, chunk - 253), int(rng.integers(chunk // 8, chunk + 1))]))
-        W = int(rng.choice([1, 3, 6, 10, 12, 13, 25]))
-        lm = bool(mode == "global" and rng.random() < 0.5)
-        thr = (float(rng.choice([0.0, 0.3, 0.6])), float(rng.choice([0.2, 0.9, 5.0])))
-        plan.append((mode, step, W, lm, thr, read_set(chunk, step)))
-    ref = []
-    for mode, step, W, lm, thr, reads in plan:
-        if mode == "global":
-            ref.append(be.basecall_raw_global(reads, 4, chunk, step, W, lm, *thr))
-        else:
-            ref.append(be.basecall_raw_chunk(reads, 4, chunk, step, W))
-    tickets = []
-    for i, (mode, step, W, lm, thr, reads) in enumerate(plan):
-        tickets.append(be.pipe_submit_raw(mode, reads, 4, chunk, step, W, lm, *thr))
-        r = rng.random()
-        if r < 0.2:
-            be.pipe_progress(0)
-        elif r < 0.3:
-            tickets[int(rng.integers(0, len(tickets)))].wait()
-        elif r < 0.4:      # a blocking call in between shares the context's workspaces
-            j = int(rng.integers(0, len(plan)))
-            m2, s2, W2, lm2, thr2, reads2 = plan[j]
-            again = be.basecall_raw_global(reads2, 4, chunk, s2, W2, lm2, *thr2) if m2 == "global" else be.basecall_raw_chunk(reads2, 4, chunk, s2, W2)
-            if not (np.array_equal(again[1], ref[j][1]) and same(m2, again[0], ref[j][0], ref[j][1])):
-                n_fail += 1
-                print(f"MISMATCH (interleaved blocking call) round={rd} batch={j}", flush=True)
-    if rng.random() < 0.5:
+def run(rounds=100, seed=0, max_len=9000, max_reads=30, log=print):
+    """-> (batches delivered, mismatches against the blocking entry points)"""
+    rng = np.random.default_rng(seed)
+    be = Backend(0)
+    w = weights.synthetic_weights(seed=1234).copy()
+    w[-645:-5] *= np.float32(0.05)
+    be.load_weights(w)
+    be.load_lm(rng.dirichlet([0.3] * 4, size=4 ** 3), 3)
+
+    def read_set(chunk, step):
+        n = int(rng.integers(1, max_reads))
+        out = []
+        for _ in range(n):
+            L = int(rng.choice([1, 2, chunk - 1, chunk, chunk + 1, chunk + step, 3 * step, int(rng.integers(1, max_len))]))
+            if rng.random() < 0.05:
+                out.append(np.full(max(L, 2), 7, dtype=np.int16))
+            else:
+                out.append(synthetic.synthetic_reads(1, L, seed=int(rng.integers(1 << 30)))[0])
+        return out
+
+    t0 = time.time()
+    n_fail = n_batches = 0
+    for rd in range(rounds):
         be.pipe_flush()
-    for i, t in enumerate(tickets):
-        got, status = t.result()
-        n_batches += 1
-        if not (np.array_equal(status, ref[i][1]) and same(plan[i][0], got, ref[i][0], status)):
-            n_fail += 1
-            mode, step, W, lm, thr, reads = plan[i]
-            print(f"MISMATCH round={rd} batch={i} mode={mode} chunk={chunk} step={step} W={W} lm={lm} thr={thr} lens={[len(r) for r in reads]}", flush=True)
-    if rd % 10 == 9:
-        print(f"{rd + 1} rounds, {n_batches} batches, {n_fail} failures, {time.time() - t0:.0f}s", flush=True)
-be.close()
-print(f"done: {rounds} rounds, {n_batches} batches, {n_fail} failures")
-sys.exit(1 if n_fail else 0)
+        be.pipe_config(int(rng.integers(1, 7)))
+        be.pipe_set_lanes(int(rng.integers(1, 5)))
+        be.set_decode_partition(int(rng.choice([-1, 0, 1, 4])))
+        be.set_logits("f16" if rng.random() < 0.2 else "f32")
+        be.set_precision("bf16x3" if rng.random() < 0.15 else "fp32")
+        chunk = int(rng.choice([256, 512, 1024]))
+        plan = []
+        for _ in range(int(rng.integers(2, 9))):
+            mode = "chunk" if rng.random() < 0.4 else "global"
+            step = int(rng.choice([chunk, chunk // 2, chunk // 4, max(1, chunk - 252), max(1, chunk - 253), int(rng.integers(chunk // 8, chunk + 1))]))
+            W = int(rng.choice([1, 3, 6, 7, 10, 12, 13, 25]))
+            lm = bool(mode == "global" and rng.random() < 0.5)
+            thr = (float(rng.choice([0.0, 0.3, 0.6])), float(rng.choice([0.2, 0.9, 5.0])))
+            plan.append((mode, step, W, lm, thr, read_set(chunk, step)))
+        ref = []
+        for mode, step, W, lm, thr, reads in plan:
+            if mode == "global":
+                ref.append(be.basecall_raw_global(reads, 4, chunk, step, W, lm, *thr))
+            else:
+                ref.append(be.basecall_raw_chunk(reads, 4, chunk, step, W))
+        tickets = []
+        for i, (mode, step, W, lm, thr, reads) in enumerate(plan):
+            tickets.append(be.pipe_submit_raw(mode, reads, 4, chunk, step, W, lm, *thr))
+            r = rng.random()
+            if r < 0.2:
+                be.pipe_progress(0)
+            elif r < 0.3:
+                tickets[int(rng.integers(0, len(tickets)))].wait()
+            elif r < 0.4:      # a blocking call in between shares the context's workspaces
+                j = int(rng.integers(0, len(plan)))
+                m2, s2, W2, lm2, thr2, reads2 = plan[j]
+                again = be.basecall_raw_global(reads2, 4, chunk, s2, W2, lm2, *thr2) if m2 == "global" else be.basecall_raw_chunk(reads2, 4, chunk, s2, W2)
+                if not (np.array_equal(again[1], ref[j][1]) and same(m2, again[0], ref[j][0], ref[j][1])):
+                    n_fail += 1
+                    log(f"MISMATCH (interleaved blocking call) round={rd} batch={j}")
+        if rng.random() < 0.5:
+            be.pipe_flush()
+        for i, t in enumerate(tickets):
+            got, status = t.result()
+            n_batches += 1
+            if not (np.array_equal(status, ref[i][1]) and same(plan[i][0], got, ref[i][0], status)):
+                n_fail += 1
+                mode, step, W, lm, thr, reads = plan[i]
+                log(f"MISMATCH round={rd} batch={i} mode={mode} chunk={chunk} step={step} W={W} lm={lm} thr={thr} lens={[len(r) for r in reads]}")
+        if rd % 10 == 9:
+            log(f"{rd + 1} rounds, {n_batches} batches, {n_fail} failures, {time.time() - t0:.0f}s")
+    be.close()
+    return n_batches, n_fail
+
+
+if __name__ == "__main__":
+    a = [int(x) for x in sys.argv[1:3]]
+    n_batches, n_fail = run(*a, log=lambda m: print(m, flush=True))
+    print(f"done: {n_batches} batches, {n_fail} failures")
+    sys.exit(1 if n_fail else 0)

@@ -8,13 +8,6 @@ sys.path.insert(0, R)
 from radian_amd import Backend, weights
 from radian_amd.preprocess import get_windows
 
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-rng = np.random.default_rng(seed)
-be = Backend(0)
-be.load_weights(weights.synthetic_weights(seed=1234))
-k = 3
-be.load_lm(rng.dirichlet([0.3] * 4, size=4 ** k), k)
 
 
 def windows(sig, chunk, step):
@@ -24,46 +17,60 @@ def windows(sig, chunk, step):
     return w.astype(np.float32), valid, pad
 
 
-t0 = time.time()
-n_fail = 0
-for it in range(iters):
-    chunk = int(rng.choice([64, 128, 256, 300, 512, 1000, 1024, 2048]))
-    step = int(rng.integers(1, chunk + 1)) if rng.random() < 0.5 else int(rng.choice([chunk, chunk // 2, max(1, chunk // 8), max(1, chunk - 252), max(1, chunk - 253)]))
-    if step < chunk // 16:
-        step = max(step, chunk // 16)          # bound the window count
-    n_reads = int(rng.integers(1, 7))
-    lengths = [int(rng.choice([1, 2, chunk - 1, chunk, chunk + 1, chunk + step, int(rng.integers(1, 6000))])) for _ in range(n_reads)]
-    W = int(rng.choice([1, 4, 10, 25]))
-    prec = "f16x3" if rng.random() < 0.3 else "fp32"
-    be.set_precision(prec)
-    sigs = [np.clip(rng.normal(size=n), -4, 4).astype(np.float32) for n in lengths]
-    mode = "chunk" if rng.random() < 0.5 else "global"
-    ok = True
-    try:
-        if mode == "chunk":
-            got = be.basecall_reads_chunk(sigs, chunk, step, W)
-            for r, sig in enumerate(sigs):
-                w, valid, _ = windows(sig, chunk, step)
-                exp = be.basecall_chunk(w, valid, W)
-                ok &= len(got[r]) == len(exp) and all(np.array_equal(a, b) for a, b in zip(got[r], exp))
-        else:
-            use_lm = bool(rng.random() < 0.5)
-            got = be.basecall_reads_global(sigs, chunk, step, W, use_lm, 0.5, 0.5)
-            wins, offs, pads = [], [0], []
-            for sig in sigs:
-                w, _, pad = windows(sig, chunk, step)
-                wins.append(w)
-                offs.append(offs[-1] + w.shape[0])
-                pads.append(pad)
-            exp = be.basecall_global(np.concatenate(wins), np.array(offs, dtype=np.int32), np.array(pads, dtype=np.int32), step, W, use_lm, 0.5, 0.5)
-            ok &= all(np.array_equal(a, b) for a, b in zip(got, exp))
-    except Exception as e:   # report and go on
-        ok = False
-        print("EXC", type(e).__name__, e)
-    if not ok:
-        n_fail += 1
-        print(f"MISMATCH it={it} mode={mode} prec={prec} chunk={chunk} step={step} W={W} lengths={lengths}", flush=True)
-    if it % 50 == 49:
-        print(f"{it + 1} iterations, {n_fail} failures, {time.time() - t0:.0f}s", flush=True)
-print(f"done: {iters} iterations, {n_fail} failures")
-sys.exit(1 if n_fail else 0)
+def run(iters=200, seed=0, max_len=6000, log=print):
+    """-> (geometries compared, geometries whose streamed labels differ from the window-level labels)"""
+    rng = np.random.default_rng(seed)
+    be = Backend(0)
+    be.load_weights(weights.synthetic_weights(seed=1234))
+    k = 3
+    be.load_lm(rng.dirichlet([0.3] * 4, size=4 ** k), k)
+    t0 = time.time()
+    n_fail = 0
+    for it in range(iters):
+        chunk = int(rng.choice([64, 128, 256, 300, 512, 1000, 1024, 2048]))
+        step = int(rng.integers(1, chunk + 1)) if rng.random() < 0.5 else int(rng.choice([chunk, chunk // 2, max(1, chunk // 8), max(1, chunk - 252), max(1, chunk - 253)]))
+        if step < chunk // 16:
+            step = max(step, chunk // 16)          # bound the window count
+        n_reads = int(rng.integers(1, 7))
+        lengths = [int(rng.choice([1, 2, chunk - 1, chunk, chunk + 1, chunk + step, int(rng.integers(1, max_len))])) for _ in range(n_reads)]
+        W = int(rng.choice([1, 4, 10, 25]))
+        prec = "f16x3" if rng.random() < 0.3 else "fp32"
+        be.set_precision(prec)
+        sigs = [np.clip(rng.normal(size=n), -4, 4).astype(np.float32) for n in lengths]
+        mode = "chunk" if rng.random() < 0.5 else "global"
+        ok = True
+        try:
+            if mode == "chunk":
+                got = be.basecall_reads_chunk(sigs, chunk, step, W)
+                for r, sig in enumerate(sigs):
+                    w, valid, _ = windows(sig, chunk, step)
+                    exp = be.basecall_chunk(w, valid, W)
+                    ok &= len(got[r]) == len(exp) and all(np.array_equal(a, b) for a, b in zip(got[r], exp))
+            else:
+                use_lm = bool(rng.random() < 0.5)
+                got = be.basecall_reads_global(sigs, chunk, step, W, use_lm, 0.5, 0.5)
+                wins, offs, pads = [], [0], []
+                for sig in sigs:
+                    w, _, pad = windows(sig, chunk, step)
+                    wins.append(w)
+                    offs.append(offs[-1] + w.shape[0])
+                    pads.append(pad)
+                exp = be.basecall_global(np.concatenate(wins), np.array(offs, dtype=np.int32), np.array(pads, dtype=np.int32), step, W, use_lm, 0.5, 0.5)
+                ok &= all(np.array_equal(a, b) for a, b in zip(got, exp))
+        except Exception as e:   # report and go on
+            ok = False
+            log(f"EXC {type(e).__name__} {e}")
+        if not ok:
+            n_fail += 1
+            log(f"MISMATCH it={it} mode={mode} prec={prec} chunk={chunk} step={step} W={W} lengths={lengths}")
+        if it % 50 == 49:
+            log(f"{it + 1} iterations, {n_fail} failures, {time.time() - t0:.0f}s")
+    be.close()
+    return iters, n_fail
+
+
+if __name__ == "__main__":
+    a = [int(x) for x in sys.argv[1:3]]
+    iters, n_fail = run(*a, log=lambda m: print(m, flush=True))
+    print(f"done: {iters} iterations, {n_fail} failures")
+    sys.exit(1 if n_fail else 0)

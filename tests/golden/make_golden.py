@@ -262,6 +262,46 @@ def gen_beam_lm():
 
 
 # ----------------------------------------------------------------------------------------------
+# 2b. beam_search with a SPARSE k-mer LM: the dict lacks some contexts; decode.py:83 `model[context]` raises KeyError when -- and
+#     only when -- a kept labeling's context is absent at some time step (round 4: VERDICT r3, "lazy KeyError LM semantics")
+# ----------------------------------------------------------------------------------------------
+def gen_beam_lm_sparse():
+    rng = np.random.default_rng(20261004)
+    arrays = {}
+    cases = []
+    cid = 0
+    for k in (1, 2, 3):
+        lm, table = make_lm(rng, k)
+        arrays[f"lm_k{k}"] = table
+        n_ctx = 4 ** k
+        for T, kind, reps in ((k + 1, "flat", 12), (k + 2, "peaky", 12), (6, "flat", 10), (12, "flat", 10), (12, "peaky", 10), (40, "flat", 6),
+                              (40, "hard", 4), (120, "peaky", 4)):
+            for _ in range(reps):
+                mat = make_matrix(rng, T, kind, np.float64)
+                name = f"m{cid}"
+                cid += 1
+                arrays[name] = mat
+                W = int(rng.choice([1, 2, 3, 6, 10]))
+                s_thr, r_thr = [(0.5, 0.5), (0.0, math.inf), (math.inf, 0.0)][int(rng.integers(0, 3))]
+                how = int(rng.integers(0, 3))
+                n_gone = 1 if how == 0 else max(1, n_ctx // 8) if how == 1 else max(1, n_ctx // 2)
+                gone = sorted(int(x) for x in rng.choice(n_ctx, size=min(n_gone, n_ctx), replace=False))
+                sparse = {c: d for i, (c, d) in enumerate(lm.items()) if i not in set(gone)}   # (make_lm inserts contexts in index order)
+                try:
+                    seq, _ = run_beam(mat, W, sparse, s_thr, r_thr, k)
+                    outcome = {"seq": seq}
+                except KeyError as e:
+                    outcome = {"key_error": [int(x) for x in e.args[0]]}
+                cases.append({"mat": name, "lm": f"lm_k{k}", "k": k, "T": T, "kind": kind, "W": W, "s_thr": fenc(s_thr), "r_thr": fenc(r_thr),
+                              "missing": gone, **outcome})
+    np.savez_compressed(os.path.join(HERE, "beam_lm_sparse_mats.npz"), **arrays)
+    with open(os.path.join(HERE, "beam_lm_sparse_cases.json"), "w") as f:
+        json.dump({"source": "radian/decode.py:79-96,100-212 with an RNA-model dict that lacks the contexts listed in `missing` "
+                             "(table row indices): the labeling, or the KeyError decode.py:83 raises", "cases": cases}, f, indent=0)
+    print("beam_lm_sparse:", len(cases), "cases,", sum("key_error" in c for c in cases), "raise KeyError")
+
+
+# ----------------------------------------------------------------------------------------------
 # 3. assemble_matrices
 # ----------------------------------------------------------------------------------------------
 def gen_assemble():
@@ -514,6 +554,7 @@ if __name__ == "__main__":
         sys.exit(0)
     gen_beam_nolm()
     gen_beam_lm()
+    gen_beam_lm_sparse()
     gen_assemble()
     gen_preprocess()
     gen_seq_assembly()

@@ -403,3 +403,28 @@ def test_stream_merger_any_interleaving(tmp_path):
             ls = open(out / f"reads-{i}.fasta").read().split("\n")[:-1]
             got += [(ls[j][1:], ls[j + 1]) for j in range(0, len(ls), 2)]
         assert n == len(exp) and got == exp, (trial, world, with_claims)
+
+
+def test_stream_merger_bound_moves_past_finished_claims_and_abort_leaves_nothing(tmp_path):
+    """ A claim whose last read has reported no longer holds the rank's lower bound once a newer claim is known,
+    so other ranks' records are written instead of piling up in the parent; the FASTA appears in fasta_dir only at finish(),
+    and a failed job (abort) leaves no reads-*.fasta behind."""
+    from radian_amd import launch
+    scratch, out = tmp_path / "s", tmp_path / "o"
+    scratch.mkdir()
+    out.mkdir()
+    r0 = [{"claim": [0, 0, 4]}, {"claim": [0, 8, 12]}] + [[[0, i], f"id{i}", "ACGT"] for i in range(4)]
+    r1 = [{"claim": [0, 4, 8]}] + [[[0, i], f"id{i}", "ACGT"] for i in range(4, 8)]
+    for r, lines in enumerate((r0, r1)):
+        with open(scratch / f"rank{r}.jsonl", "w") as f:
+            f.write("".join(json.dumps(x) + "\n" for x in lines))
+    m = launch.StreamMerger(str(scratch), 2, str(out))
+    m.poll()
+    assert m.n == 8 and not any(m.recs)             # rank 0's bound is its second claim's first read, (0, 8)
+    assert not [n for n in os.listdir(out) if n.startswith("reads-")]
+    m.abort()
+    assert os.listdir(out) == []
+    m = launch.StreamMerger(str(scratch), 2, str(out))
+    assert m.finish() == 8
+    assert os.listdir(out) == ["reads-0.fasta"]
+    assert open(out / "reads-0.fasta").read().count(">") == 8

@@ -155,3 +155,174 @@ def test_cli_cfg5_flags_f16_logits_and_hashed_long_context(tmp_path, golden_dir,
                        "--sig-config", "none", "--rna-model", "None", "--decode-math", math])
         outs.append(_read_fasta(str(o)))
     assert len(outs[0]) == 5 and outs[0] == outs[1]
+
+
+def _write_default_artifacts(cwd, seed, k, dilations=(1, 2, 4, 8, 16, 32), nb_stacks=1, tcn_overrides=None, lm_name="rnamodel_12mer_pc.json"):
+    """The three artefact files at the reference's DEFAULT relative paths (basecall.py:28-30) under `cwd`: models/sig2seq.h5
+    (Keras-2.4 weights-only layout, NUL-padded name attributes), models/sig2seq.yaml (the keys of sig2seq.yaml:34-49) and the
+    RNA model JSON."""
+    import yaml
+    from radian_amd import h5weights, weights
+    models = cwd / "models"
+    models.mkdir(exist_ok=True)
+    all_dil = tuple(dilations) * nb_stacks
+    flat = weights.synthetic_weights(seed=seed, dilations=all_dil)
+    h5weights.write_keras_weights(str(models / "sig2seq.h5"), flat, dilations=all_dil, attr_kind="nullpad")
+    tcn = {"nb_filters": 256, "kernel_size": 3, "nb_stacks": nb_stacks, "dilations": list(dilations), "padding": "causal",
+           "use_skip_connections": False, "dropout_rate": 0.0, "return_sequences": True, "activation": "relu",
+           "kernel_initializer": "he_normal", "use_batch_norm": False}
+    tcn.update(tcn_overrides or {})
+    cfg = {"data": {"n_classes": 5, "window_size": 1024},
+           "model": {"relu_units": 128, "softmax_units": 5, "timesteps": 1024, "tcn": tcn}}
+    (models / "sig2seq.yaml").write_text(yaml.safe_dump(cfg))
+    rng = np.random.default_rng(21)
+    raw = {}
+    for i in range(4 ** k):
+        ctx = "".join("ACGT"[(i >> (2 * (k - 1 - j))) & 3] for j in range(k))
+        raw[ctx] = [float(x) for x in rng.dirichlet([0.3] * 4)]
+    (models / lm_name).write_text(json.dumps(raw))
+    return flat, all_dil
+
+
+def test_cli_default_artifact_route(tmp_path, golden_dir, oracle, monkeypatch):
+    """The route a RADIAN user takes (basecall.py:28-30,48-62; model.py:42-45; utilities.py:16-18): NO --sig-model, NO --sig-config,
+    NO --rna-model -- models/sig2seq.h5 goes through the Keras-h5 converter, models/sig2seq.yaml through load_dilations, the RNA
+    model JSON at its default path through lm.load_json, all relative to the working directory, and the result feeds the device.
+    FASTA == the `synthetic:1234` run with explicit flags == the oracle's decode of the GPU's probabilities."""
+    from radian_amd import Backend, basecall, weights, lm
+    ids, sig, in_dir, lm_path = _make_inputs(tmp_path, golden_dir)
+    cwd = tmp_path / "cwd"
+    cwd.mkdir()
+    flat, dil = _write_default_artifacts(cwd, 1234, 3)
+    assert np.array_equal(flat, weights.synthetic_weights(seed=1234))
+    monkeypatch.chdir(cwd)
+    out_a, out_b, out_c = tmp_path / "a", tmp_path / "b", tmp_path / "c"
+    for o in (out_a, out_b, out_c):
+        o.mkdir()
+    basecall.main([in_dir, str(out_a), "--context-len", "3"])                 # every artefact flag at its default
+    basecall.main([in_dir, str(out_b), "--context-len", "3", "--sig-model", "synthetic:1234", "--sig-config", "none",
+                   "--rna-model", lm_path])
+    got = _read_fasta(str(out_a))
+    assert len(got) == 5 and got == _read_fasta(str(out_b))
+    table, k = lm.load_json(str(cwd / "models" / "rnamodel_12mer_pc.json"))
+    be = Backend(0)
+    be.load_weights(weights.synthetic_weights(seed=1234))
+    exp = _expected(be, oracle, ids, sig, 1024, 128, 6, "global", table, k)
+    be.close()
+    assert got == exp
+    # chunk mode never reads the RNA model (basecall.py:110-121): same default files, LM ignored
+    basecall.main([in_dir, str(out_c), "--decode-type", "chunk", "--step-size", "512", "--beam-width", "10"])
+    be = Backend(0)
+    be.load_weights(weights.synthetic_weights(seed=1234))
+    exp = _expected(be, oracle, ids, sig, 1024, 512, 10, "chunk")
+    be.close()
+    assert _read_fasta(str(out_c)) == exp
+
+
+def test_cli_default_artifact_route_two_stacks_and_rejections(tmp_path, golden_dir, oracle, monkeypatch):
+    """sig2seq.yaml drives the graph: nb_stacks 2 x dilations [1, 2, 4] (six blocks with dilations 1,2,4,1,2,4) loads a
+    matching .h5 and basecalls like the oracle; a config the backend does not implement (batch norm, another filter count) and an
+    .h5 whose tensor list does not fit the config raise ValueError before any read is touched."""
+    from radian_amd import Backend, basecall, weights, h5weights
+    ids, sig, in_dir, _ = _make_inputs(tmp_path, golden_dir)
+    cwd = tmp_path / "cwd"
+    cwd.mkdir()
+    flat, dil = _write_default_artifacts(cwd, 77, 3, dilations=(1, 2, 4), nb_stacks=2)
+    assert dil == (1, 2, 4, 1, 2, 4)
+    monkeypatch.chdir(cwd)
+    out = tmp_path / "o"
+    out.mkdir()
+    basecall.main([in_dir, str(out), "--rna-model", "None", "--step-size", "512", "--beam-width", "3"])
+    be = Backend(0)
+    be.load_weights(flat, dil)
+    exp = []
+    for r in ids:
+        win, pad = oracle.get_windows(oracle.mad_normalise(sig[r], 4), 1024, 512)
+        win = np.asarray(win, dtype=np.float32)
+        probs = be.forward(win)
+        assert float(np.abs(probs - oracle.tcn_forward(flat, win, dilations=dil)).max()) <= 1e-4
+        exp.append((r, oracle.beam_search(oracle.assemble_matrices(probs, pad, 512), "ACGT", 3)[::-1]))
+    be.close()
+    assert _read_fasta(str(out)) == exp
+    # 12-vs-13 tensors: the default six-block config against an .h5 that lacks the matching conv's bias
+    _write_default_artifacts(cwd, 77, 3)
+    from radian_amd import h5
+    shapes = weights.tensor_shapes()
+    bad = str(cwd / "models" / "sig2seq.h5")
+    os.remove(bad)
+    with h5.File(bad, "w") as f:
+        names = []
+        f.create_group("/tcn")
+        for name, shape in shapes[:12]:
+            f.write(f"/tcn/{name}:0", np.zeros(shape, dtype=np.float32))
+            names.append(f"{name}:0")
+        f.set_attr_str("/tcn", "weight_names", names, kind="nullpad")
+        f.set_attr_str("/", "layer_names", ["tcn"], kind="nullpad")
+    with pytest.raises(ValueError, match="weight tensors"):
+        basecall.main([in_dir, str(out), "--rna-model", "None"])
+    for override, msg in (({"use_batch_norm": True}, "does not implement"), ({"nb_filters": 128}, "geometry"),
+                          ({"use_skip_connections": True}, "does not implement"), ({"dropout_rate": 0.1}, "does not implement")):
+        _write_default_artifacts(cwd, 77, 3, tcn_overrides=override)
+        with pytest.raises(ValueError, match=msg):
+            basecall.main([in_dir, str(out), "--rna-model", "None"])
+    # the default six-block config against an .h5 written for a three-block graph
+    _write_default_artifacts(cwd, 77, 3)
+    h5weights.write_keras_weights(bad, weights.synthetic_weights(seed=1, dilations=(1, 2, 4)), dilations=(1, 2, 4))
+    with pytest.raises(ValueError):
+        basecall.main([in_dir, str(out), "--rna-model", "None"])
+
+
+def test_cli_sparse_rna_model_fails_like_the_reference(tmp_path, golden_dir, oracle):
+    """A JSON that lacks a context loads (basecall.py:48-57 builds a dict of whatever it holds); the run dies with KeyError at the
+    first read whose beam search looks that context up (decode.py:83) and the reads before it are in the FASTA -- through the
+    in-context pipeline and through the blocking calls; reads that never reach the context decode as with the dense model."""
+    from radian_amd import Backend, basecall, weights, lm
+    ids, sig, in_dir, lm_path = _make_inputs(tmp_path, golden_dir, k=3)
+    dense = json.load(open(lm_path))
+    table, k = lm.load_json(lm_path)
+    flat = weights.synthetic_weights(seed=1234).copy()
+    flat[-645:-5] *= np.float32(0.05)          # soft head: labelings of hundreds of bases, so contexts are reached
+    wpath = str(tmp_path / "soft.rdnw")
+    open(wpath, "wb").write(weights.pack_blob(flat))
+    be = Backend(0)
+    be.load_weights(flat)
+    raws = [sig[r] for r in ids]
+    be.load_lm(table, k)
+    full, _ = be.basecall_raw_global(raws, 4, 1024, 512, 6, True, 0.0, 9.0)
+    found = None
+    omats = []
+    for r in ids:
+        win, pad = oracle.get_windows(oracle.mad_normalise(sig[r], 4), 1024, 512)
+        omats.append(oracle.assemble_matrices(be.forward(np.asarray(win, dtype=np.float32)), pad, 512))
+    for c in range(4 ** k):
+        t = table.copy()
+        t[c] = np.nan
+        be.load_lm(t, k)
+        labs, status = be.basecall_raw_global(raws, 4, 1024, 512, 6, True, 0.0, 9.0)
+        bad = [i for i, l in enumerate(labs) if l is None]
+        # the oracle agrees read by read on the GPU's own probabilities
+        for i, mat in enumerate(omats):
+            exp = oracle.beam_search_batch(mat, [0], [mat.shape[0]], 6, t, 0.0, 9.0, k)[0]
+            assert (exp is None) == (labs[i] is None) and (exp is None or np.array_equal(exp, labs[i])), (c, i)
+        if bad and bad[0] >= 1 and len(bad) < len(ids):
+            assert all(labs[i] is None or np.array_equal(labs[i], full[i]) for i in range(len(ids)))
+            found = (c, bad)
+            break
+        if c >= 12 and found is None and bad and bad[0] >= 1:
+            found = (c, bad)
+            break
+    be.close()
+    assert found is not None, "no absent context splits the five reads"
+    c, bad = found
+    ctx = "".join("ACGT"[(c >> (2 * (k - 1 - j))) & 3] for j in range(k))
+    del dense[ctx]
+    sparse_path = tmp_path / "sparse.json"
+    sparse_path.write_text(json.dumps(dense))
+    for extra in ([], ["--no-pipeline"]):
+        out = tmp_path / ("o" + str(len(extra)))
+        out.mkdir()
+        with pytest.raises(KeyError, match="decode.py:83"):
+            basecall.main([in_dir, str(out), "--sig-model", wpath, "--sig-config", "none", "--rna-model", str(sparse_path), "--context-len", "3",
+                           "--step-size", "512", "--sig-threshold", "0.0", "--rna-threshold", "9.0"] + extra)
+        got = _read_fasta(str(out))
+        assert got == [(ids[i], "".join("ACGT"[x] for x in full[i])[::-1]) for i in range(bad[0])]

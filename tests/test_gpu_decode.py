@@ -304,3 +304,59 @@ def test_two_sequences_per_wave_form(be, golden_dir, oracle):
         be.load_lm(None, 0)
         be.set_decode_form("auto")
         be.set_decode_math("glibc")
+
+
+def test_sparse_lm_reports_exactly_the_reads_the_reference_fails_on(be, golden_dir, oracle):
+    """Round 4: an RNA model that lacks contexts.  204 cases generated from the imported reference: the labeling, or
+    the KeyError of decode.py:83 -- here RD_LEN_MISSING_CONTEXT for that sequence (None from the binding).  Every case alone and in
+    a batch beside sequences that do not reach the context; every launch form its width has; both arithmetics; float32 rows too
+    (vs the oracle, itself pinned by the same goldens)."""
+    g = json.load(open(os.path.join(golden_dir, "beam_lm_sparse_cases.json")))["cases"]
+    mats = np.load(os.path.join(golden_dir, "beam_lm_sparse_mats.npz"))
+    bad = []
+    try:
+        for math in ("glibc", "fast"):
+            be.set_decode_math(math)
+            for c in g:
+                table = mats[c["lm"]].copy()
+                table[c["missing"]] = np.nan
+                be.load_lm(table, c["k"])
+                mat = mats[c["mat"]]
+                for form in (("auto", "one") if c["W"] <= 6 else ("auto",)):
+                    be.set_decode_form(form)
+                    # the case twice in one launch (both halves of a two-sequence wave) + a one-row sequence that cannot reach any context
+                    rows = np.concatenate([mat, mat, mat[:1]])
+                    got = be.decode_batch(rows, [0, len(mat), 2 * len(mat)], [len(mat), len(mat), 1], c["W"], use_lm=True,
+                                          s_threshold=fdec(c["s_thr"]), r_threshold=fdec(c["r_thr"]))
+                    exp = None if "key_error" in c else c["seq"]
+                    for lab in got[:2]:
+                        if (None if lab is None else s_of(lab)) != exp:
+                            bad.append((math, form, c["mat"], c["k"], c["W"]))
+                    assert got[2] is not None and len(got[2]) <= 1
+        assert not bad, bad[:10]
+        # a batch of ragged random sequences against the oracle: float32 and float64 rows, W incl. the wide forms
+        rng = np.random.default_rng(77)
+        k = 3
+        table = rng.dirichlet([0.3] * 4, size=4 ** k)
+        table[rng.choice(4 ** k, size=6, replace=False)] = np.nan
+        be.load_lm(table, k)
+        be.set_decode_form("auto")
+        for dtype in (np.float64, np.float32):
+            lens = [int(x) for x in rng.integers(1, 90, size=64)]
+            rows = np.concatenate([softmax_rows(rng.normal(size=(n, 5)) * rng.choice([0.7, 2.0])) for n in lens]).astype(dtype)
+            off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+            for W in (1, 4, 6, 10, 13, 25, 30):
+                for math in ("glibc", "fast"):
+                    be.set_decode_math(math)
+                    got = be.decode_batch(rows, off, lens, W, use_lm=True, s_threshold=0.2, r_threshold=1.5)
+                    exp = oracle.beam_search_batch(rows, off, lens, W, table, 0.2, 1.5, k)
+                    n_none = 0
+                    for i in range(len(lens)):
+                        assert (got[i] is None) == (exp[i] is None), (dtype.__name__, W, math, i)
+                        n_none += got[i] is None
+                        assert got[i] is None or np.array_equal(got[i], exp[i]), (dtype.__name__, W, math, i)
+                    assert 0 < n_none < len(lens)
+    finally:
+        be.load_lm(None, 0)
+        be.set_decode_math("glibc")
+        be.set_decode_form("auto")

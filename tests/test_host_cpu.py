@@ -132,10 +132,45 @@ def test_lm_json_loader(tmp_path):
     # index = base-4 number of the context, first char most significant (tuple keys of basecall.py:56)
     assert np.array_equal(table[lm.context_index("GTA")], raw["GTA"])
     assert lm.context_index("GTA") == 2 * 16 + 3 * 4 + 0 == lm.context_index((2, 3, 0))
-    del raw["AAA"]
+    assert lm.n_missing(table) == 0
+    # tuple keys (the reference's re-keyed dict, basecall.py:51-57) give the same table
+    t2, k2 = lm.table_from_dict({tuple("ACGT".index(b) for b in c): d for c, d in raw.items()})
+    assert k2 == k and np.array_equal(t2, table)
+    # a sparse model loads (the reference's dict simply lacks the key; decode.py:83 fails only when it is looked up):
+    # absent contexts are rows of NaN
+    del raw["AAA"], raw["GTC"]
     p.write_text(json.dumps(raw))
-    with pytest.raises(ValueError):
-        lm.load_json(str(p))
+    sparse, _ = lm.load_json(str(p))
+    assert lm.n_missing(sparse) == 2 and np.isnan(sparse[0]).all() and np.isnan(sparse[lm.context_index("GTC")]).all()
+    keep = ~np.isnan(sparse[:, 0])
+    assert np.array_equal(sparse[keep], table[keep])
+    for bad in ({"AAX": [0.25] * 4, "AAA": [0.25] * 4}, {"AA": [0.25] * 4, "AAA": [0.25] * 4}, {"AAA": [0.5, 0.5]}, {}):
+        with pytest.raises(ValueError):
+            lm.table_from_dict(bad)
+
+
+def test_lm_loader_vectorised_at_scale():
+    """4^9 = 262 144 contexts in shuffled order, 1000 of them absent: the key -> row conversion is one vectorised pass.  (The real
+    model has 4^11 = 4 194 304 twelve-mer contexts, models/rnamodel_12mer_pc.json, basecall.py:28: tools/lm_load_bench.py writes
+    a JSON of that size, times the whole route and reports the peak RSS -- DESIGN.md section 4.13.)"""
+    import time
+    from radian_amd import lm
+    k = 9
+    n = 4 ** k
+    rng = np.random.default_rng(1)
+    vals = rng.random((n, 4))
+    letters = np.array(list("ACGT"))
+    digits = (np.arange(n)[:, None] >> (2 * np.arange(k - 1, -1, -1))) & 3
+    keys = ["".join(r) for r in letters[digits]]
+    perm = rng.permutation(n)
+    model = {keys[i]: vals[i].tolist() for i in perm[: n - 1000]}       # (shuffled order, 1000 contexts absent)
+    t0 = time.time()
+    table, kk = lm.table_from_dict(model)
+    dt = time.time() - t0
+    assert kk == k and table.shape == (n, 4) and lm.n_missing(table) == 1000
+    held = np.sort(perm[: n - 1000])
+    assert np.array_equal(table[held], vals[held])
+    assert dt < 10, f"table_from_dict took {dt:.1f} s for 4^9 contexts"
 
 
 def _have_hdf5():
@@ -375,3 +410,107 @@ def test_native_stitch_equals_difflib_randomised():
             lab, lens, nw = _label_matrix([reads[i]], 1024)
             with pytest.raises(IndexError):
                 S.consensus_batch(lab, lens, nw, threads=1)
+
+
+@pytest.mark.skipif(not _have_hdf5(), reason="libhdf5 not available")
+def test_default_artifact_route_host_half(tmp_path, monkeypatch):
+    """basecall.py:28-30,48-62 without a GPU: the parser's DEFAULT paths (models/sig2seq.h5, models/sig2seq.yaml,
+    models/rnamodel_12mer_pc.json, relative to the working directory) through load_dilations (utilities.py:16-18 +
+    sig2seq.yaml:34-49), the Keras-h5 converter (model.py:42-45) and the LM loader -- including nb_stacks > 1 and the
+    configurations the backend refuses."""
+    import json
+    import yaml
+    from radian_amd import basecall, h5weights, weights
+    models = tmp_path / "models"
+    models.mkdir()
+    monkeypatch.chdir(tmp_path)
+
+    def write_cfg(**over):
+        tcn = {"nb_filters": 256, "kernel_size": 3, "nb_stacks": 1, "dilations": [1, 2, 4, 8, 16, 32], "padding": "causal",
+               "use_skip_connections": False, "dropout_rate": 0.0, "return_sequences": True, "activation": "relu",
+               "kernel_initializer": "he_normal", "use_batch_norm": False}
+        model = {"relu_units": 128, "softmax_units": 5, "timesteps": 1024}
+        for k, v in over.items():
+            (model if k in model else tcn)[k] = v
+        model["tcn"] = tcn
+        (models / "sig2seq.yaml").write_text(yaml.safe_dump({"train": {"batch_size": 32}, "model": model}))
+
+    args = basecall.build_parser().parse_args(["in", "out", "--context-len", "2"])
+    assert (args.sig_model, args.sig_config, args.rna_model) == ("models/sig2seq.h5", "models/sig2seq.yaml", "models/rnamodel_12mer_pc.json")
+    write_cfg()
+    assert basecall.load_dilations(args.sig_config) == (1, 2, 4, 8, 16, 32)
+    write_cfg(nb_stacks=2, dilations=[1, 2, 4])
+    assert basecall.load_dilations(args.sig_config) == (1, 2, 4, 1, 2, 4)
+    write_cfg(nb_stacks=3, dilations=[1, 8])
+    assert basecall.load_dilations(args.sig_config) == (1, 8, 1, 8, 1, 8)
+    for over, msg in (({"use_batch_norm": True}, "does not implement"), ({"use_skip_connections": True}, "does not implement"),
+                      ({"dropout_rate": 0.05}, "does not implement"), ({"padding": "same"}, "does not implement"),
+                      ({"activation": "tanh"}, "does not implement"), ({"nb_filters": 64}, "geometry"), ({"kernel_size": 5}, "geometry"),
+                      ({"relu_units": 64}, "geometry"), ({"softmax_units": 4}, "geometry")):
+        write_cfg(**over)
+        with pytest.raises(ValueError, match=msg):
+            basecall.load_dilations(args.sig_config)
+    assert basecall.load_dilations("none") == weights.DEFAULT_DILATIONS     # no file: the constants of sig2seq.yaml
+
+    # the whole host half at the default paths: yaml (two stacks) + matching .h5 + LM JSON
+    write_cfg(nb_stacks=2, dilations=[1, 2, 4])
+    dil = (1, 2, 4, 1, 2, 4)
+    w = weights.synthetic_weights(seed=9, dilations=dil)
+    h5weights.write_keras_weights(str(models / "sig2seq.h5"), w, dilations=dil)
+    rng = np.random.default_rng(0)
+    lm = {a + b: [float(x) for x in rng.dirichlet([1.0] * 4)] for a in "ACGT" for b in "ACGT"}
+    (models / "rnamodel_12mer_pc.json").write_text(json.dumps(lm))
+    art = basecall.load_artifacts(args)
+    assert art["dilations"] == dil and np.array_equal(art["weights"], w) and art["lm_k"] == 2
+    assert np.array_equal(art["lm_table"][4 * 1 + 2], lm["CG"])
+    # (a weights file does not record dilations: the same six-block file loads under the default config too)
+    write_cfg()
+    assert np.array_equal(basecall.load_artifacts(args)["weights"], w)
+    # the config says four blocks, the file holds six: refused by the tensor count before any GPU is touched
+    write_cfg(dilations=[1, 2, 4, 8])
+    with pytest.raises(ValueError, match="weight tensors"):
+        basecall.load_artifacts(args)
+    # the reference's default --context-len (11) against this 2-label model: decode.py:83's KeyError, raised at load
+    write_cfg(nb_stacks=2, dilations=[1, 2, 4])
+    with pytest.raises(KeyError):
+        basecall.load_artifacts(basecall.build_parser().parse_args(["in", "out"]))
+
+
+def test_driver_raises_reference_keyerror_at_the_read_that_reaches_a_missing_context(oracle, capsys):
+    """A sparse RNA model (basecall.py:48-57 builds a dict of whatever the JSON holds) works in the reference until a read's beam
+    search looks an absent context up (decode.py:83: KeyError, uncaught in basecall.py:70-141, so the run dies there with the
+    earlier reads written).  Same here, whatever the device batch size: reads before the failing one come out, then KeyError."""
+    from radian_amd import basecall, weights
+    from _oracle_backend import OracleBackend
+    from _reads import golden_reads
+    be = OracleBackend()
+    be.load_weights(weights.synthetic_weights(seed=5, dilations=(1, 2)), (1, 2))
+    dense = np.random.default_rng(9).dirichlet([0.3] * 4, size=16)
+    base = ["a", "b", "--chunk-len", "128", "--step-size", "64", "--beam-width", "3", "--decode-type", "global", "--context-len", "2",
+            "--sig-threshold", "0.0", "--rna-threshold", "9.0"]
+    args = basecall.build_parser().parse_args(base + ["--gpu-batch-windows", "40"])
+    args._lm_loaded = True
+    be.load_lm(dense, 2)
+    full = basecall.run(args, be, reads=golden_reads(700), writer=None)
+    assert len(full) >= 4
+    found = None
+    for c in range(16):
+        t = dense.copy()
+        t[c] = np.nan
+        be.load_lm(t, 2)
+        labs, _ = be.basecall_raw_global([r.get_raw_data() for r in golden_reads(700)], 4, 128, 64, 3, True, 0.0, 9.0)
+        bad = [i for i, l in enumerate(labs) if l is None]
+        if bad and 1 <= bad[0] and len(bad) < len(labs):
+            found = (c, bad)
+            break
+    assert found is not None, "no single absent context splits the five reads"
+    c, bad = found
+    for gbw in ("1", "40"):
+        a2 = basecall.build_parser().parse_args(base + ["--gpu-batch-windows", gbw])
+        a2._lm_loaded = True
+        seen = []
+        with pytest.raises(KeyError, match="decode.py:83"):
+            basecall.run(a2, be, reads=golden_reads(700), writer=None, on_result=lambda idx, rid, seq: seen.append((idx, rid, seq)))
+        # (reads that do not reach the context decode exactly as with the dense model: the absent row is never read for them)
+        assert seen == full[: bad[0]]
+    capsys.readouterr()

@@ -179,3 +179,40 @@ def test_logaddexp_matches_numpy_scalar(oracle):
     assert oracle.logaddexp(ninf, ninf) == ninf
     assert oracle.logaddexp(ninf, -3.5) == -3.5
     assert oracle.logaddexp(-3.5, ninf) == -3.5
+
+
+def test_sparse_lm_matches_reference_key_errors(golden_dir, oracle):
+    """Round 4: an RNA-model dict that lacks contexts.  The reference raises KeyError at decode.py:83 when -- and only when -- a
+    kept labeling's context is absent; 204 cases generated from the imported reference (141 raise, 63 decode)."""
+    cases = json.load(open(os.path.join(golden_dir, "beam_lm_sparse_cases.json")))["cases"]
+    mats = np.load(os.path.join(golden_dir, "beam_lm_sparse_mats.npz"))
+    n_err = 0
+    for c in cases:
+        table = mats[c["lm"]].copy()
+        table[c["missing"]] = np.nan
+        args = (mats[c["mat"]], "ACGT", c["W"], table, float.fromhex(c["s_thr"]), float.fromhex(c["r_thr"]), c["k"])
+        if "key_error" in c:
+            n_err += 1
+            with pytest.raises(KeyError):
+                oracle.beam_search(*args)
+        else:
+            assert oracle.beam_search(*args) == c["seq"], c
+    assert n_err == 141 and len(cases) == 204
+    # the batch form reports the same reads as None and decodes the others
+    for k in (1, 2, 3):
+        sel = [c for c in cases if c["k"] == k and c["W"] == 6 and c["s_thr"] == (0.5).hex() and len(c["missing"]) == 1 and c["missing"] == [c["missing"][0]]]
+        by_missing = {}
+        for c in sel:
+            by_missing.setdefault(c["missing"][0], []).append(c)
+        for miss, group in by_missing.items():
+            table = mats[f"lm_k{k}"].copy()
+            table[miss] = np.nan
+            rows = np.concatenate([mats[c["mat"]] for c in group])
+            lens = np.array([c["T"] for c in group], dtype=np.int32)
+            off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+            got = oracle.beam_search_batch(rows, off, lens, 6, table, 0.5, 0.5, k)
+            for g, c in zip(got, group):
+                if "key_error" in c:
+                    assert g is None
+                else:
+                    assert "".join("ACGT"[x] for x in g) == c["seq"]
