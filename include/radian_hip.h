@@ -213,6 +213,13 @@ int rd_memcpy_d2h(rd_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 /* same contract as rd_forward / rd_basecall_chunk with d_windows resident; d_probs may be NULL
  * (internal workspace).  Asynchronous on the context stream except for the label copy-out. */
 int rd_forward_resident(rd_ctx* ctx, const float* d_windows, int n_windows, int chunk_len, float* d_probs);
+/* sig_model.predict alone (radian/basecall.py:88-93; BASELINE configs[1] "forward only") for a batch of whole normalised
+ * reads resident in HBM: the streamed evaluation of rd_basecall_reads_chunk (decode_type 0: one row per time step + the
+ * rows of every window's zero-padded head) or rd_basecall_reads_global (1) without the decode, asynchronous on forward
+ * lane `lane` (0..3; lanes are independent streams with their own activations).  Rows go to the context's probability
+ * workspace; *total_rows (nullable) = their number.  rd_sync waits for every lane. */
+int rd_forward_reads_resident(rd_ctx* ctx, const float* d_signal, const int64_t* read_off, int n_reads, int chunk_len,
+                              int step, int decode_type, int lane, int64_t* total_rows);
 int rd_basecall_chunk_resident(rd_ctx* ctx, const float* d_windows, int n_windows, int chunk_len,
                                const int32_t* valid_len, int beam_width, uint8_t* labels_out, int32_t* label_len);
 int rd_decode_resident(rd_ctx* ctx, const float* d_probs, int n_windows, int chunk_len, const int32_t* valid_len,

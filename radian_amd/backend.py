@@ -377,6 +377,13 @@ class Backend:
     def forward_resident(self, d_windows, n, T, d_probs=None):
         self._check(self._L.rd_forward_resident(self._h, d_windows, n, T, d_probs))
 
+    def forward_reads_resident(self, d_signal, read_off, n_reads, chunk_len, step, decode_type="chunk", lane=0):
+        """forward only over whole reads resident in HBM (rd_forward_reads_resident): asynchronous on `lane`; -> rows evaluated"""
+        rows = ctypes.c_int64(0)
+        self._check(self._L.rd_forward_reads_resident(self._h, d_signal, _p(read_off), int(n_reads), int(chunk_len), int(step),
+                                                      {"chunk": 0, "global": 1}[decode_type], int(lane), ctypes.byref(rows)))
+        return rows.value
+
     def basecall_chunk_resident(self, d_windows, n, T, valid_len, beam_width, labels, lens):
         self._check(self._L.rd_basecall_chunk_resident(self._h, d_windows, n, T, _p(valid_len), int(beam_width), _p(labels), _p(lens)))
 

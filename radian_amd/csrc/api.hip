@@ -1359,6 +1359,25 @@ extern "C" int rd_basecall_reads_chunk_resident(rd_ctx* ctx, const float* d_sign
                             labels_out, lab_off.data(), label_len, nullptr, P->off2.data(), P->split.data());
 }
 
+// forward only, at the reads level: the streamed evaluation (every time step once + the window heads in chunk mode) of a batch of
+// normalised reads resident in HBM, on forward lane `lane`, asynchronous.  The probability rows land in the context's workspace
+// (row layout of the plan: DESIGN.md 4.6); *total_rows (nullable) receives their number.
+extern "C" int rd_forward_reads_resident(rd_ctx* ctx, const float* d_signal, const int64_t* read_off, int n_reads, int chunk_len,
+                                         int step, int decode_type, int lane, int64_t* total_rows)
+{
+    int rc = check_reads_args(ctx, d_signal, read_off, n_reads, chunk_len, step, 1);
+    if (rc) return rc;
+    RD_REQUIRE(decode_type == 0 || decode_type == 1, "rd_forward_reads_resident: decode_type %d (0 = chunk plan, 1 = global plan)", decode_type);
+    RD_REQUIRE(lane >= 0 && lane < RD_MAX_LANES, "rd_forward_reads_resident: lane %d out of range [0,%d)", lane, RD_MAX_LANES);
+    RD_HIP(hipSetDevice(ctx->device));
+    const ReadsPlan* P = nullptr;
+    const TileLists* tl = nullptr;
+    if ((rc = get_plan(ctx, read_off, n_reads, chunk_len, step, decode_type, &P, &tl, nullptr))) return rc;
+    if (ctx->ws_probs.reserve((size_t)P->total_rows * 20)) return RD_ERR_NOMEM;
+    if (total_rows) *total_rows = P->total_rows;
+    return rd_forward_tiles_dev(ctx, d_signal, *tl, P->total_rows, ctx->ws_probs.p, lane, ctx->logits_f16);
+}
+
 extern "C" int rd_basecall_reads_chunk(rd_ctx* ctx, const float* signal, const int64_t* read_off, int n_reads, int chunk_len,
                                        int step, int beam_width, uint8_t* labels_out, int32_t* label_len)
 {

@@ -33,6 +33,7 @@
 #include <mutex>
 
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -1712,15 +1713,35 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl
     const int zero_row = (int)total_rows;
     // (the three tensors' zero rows are cleared by the forward's first kernel: clear_zero_rows)
     const int nl = 2 * m.nblocks + 1;
+    // EXPERIMENT (wrong results, timing only; tools/alt_streams.sh): neighbouring layers on two streams with NO ordering between
+    // them -- an upper bound on what overlapping a layer's last round with the next layer's first could win
+#ifdef RD_EXPERIMENTS   // (python -m radian_amd.build -DRD_EXPERIMENTS -o...: not in the product library)
+    static const bool x_alt = getenv("RD_X_ALT_STREAMS") != nullptr;
+#else
+    constexpr bool x_alt = false;
+#endif
+    if (x_alt) {
+        if (!L->st2) {
+            RD_HIP(hipStreamCreateWithFlags(&L->st2, hipStreamNonBlocking));
+            RD_HIP(hipEventCreateWithFlags(&L->ev_a, hipEventDisableTiming));
+            RD_HIP(hipEventCreateWithFlags(&L->ev_b, hipEventDisableTiming));
+        }
+        RD_HIP(hipEventRecord(L->ev_a, L->st));
+        RD_HIP(hipStreamWaitEvent(L->st2, L->ev_a, 0));
+    }
     for (int li = 0; li < nl; li++) {
         const int b = li == nl - 1 ? m.nblocks : li / 2;
         const int kind = li == nl - 1 ? 3 : (li == 0 ? 0 : (li & 1 ? 2 : 1));
-        if ((rc = launch_layer(ctx, L->st, b, kind, tl.d[li], tl.n[li], (double)tl.rows[li], zero_row, d_signal, Xin, Xout, MID, (float*)d_probs, probs_f16))) return rc;
+        if ((rc = launch_layer(ctx, x_alt && (li & 1) ? L->st2 : L->st, b, kind, tl.d[li], tl.n[li], (double)tl.rows[li], zero_row, d_signal, Xin, Xout, MID, (float*)d_probs, probs_f16))) return rc;
         if (kind == 2) {   // block finished: its output becomes the next block's input
             float* t = Xin;
             Xin = Xout;
             Xout = t;
         }
+    }
+    if (x_alt) {
+        RD_HIP(hipEventRecord(L->ev_b, L->st2));
+        RD_HIP(hipStreamWaitEvent(L->st, L->ev_b, 0));
     }
     RD_HIP(hipEventRecord(L->done, L->st));
     return RD_OK;
