@@ -273,6 +273,14 @@ int rd_pipe_submit_raw_chunk(rd_ctx* ctx, const int16_t* raw, const int64_t* rea
  * wait_for <= 0; otherwise returns once at least wait_for of the batches submitted so far (counted since the context was
  * created) have been delivered, closing the open group if what is awaited sits in it.  *delivered = that count. */
 int rd_pipe_progress(rd_ctx* ctx, int64_t wait_for, int64_t* delivered);
+/* The global-mode groups close by COVERAGE: when the forward rows gathered so far take the next group's forwards as long as the
+ * beam search of this group's longest read will take (a read's search is one serial chain; radian/basecall.py:99-109 runs it
+ * inline, here it runs under the next reads' forwards).  Both sides of that rule are measured by the context itself with HIP
+ * events -- ns per forward row (per matrix-product mode) and us per time step of a group's longest chain (per beam width,
+ * arithmetic, LM, with / without the decode partition) -- starting from built-in figures for the exact-fp32 mode.  Read-out for
+ * tools and tests: 0 = not measured yet; *rows_per_step = the rule in force (forward rows per time step of the longest read). */
+int rd_pipe_policy_read(rd_ctx* ctx, int beam_width, int on_partition, int use_lm, double* ns_per_row, double* us_per_step,
+                        int64_t* rows_per_step);
 /* Batches submitted to the reads-level pipeline so far: right after a submit, the number rd_pipe_progress must reach for
  * that batch to have been delivered. */
 int rd_pipe_submitted(rd_ctx* ctx, int64_t* submitted);

@@ -1239,7 +1239,7 @@ int launch_pt(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm, int n_sim
     // latter (rd_set_decode_form 4 keeps it reachable for tests and A/B runs; 3 = the default's choice, spelled out)
     (void)n_simd;
     if (a.W <= 6 && !(lm && a.hashed) && form != 4 && n_seq >= 2) return launch_two<PT>(st, a, n_seq, lm);
-    if (a.W <= Cfg<1, 1>::WM) return launch_r<PT, 1, 1>(st, a, n_seq, lm);
+    if (a.W <= Cfg<1, 1>::WM) return form == 2 ? launch_r<PT, 2, 1>(st, a, n_seq, lm) : launch_r<PT, 1, 1>(st, a, n_seq, lm);   // (form 2 here: measurements only)
     // wide form while every wave still gets a SIMD of its own
     const bool mid = a.W <= Cfg<1, 2>::WM;
     const bool wide = form == 1 || (form == 0 && (long long)n_seq * (mid ? 2 : 4) <= n_simd);

@@ -42,14 +42,131 @@ namespace {
 // chip 25.0 M samples/s; the longest 288 reads of every group on the partition and the rest on the whole chip 18.8 M (the
 // partition becomes the bottleneck) -- hence no split inside a group, and no partition under batches of many reads (forced there
 // with two sequences per wave and longest-first order: 20.0 M at 3 or 4 CUs per XCD, 18.0 M at 6).
-inline int64_t chain_rows(int W, bool on_partition)
+// These constants are what a context starts from (exact fp32, glibc arithmetic: 34 ns per forward row); the figures it measures
+// in its own first groups replace them (Calib below).
+constexpr double kDefaultNsPerRow = 34.0;
+inline int64_t chain_rows_default(int W, bool on_partition)
 {
-    static const long env = getenv("RD_CHAIN_ROWS") ? atol(getenv("RD_CHAIN_ROWS")) : 0;   // (measurements only)
+#ifdef RD_EXPERIMENTS   // (python -m radian_amd.build -DRD_EXPERIMENTS -o...: measurements only, not in the product library)
+    static const long env = getenv("RD_CHAIN_ROWS") ? atol(getenv("RD_CHAIN_ROWS")) : 0;
     if (env > 0) return env;
+#endif
     // (W <= 6: two sequences share a wave's instructions -- beam_search2_kernel -- so beside conv waves a sequence advances
     // twice as fast per issued instruction)
     if (!on_partition) return W <= 6 ? 300 : W <= 12 ? 560 : W <= 25 ? 900 : 1500;
     return W <= 12 ? 96 : W <= 25 ? 140 : 260;
+}
+
+// Self-calibration of the group policy (round 4).  Two figures decide when a global-mode group is worth closing: what a forward row
+// costs (ns, all lanes together) and what a time step of the group's longest chain costs while the NEXT group's forwards run (us).
+// Both depend on things the constants above cannot know -- the matrix-product mode (f16x3 / bf16x3 forwards are 1.3-2.2x faster), the
+// beam width, the arithmetic of the beam search, whether the search has the decode partition to itself, the device -- so the context
+// measures them with HIP events: the end of every submit's lane work (forward rate over a window of consecutive submits) and both
+// ends of every group's beam search (elapsed / longest chain).  Until a figure exists the constant stands in, scaled by the measured
+// forward rate when that is known.
+struct Calib {
+    static constexpr int NF = 16, WIN = 8, ND = 4;
+    hipEvent_t f_ev[NF] = {};
+    int64_t f_rows[NF] = {};
+    int f_prec[NF] = {};
+    int64_t f_next = 0;        // submits recorded so far
+    int64_t f_seen = 0;        // windows ending before this submit index have been looked at
+    double ns_row[3] = {0.0, 0.0, 0.0};   // per matrix-product mode; 0: not measured yet
+    struct Dec {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        int64_t longest = 0;
+        uint32_t key = 0;
+        bool pending = false;
+    } d[ND];
+    int64_t d_next = 0;
+    std::vector<std::pair<uint32_t, double>> us_step;   // (key, us per time step of the longest chain), few entries
+
+    static uint32_t key_of(int W, bool on_part, int math, int prec, int lm) { return (uint32_t)W | (on_part ? 1u << 8 : 0u) | (uint32_t)math << 9 | (uint32_t)prec << 10 | (uint32_t)lm << 12; }
+    double* find(uint32_t key)
+    {
+        for (auto& e : us_step)
+            if (e.first == key) return &e.second;
+        return nullptr;
+    }
+};
+
+// completed measurements -> estimates (never blocks: an event that has not fired yet is looked at again later)
+void calib_harvest(Calib& c)
+{
+    while (c.f_seen < c.f_next) {
+        const int64_t j = c.f_seen;
+        if (j < Calib::WIN) {
+            c.f_seen++;
+            continue;
+        }
+        if (c.f_next - j >= Calib::NF - Calib::WIN) {   // its first event has been re-recorded since: skip
+            c.f_seen++;
+            continue;
+        }
+        hipEvent_t a = c.f_ev[(j - Calib::WIN) % Calib::NF], b = c.f_ev[j % Calib::NF];
+        if (hipEventQuery(b) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        float ms = 0.f;
+        bool same = true;
+        int64_t rows = 0;
+        for (int64_t k = j - Calib::WIN + 1; k <= j; k++) {
+            rows += c.f_rows[k % Calib::NF];
+            same = same && c.f_prec[k % Calib::NF] == c.f_prec[j % Calib::NF];
+        }
+        same = same && c.f_prec[(j - Calib::WIN) % Calib::NF] == c.f_prec[j % Calib::NF];
+        if (same && rows > 0 && hipEventElapsedTime(&ms, a, b) == hipSuccess && ms > 0.f) {
+            const double ns = (double)ms * 1e6 / (double)rows;
+            double& e = c.ns_row[c.f_prec[j % Calib::NF]];
+            // a window that held a pause of the host reads slow: such samples are taken with a small weight only
+            e = e == 0.0 ? ns : (ns < e ? 0.5 * e + 0.5 * ns : 0.9 * e + 0.1 * ns);
+        } else {
+            (void)hipGetLastError();
+        }
+        c.f_seen++;
+    }
+    for (auto& d : c.d) {
+        if (!d.pending || hipEventQuery(d.e1) != hipSuccess) {
+            (void)hipGetLastError();
+            continue;
+        }
+        float ms = 0.f;
+        if (d.longest > 0 && hipEventElapsedTime(&ms, d.e0, d.e1) == hipSuccess && ms > 0.f) {
+            const double us = (double)ms * 1e3 / (double)d.longest;
+            if (double* e = c.find(d.key)) *e = 0.5 * *e + 0.5 * us;
+            else c.us_step.emplace_back(d.key, us);
+        } else {
+            (void)hipGetLastError();
+        }
+        d.pending = false;
+    }
+}
+
+// forward rows a group must hold per time step of its longest read before it closes
+int64_t chain_rows(const rd_ctx* ctx, Calib& c, int W, bool on_partition, int use_lm)
+{
+    const int64_t def = chain_rows_default(W, on_partition);
+#ifdef RD_EXPERIMENTS
+    static const bool no_calib = getenv("RD_NO_CALIB") != nullptr;   // A/B against the constants (tools only)
+    if (no_calib) return def;
+#endif
+    const double ns = c.ns_row[ctx->precision];
+    const double* us = c.find(Calib::key_of(W, on_partition, ctx->decode_math, ctx->precision, use_lm));
+    if (ns <= 0.0) return def;
+    const double scaled = (double)def * kDefaultNsPerRow / ns;   // the constant, for the forward this context really runs
+    double rows = scaled;
+    if (us) {
+        rows = *us * 1e3 / ns * 1.3;          // measured chain pace over measured forward pace, + 30 %
+        // Beside conv waves (no partition) a group's search time depends on the group's own size -- thousands of slow waves
+        // hide each other -- so elapsed / longest chain of a SMALL group under-states what coverage needs: there the measurement
+        // may only raise the rule (measured with the constants: 512 reads x 4096 per step 30.2 M samples/s, 29.1 M when the
+        // measured figure was allowed to shrink the groups; profiles/r04_policy_ab.txt)
+        if (!on_partition && rows < scaled) rows = scaled;
+    }
+    const double lo = (double)def / 3.0, hi = (double)def * 6.0;
+    rows = rows < lo ? lo : rows > hi ? hi : rows;
+    return (int64_t)rows;
 }
 // sequences the partition decodes at chain pace: three waves per SIMD (a sequence is 1 / 2 / 4 waves for W <= 12 / 25 / 51;
 // ~12 KiB of LDS per sequence keeps 13 resident per CU).  Measured at W = 10 on 64 SIMDs: 128 / 256 sequences 28.2 / 27.8 M
@@ -140,6 +257,7 @@ struct ReadsPipe {
     int64_t submitted = 0, delivered = 0, launches = 0;
     hipStream_t last_dec = nullptr;   // stream of the latest beam-search launch
     hipEvent_t ev_switch = nullptr;
+    Calib calib;
 };
 
 void slot_reset(RSlot& s)
@@ -163,6 +281,11 @@ int rpipe_get(rd_ctx* ctx, ReadsPipe** out)
         RD_HIP(hipStreamCreateWithPriority(&p->s_dec, hipStreamNonBlocking, hi));
         for (int i = 0; i < 2; i++) RD_HIP(hipEventCreateWithFlags(&p->slot[i].dec_done, hipEventDisableTiming));
         RD_HIP(hipEventCreateWithFlags(&p->ev_switch, hipEventDisableTiming));
+        for (auto& e : p->calib.f_ev) RD_HIP(hipEventCreate(&e));          // (timing events: the policy's measurements)
+        for (auto& d : p->calib.d) {
+            RD_HIP(hipEventCreate(&d.e0));
+            RD_HIP(hipEventCreate(&d.e1));
+        }
     }
     *out = (ReadsPipe*)ctx->rpipe;
     return RD_OK;
@@ -266,6 +389,19 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
         if (s.lane_mask & (1u << l)) RD_HIP(hipStreamWaitEvent(ds, ctx->lanes[l].done, 0));
     RD_HIP(hipMemcpyAsync(s.meta.p, s.h_meta, o_llen, hipMemcpyHostToDevice, ds));
     char* dm = (char*)s.meta.p;
+    // global mode: the group's beam search is timed for the group policy (Calib)
+    Calib::Dec* cd = nullptr;
+    if (s.mode == 1 && s.longest > 0) {
+        calib_harvest(p->calib);
+        Calib::Dec& d = p->calib.d[p->calib.d_next % Calib::ND];
+        if (!d.pending) {
+            cd = &d;
+            p->calib.d_next++;
+            d.longest = s.longest;
+            d.key = Calib::key_of(s.W, on_part, ctx->decode_math, ctx->precision, s.use_lm);
+            RD_HIP(hipEventRecord(d.e0, ds));
+        }
+    }
     for (int pass = 0; pass < 2; pass++) {
         const int k0 = pass == 0 ? 0 : s.n64, k1 = pass == 0 ? s.n64 : (int)n;
         if (k1 == k0) continue;
@@ -277,6 +413,10 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
                            (int32_t*)(dm + o_llen) + k0, nullptr, ds, chunk ? (const int64_t*)(dm + o_off2) + k0 : nullptr,
                            chunk ? (const int32_t*)(dm + o_split) + k0 : nullptr, on_part ? RD_XCDS * s.part : 0);
         if (rc) return rc;
+    }
+    if (cd) {
+        RD_HIP(hipEventRecord(cd->e1, ds));
+        cd->pending = true;
     }
     RD_HIP(hipMemcpyAsync(s.h_out, s.labels.p, (size_t)s.labels_total, hipMemcpyDeviceToHost, ds));
     RD_HIP(hipMemcpyAsync((char*)s.h_out + ho_len, dm + o_llen, n * 4, hipMemcpyDeviceToHost, ds));
@@ -493,7 +633,8 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
     if (mode == 1) {
         int64_t longest_b = 0;
         for (int r = 0; r < n_reads; r++) longest_b = std::max<int64_t>(longest_b, read_off[r + 1] - read_off[r]);
-        expect_rows = std::min<int64_t>(kGroupRowsCap, chain_rows(W, part != 0) * longest_b + 2 * P.total_rows);
+        calib_harvest(p->calib);
+        expect_rows = std::min<int64_t>(kGroupRowsCap, chain_rows(ctx, p->calib, W, part != 0, use_lm) * longest_b + 2 * P.total_rows);
     }
     if ((rc = open_slot(ctx, p, mode, W, f16, use_lm, s_thr, r_thr, part, P.total_rows, expect_rows, &s))) return rc;
 
@@ -602,6 +743,15 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
     if (raw)
         RD_HIP(hipMemcpyAsync((char*)s->status.p + (size_t)s->n_reads * 4, (char*)R.raw.p + d_st, (size_t)n_reads * 4, hipMemcpyDeviceToDevice, L->st));
     RD_HIP(hipEventRecord(L->done, L->st));   // the decode stream waits for this before it reads the group
+    {   // the policy's forward-rate measurement: the end of this submit's lane work
+        Calib& c = p->calib;
+        const int i = (int)(c.f_next % Calib::NF);
+        RD_HIP(hipEventRecord(c.f_ev[i], L->st));
+        c.f_rows[i] = P.total_rows;
+        c.f_prec[i] = ctx->precision;
+        c.f_next++;
+        if (c.f_seen + Calib::NF - Calib::WIN < c.f_next) c.f_seen = c.f_next - (Calib::NF - Calib::WIN);   // (windows whose first event is gone)
+    }
 
     // ---- the batch is part of the group
     s->seqs.insert(s->seqs.end(), seqs.begin(), seqs.end());
@@ -618,7 +768,7 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
     if (mode == 1) {
         // global mode: by coverage of the longest read's chain (see chain_rows), not by a batch count
         const bool few = part && (int)s->seqs.size() <= part_seq_limit(part, W);
-        close = s->rows >= chain_rows(W, few) * s->longest || s->rows >= kGroupRowsCap;
+        close = s->rows >= chain_rows(ctx, p->calib, W, few, use_lm) * s->longest || s->rows >= kGroupRowsCap;
         // (the very first group of a context closes with its first batch: nothing is decoding yet, and its chains start one
         // group's forward time earlier -- a quarter of a second on a job of long reads)
         close = close || p->launches == 0;
@@ -630,6 +780,25 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------------------------------------ read-out of the policy
+// What the context has measured for its group policy so far (0: not yet) and the rule it would apply now.
+extern "C" int rd_pipe_policy_read(rd_ctx* ctx, int beam_width, int on_partition, int use_lm, double* ns_per_row, double* us_per_step,
+                                   int64_t* rows_per_step)
+{
+    RD_REQUIRE(ctx && ns_per_row && us_per_step && rows_per_step, "rd_pipe_policy_read: null argument");
+    RD_REQUIRE(beam_width >= 1 && beam_width <= rd_decode_max_width(), "beam_width %d out of range", beam_width);
+    RD_HIP(hipSetDevice(ctx->device));
+    ReadsPipe* p = nullptr;
+    int rc = rpipe_get(ctx, &p);
+    if (rc) return rc;
+    calib_harvest(p->calib);
+    *ns_per_row = p->calib.ns_row[ctx->precision];
+    const double* us = p->calib.find(Calib::key_of(beam_width, on_partition != 0, ctx->decode_math, ctx->precision, use_lm != 0));
+    *us_per_step = us ? *us : 0.0;
+    *rows_per_step = chain_rows(ctx, p->calib, beam_width, on_partition != 0, use_lm != 0);
+    return RD_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ internal hooks
 bool rd_rpipe_idle(const rd_ctx* ctx)
@@ -668,6 +837,12 @@ void rd_rpipe_destroy(rd_ctx* ctx)
     if (p->s_dec) (void)hipStreamSynchronize(p->s_dec);
     rd_masked_stream_release(p->s_part);   // (CU-masked streams are pooled, never destroyed: forward.hip)
     if (p->ev_switch) (void)hipEventDestroy(p->ev_switch);
+    for (auto& e : p->calib.f_ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& d : p->calib.d) {
+        if (d.e0) (void)hipEventDestroy(d.e0);
+        if (d.e1) (void)hipEventDestroy(d.e1);
+    }
     for (int i = 0; i < 2; i++) {
         RSlot& s = p->slot[i];
         s.probs.release();

@@ -238,3 +238,47 @@ def test_pipe_mode_and_partition_changes_between_batches(dev):
         else:
             assert all(len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b)) for a, b in zip(got, exp))
     dev.pipe_config(4)
+
+
+def test_pipe_policy_follows_precision_changes_mid_stream(dev):
+    """Round 4: the group policy measures its own forward rate and chain pace (pipe_reads.hip, Calib) per matrix-product mode, beam
+    width and arithmetic.  A stream of global-mode batches whose precision, arithmetic and width change between submits -- enough
+    submits for every measurement window to fill and be used -- delivers what the blocking calls deliver in the same modes."""
+    rng = np.random.default_rng(123)
+    small = _ragged(rng, 6, lo=3000, hi=7000)
+    big = _ragged(rng, 120, lo=300, hi=1200)
+    plan = []
+    for rep in range(3):
+        for prec, math, W in (("fp32", "glibc", 6), ("f16x3", "glibc", 6), ("bf16x3", "fast", 10), ("fp32", "fast", 10), ("f16x3", "glibc", 10)):
+            for reads in (small, small, big, small, small, big, small, small, small, small):
+                plan.append((prec, math, W, reads))
+    ref_cache = {}
+    dev.pipe_flush()
+    dev.pipe_config(2)
+    dev.pipe_set_lanes(2)
+    tickets = []
+    try:
+        for prec, math, W, reads in plan:
+            key = (prec, math, W, id(reads))
+            if key not in ref_cache:
+                dev.pipe_flush()
+                dev.set_precision(prec)
+                dev.set_decode_math(math)
+                ref_cache[key] = dev.basecall_raw_global(reads, 4, CHUNK, 256, W, False)
+        cur = None
+        for prec, math, W, reads in plan:
+            if cur != (prec, math):
+                dev.set_precision(prec)        # (context state: takes effect for the submits that follow; no flush)
+                dev.set_decode_math(math)
+                cur = (prec, math)
+            tickets.append(dev.pipe_submit_raw("global", reads, 4, CHUNK, 256, W, False))
+        for (prec, math, W, reads), t in zip(plan, tickets):
+            got, st = t.result()
+            exp, st_exp = ref_cache[(prec, math, W, id(reads))]
+            assert np.array_equal(st, st_exp)
+            assert all(np.array_equal(a, b) for a, b in zip(got, exp)), (prec, math, W, len(reads))
+    finally:
+        dev.pipe_flush()
+        dev.set_precision("fp32")
+        dev.set_decode_math("glibc")
+        dev.pipe_config(4)
