@@ -223,6 +223,72 @@ def _owned_reads(args, reads, shard, queue, sources):
         yield idx, read
 
 
+def _read_ahead(pairs, max_reads=8192, max_samples=48 << 20, block=128):
+    """(key, read) pairs -> (key, read_id, raw signal) with the HDF5 work -- group walks, dataset reads, the work queue's
+    claims -- done on a reader thread that runs ahead of the driver loop by at most max_reads reads / max_samples samples.
+    libhdf5 is called through ctypes, which releases the interpreter lock for the call, so parsing (~60 us of a ~100-us read in
+    libhdf5: tools/host_feed_bench.py) overlaps the loop's batching and the finishing of earlier batches; every libhdf5 call of
+    the process stays on this one thread.  Reads change hands in blocks of `block`: handing over every read makes the two
+    threads fight for the interpreter lock at every ctypes call (measured: half the rate of no thread at all).  Order is
+    preserved; an exception of the producer is re-raised by the consumer."""
+    import queue as queue_mod
+    import threading
+    q = queue_mod.Queue()
+    room = threading.Condition()
+    state = {"reads": 0, "samples": 0, "stop": False}
+
+    def produce():
+        try:
+            blk, n_s = [], 0
+            for key, read in pairs:
+                raw = np.asarray(read.get_raw_data())
+                blk.append((key, read.read_id, raw))
+                n_s += raw.shape[0]
+                if len(blk) >= block or n_s >= max_samples // 4:
+                    with room:
+                        while not state["stop"] and state["reads"] > 0 and (state["reads"] + len(blk) > max_reads or state["samples"] + n_s > max_samples):
+                            room.wait(0.1)
+                        if state["stop"]:
+                            return
+                        state["reads"] += len(blk)
+                        state["samples"] += n_s
+                    q.put((blk, n_s))
+                    blk, n_s = [], 0
+            if blk:
+                q.put((blk, n_s))
+            q.put(None)
+        except BaseException as e:      # (handed to the consumer)
+            q.put(e)
+        finally:
+            close = getattr(pairs, "close", None)
+            if close is not None:
+                try:
+                    close()             # (a generator: its finally blocks close the open fast5 file on this thread)
+                except Exception:
+                    pass
+
+    t = threading.Thread(target=produce, name="radian-read-ahead", daemon=True)
+    t.start()
+    try:
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            blk, n_s = item
+            with room:
+                state["reads"] -= len(blk)
+                state["samples"] -= n_s
+                room.notify()
+            yield from blk
+    finally:
+        with room:
+            state["stop"] = True
+            room.notify_all()
+        t.join(timeout=30.0)
+
+
 def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue=None, sources=None, on_result=None):
     """The driver loop (basecall.py:69-141) over `reads` (default: every read under args.fast5_dir), or over file-level
     `sources` (fast5.Fast5Source per file: the multi-GPU launcher's form).
@@ -372,13 +438,12 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
         finishing.clear()
 
     try:
-        for idx, read in _owned_reads(args, reads, shard, queue, sources):
-            raw = np.asarray(read.get_raw_data())
+        for idx, read_id, raw in _read_ahead(_owned_reads(args, reads, shard, queue, sources)):
             n = raw.shape[0]
             if n == 0:
                 flush()                  # keep the reference's message order
                 drain()
-                report_skipped(read.read_id, 2)
+                report_skipped(read_id, 2)
                 continue
             if args.decode_type == "chunk":
                 nw = (0 if n < args.chunk_len else (n - args.chunk_len) // args.step_size + 1) + 1   # windows decoded
@@ -387,7 +452,7 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
             if batch and n_win + nw > batch_limit(max(longest, n)):
                 flush()
                 longest = 0
-            batch.append((read.read_id, raw))
+            batch.append((read_id, raw))
             batch_idx.append(idx)
             n_win += nw
             longest = max(longest, n)

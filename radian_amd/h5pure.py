@@ -101,7 +101,16 @@ class PureFile:
 
     # ------------------------------------------------------------------ groups
     def _group_entries(self, addr):
-        """{name: object header address} of a symbol-table group."""
+        """{name: object header address} of a group.  Memoised per group (the file is read-only): resolving /read_x/Raw/Signal
+        walked the root group's whole symbol table for every read -- 15 ms per read in a 16 384-read file, 0.3 M samples/s
+        (tools/host_feed_bench.py read)."""
+        cache = self.__dict__.setdefault("_ent_cache", {})
+        got = cache.get(addr)
+        if got is None:
+            got = cache[addr] = self._group_entries_uncached(addr)
+        return got
+
+    def _group_entries_uncached(self, addr):
         m = self._msg(addr, 0x0011)
         if m is None:
             return self._compact_links(addr)

@@ -428,3 +428,25 @@ def test_stream_merger_bound_moves_past_finished_claims_and_abort_leaves_nothing
     assert m.finish() == 8
     assert os.listdir(out) == ["reads-0.fasta"]
     assert open(out / "reads-0.fasta").read().count(">") == 8
+
+
+def test_host_feed_dry_run_rate_floor(tmp_path):
+    """ The host side of a node WITHOUT its GPUs: tools/host_feed_bench.py runs the CLI's multi-GPU route -- launcher,
+    per-node file/read queue, fast5 parsing on each rank's read-ahead thread, the driver loop's batching and pipeline tickets, rank
+    result streams, the parent's streaming merge, FASTA rotation -- with a null device that returns at once.  Two ranks, 8000 reads
+    of 4096 samples: every read once, in input order, nine FASTA files, and a rate floor an order of magnitude under what this
+    measures on an idle 8-core box (2 ranks: ~45 M samples/s) -- a regression to per-read Python parsing
+    (0.3 M samples/s per core) or to a merge that runs after the ranks would fall through it."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import host_feed_bench as hb
+    res = hb.bench_ranks(2, 8000, 4096, 3, "global", keep=str(tmp_path))
+    assert res["records"] == 8000 and res["fasta_files"] == 9
+    assert res["M_samples_per_s"] >= 4.0, res
+    assert res["merge_after_last_rank_s"] <= 2.0, res
+    ids = []
+    for i in range(9):
+        with open(tmp_path / "out" / f"reads-{i}.fasta") as f:
+            ids += [ln[1:].strip() for ln in f if ln.startswith(">")]
+    exp = [f"{fi:03d}-{i:07d}" for fi in range(3) for i in range(2667 if fi < 2 else 2666)]
+    assert ids == exp
