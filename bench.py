@@ -327,6 +327,8 @@ def main():
                     help="untimed cross-checks on batch 0: streamed labels == windowed labels == the oracle's; probabilities within 1e-4 of the oracle's")
     ap.add_argument("--decode-group", type=int, default=8, help="batches per beam-search launch in the two-stream pipeline")
     ap.add_argument("--lanes", type=int, default=2, help="forward streams the pipelined batches rotate over (1..4)")
+    ap.add_argument("--decode-form", default="auto", choices=["auto", "one", "two", "waves", "lanes"],
+                    help="launch shape of the beam search (rd_set_decode_form; no effect on results): A/B runs")
     ap.add_argument("--conv-shape", type=int, default=0, choices=[0, 1],
                     help="fp32 conv workgroup shape: 0 = 128 x 256 tiles, two workgroups per CU (product); 1 = 256 x 256, one per CU (measurement)")
     ap.add_argument("--cpu-reads", type=int, default=0, help="reads in the CPU-baseline sample (0: sized to the usable core count)")
@@ -384,6 +386,7 @@ def main():
     be.set_precision(args.precision)
     be.set_decode_math(args.decode_math)
     be.set_conv_shape(args.conv_shape)
+    be.set_decode_form(args.decode_form)
 
     # ---- synthetic input, resident in HBM: 4 distinct batches of 64 reads per rank, cycled
     reads_per_batch = BATCH_WINDOWS // 8

@@ -110,8 +110,9 @@ int rd_load_lm_hashed(rd_ctx* ctx, const double* table, int table_order, int con
 int rd_set_logits(rd_ctx* ctx, int mode);
 /* Launch shape of the beam search (no effect on results; no reference counterpart): 0 = chosen per launch (default).  Widths
  * above 12: several waves per sequence while the launch leaves SIMDs idle, else two candidates per lane; 1 / 2 pin either.
- * Widths up to 6 (the reference's default, basecall.py:32): two sequences per wave (3 = the same, spelled out; 4 = one per
- * wave).  For tests and measurements. */
+ * Widths up to 12: two sequences per wave -- always for widths up to 6 (the reference's default, basecall.py:32: one
+ * candidate per lane of a half-wave), and for 7..12 (two candidates per lane) when the launch puts several waves on
+ * every SIMD; 3 = two per wave whenever the width allows, 4 = one per wave.  For tests and measurements. */
 int rd_set_decode_form(rd_ctx* ctx, int form);
 /* Decode partition of the global-mode reads pipeline (rd_pipe_submit_reads_global / rd_pipe_submit_raw_global; no effect on
  * results, no reference counterpart): cus_per_xcd CUs of each of the 8 XCDs are kept free of forward workgroups (the

@@ -168,7 +168,7 @@ class Backend:
         self._check(self._L.rd_set_logits(self._h, {"f32": 0, "f16": 1}[mode] if isinstance(mode, str) else int(mode)))
 
     def set_decode_form(self, form):
-        """'auto' (default); 'waves' / 'lanes': launch shape for widths above 12; 'two' / 'one': widths up to 6 always / never as
+        """'auto' (default); 'waves' / 'lanes': launch shape for widths above 12; 'two' / 'one': widths up to 12 always / never as
         two sequences per wave (rd_set_decode_form)."""
         self._check(self._L.rd_set_decode_form(self._h, {"auto": 0, "waves": 1, "lanes": 2, "two": 3, "one": 4}[form] if isinstance(form, str) else int(form)))
 

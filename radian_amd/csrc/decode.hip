@@ -792,28 +792,33 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
 }
 
 
-// ---- two sequences per wave (W <= 6) ------------------------------------------------------------------------------------
+// ---- two sequences per wave (W <= 12) -----------------------------------------------------------------------------------
 // At the reference's default width (basecall.py:32: beam 6) a step has at most 30 candidates: half of a wave.  Here a wave
-// carries TWO sequences, lanes 0-31 and lanes 32-63 ("halves"), through the same step as beam_search_kernel<PT, 1, 1, ...>:
+// carries TWO sequences, lanes 0-31 and lanes 32-63 ("halves"), through the same step as beam_search_kernel<PT, R, 1, ...>:
 // every phase is the one-wave kernel's with "wave-uniform" replaced by "uniform within the half" -- nb, next_id, the trie
 // pointers, the gate's signal side live in vector registers; ballots are taken per half; a branch is taken when either half
 // needs it and is a no-op for the lanes of the other; a half whose sequence has ended idles (valid = false everywhere) while
 // the other finishes.  Per issued instruction twice the sequences advance: the form for launches that are bound by
-// instruction issue (thousands of windows; waves beside a forward), not for a few long chains (a step is slower than the
-// one-sequence wave's).  No hashed contexts (the one-wave kernel takes those).
-template <typename PT, bool LM, bool GX>
+// instruction issue (thousands of windows; waves beside a forward), not for a few long chains.  No hashed contexts (the
+// one-wave kernel takes those).
+// R = 1: W <= 6, one candidate per lane of the half.  R = 2 (round 4): 7 <= W <= 12 -- the metric's width, beam 10 -- with two
+// candidates per lane (candidate q = s * 32 + lane of the half, the reference's insertion order again): the instruction stream
+// of the one-wave kernel's two-candidates-per-lane form, which costs 1.62-1.70x the one-candidate form's (tools/decode_r2.py),
+// for two sequences.
+template <typename PT, bool LM, bool GX, int R>
 __global__ __launch_bounds__(64) void beam_search2_kernel(DecodeArgs a, int n_seq)
 {
-    // (117-129 VGPRs: beside two conv waves of 176-200 a SIMD has 112-160 left, so the wave fits next to the relu / match variants and
-    // waits for a slot next to two residual ones; capping it at 96 -- amdgpu_waves_per_eu -- puts spills into scratch memory)
-    constexpr int WM = 6;               // beams per sequence
+    // (R = 1: 117-129 VGPRs: beside two conv waves of 176-200 a SIMD has 112-160 left, so the wave fits next to the relu / match variants
+    // and waits for a slot next to two residual ones; capping it at 96 -- amdgpu_waves_per_eu -- puts spills into scratch memory)
+    constexpr int WM = R == 1 ? 6 : 12; // beams per sequence: 5 WM <= 32 R candidates
     constexpr int TS = 32;              // time steps per prepass tile: one lane of the half per step
-    constexpr int KG = 16;              // keys per pass of the ranking loop
-    constexpr int SEG = 32 + KG;        // doubles per key segment (<= 30 survivors + the padding of the last group)
+    constexpr int KG = R == 1 ? 16 : 8; // keys per pass of the ranking loop
+    constexpr int SEG = 32 + KG;        // doubles per key segment (<= 32 survivors + the padding of the last group)
     constexpr int LOG_TN = 9, TN = 1 << LOG_TN;
+    static_assert(5 * WM <= 32 * R, "the candidates of a sequence fit its half");
     const int lane = threadIdx.x;
     const int h = lane >> 5;            // half = sequence slot of the wave
-    const int hl = lane & 31;           // lane inside the half = candidate index q
+    const int hl = lane & 31;           // lane inside the half
     const int seq_raw = 2 * (int)blockIdx.x + h;
     const bool have = seq_raw < n_seq;
     const int seq = have ? seq_raw : n_seq - 1;          // (an odd last wave: the second half idles on valid addresses)
@@ -830,7 +835,7 @@ __global__ __launch_bounds__(64) void beam_search2_kernel(DecodeArgs a, int n_se
 
     __shared__ Beam st_[2][2][WM];
     __shared__ __attribute__((aligned(16))) double scr_[2][5 * WM];      // cpy_pnb | cpy_pb | mb_v | mP | mQ
-    __shared__ __attribute__((aligned(16))) double keyC_[2][SEG];
+    __shared__ __attribute__((aligned(16))) double keyC_[2][R * SEG];    // one key segment per candidate slot, in insertion order
     __shared__ int mb_q_[2][WM], d_sel_[2][WM], newslot_[2][WM];
     __shared__ unsigned claims_[2][WM];
     __shared__ double lp_[2][TS][5];
@@ -931,156 +936,204 @@ __global__ __launch_bounds__(64) void beam_search2_kernel(DecodeArgs a, int n_se
             const int ncand = live ? 5 * nb : 0;
 
             // ---------------- Phase A (beam_search_kernel, Phase A: same reads, same selects)
-            const int q = hl;
-            bool valid = q < ncand;
-            const int bi = valid ? q / 5 : 0;
-            const int kk = q - 5 * (q / 5);
-            const bool is_copy = kk == 0;
+            bool valid[R], is_copy[R];
+            int bi[R], kk[R], pj[R], dcopy[R], xch[R], chx[R];
+            double c_ptot[R], c_pnb[R], c_pb[R], pnb_i[R], lpc[R];
+            double2 pp[R];
+            int2 ll[R];
+            unsigned p_e[R];
             const double lp_blank = lp[tt][4];
             bool s_open = false;
             if constexpr (LM) s_open = sent[tt] > a.s_thr;
             const double ptot_last = os[nb - 1].ptot;
             const int myn = os[hl < nb ? hl : 0].node;
-            const double2 pp = *(const double2*)&os[bi].ptot;
-            const double pnb_i = os[bi].pnb;
-            const int2 ll = *(const int2*)&os[bi].last;
-            int4 c4 = *(const int4*)&os[bi].child[0];
-            asm("" : "+v"(c4.x), "+v"(c4.y), "+v"(c4.z), "+v"(c4.w));
-            const int ci = (kk - 1) & 3;
-            const int c_lo = (ci & 1) ? c4.y : c4.x, c_hi = (ci & 1) ? c4.w : c4.z;
-            const int chx = (ci & 2) ? c_hi : c_lo;
+#pragma unroll
+            for (int s = 0; s < R; s++) {
+                const int q = s * 32 + hl;
+                valid[s] = q < ncand;
+                bi[s] = valid[s] ? q / 5 : 0;
+                kk[s] = q - 5 * (q / 5);
+                is_copy[s] = kk[s] == 0;
+                pp[s] = *(const double2*)&os[bi[s]].ptot;
+                pnb_i[s] = os[bi[s]].pnb;
+                ll[s] = *(const int2*)&os[bi[s]].last;
+                int4 c4 = *(const int4*)&os[bi[s]].child[0];
+                asm("" : "+v"(c4.x), "+v"(c4.y), "+v"(c4.z), "+v"(c4.w));
+                const int ci = (kk[s] - 1) & 3;
+                const int c_lo = (ci & 1) ? c4.y : c4.x, c_hi = (ci & 1) ? c4.w : c4.z;
+                chx[s] = (ci & 2) ? c_hi : c_lo;
+            }
             if (hl < W) claims[hl] = 0u;
             const unsigned my_e = tab[myn & (TN - 1)];
-            const int cc = is_copy ? ll.x : kk - 1;
-            double lpc = lp[tt][cc < 0 ? 0 : cc];
-            lpc = cc < 0 ? -INFINITY : lpc;
-            const int xch = (valid & !is_copy) ? chx : 0;
-            const unsigned p_e = tab[xch & (TN - 1)];
+#pragma unroll
+            for (int s = 0; s < R; s++) {
+                const int cc = is_copy[s] ? ll[s].x : kk[s] - 1;
+                lpc[s] = lp[tt][cc < 0 ? 0 : cc];
+                lpc[s] = cc < 0 ? -INFINITY : lpc[s];
+                xch[s] = (valid[s] & !is_copy[s]) ? chx[s] : 0;
+                p_e[s] = tab[xch[s] & (TN - 1)];
+            }
             const bool self_bad = live & (hl < nb) & (my_e != ((((unsigned)myn >> LOG_TN) << 8) | (unsigned)hl));
             const bool tab_ok = (__ballot(self_bad) & hmask) == 0ull;
-            const int last_i = ll.x;
-            if constexpr (LM) {
-                const int len_i = ll.y;
-                const int need = is_copy ? a.k + 1 : a.k;
-                if (s_open && valid && cc >= 0 && len_i >= need) {
-                    const unsigned hh = os[bi].hist;
-                    const unsigned ctx = (is_copy ? (hh >> 2) : hh) & ctx_mask;
-                    const bool gate = (a.lm_gate[ctx >> 5] >> (ctx & 31)) & 1u;
-                    if (gate) {
-                        const double r = a.lm_table[(size_t)ctx * 4 + cc];
-                        double val;
-                        if constexpr (sizeof(PT) == 4) {
-                            const float f0 = (float)praw[tt][0], f1 = (float)praw[tt][1], f2 = (float)praw[tt][2], f3 = (float)praw[tt][3];
-                            const float bp = ((f0 + f1) + f2) + f3;
-                            const float sb = (float)praw[tt][cc] / bp;
-                            val = ((r + (double)sb) / 2.0) * (double)bp;
-                        } else {
-                            const double bp = ((praw[tt][0] + praw[tt][1]) + praw[tt][2]) + praw[tt][3];
-                            const double sb = praw[tt][cc] / bp;
-                            val = ((r + sb) / 2.0) * bp;
+#pragma unroll
+            for (int s = 0; s < R; s++) {
+                const int last_i = ll[s].x;
+                if constexpr (LM) {
+                    const int len_i = ll[s].y;
+                    const int cc = is_copy[s] ? last_i : kk[s] - 1;
+                    const int need = is_copy[s] ? a.k + 1 : a.k;
+                    if (s_open && valid[s] && cc >= 0 && len_i >= need) {
+                        const unsigned hh = os[bi[s]].hist;
+                        const unsigned ctx = (is_copy[s] ? (hh >> 2) : hh) & ctx_mask;
+                        const bool gate = (a.lm_gate[ctx >> 5] >> (ctx & 31)) & 1u;
+                        if (gate) {
+                            const double r = a.lm_table[(size_t)ctx * 4 + cc];
+                            double val;
+                            if constexpr (sizeof(PT) == 4) {
+                                const float f0 = (float)praw[tt][0], f1 = (float)praw[tt][1], f2 = (float)praw[tt][2], f3 = (float)praw[tt][3];
+                                const float bp = ((f0 + f1) + f2) + f3;
+                                const float sb = (float)praw[tt][cc] / bp;
+                                val = ((r + (double)sb) / 2.0) * (double)bp;
+                            } else {
+                                const double bp = ((praw[tt][0] + praw[tt][1]) + praw[tt][2]) + praw[tt][3];
+                                const double sb = praw[tt][cc] / bp;
+                                val = ((r + sb) / 2.0) * bp;
+                            }
+                            lpc[s] = safe_log<GX>(val);
                         }
-                        lpc = safe_log<GX>(val);
                     }
                 }
+                const double pnb_c = (last_i >= 0) ? pnb_i[s] + lpc[s] : -INFINITY;
+                const double pb_c = pp[s].x + lp_blank;
+                const double v = ((last_i == kk[s] - 1) ? pp[s].y : pp[s].x) + lpc[s];
+                c_pnb[s] = is_copy[s] ? pnb_c : v;
+                c_pb[s] = is_copy[s] ? pb_c : -INFINITY;
+                c_ptot[s] = is_copy[s] ? 0.0 : v;
+                dcopy[s] = is_copy[s] ? bi[s] : -1;
+                if (valid[s] & is_copy[s]) {
+                    cpy_pnb[bi[s]] = pnb_c;
+                    cpy_pb[bi[s]] = pb_c;
+                    mb_q[bi[s]] = -1;
+                    newslot[bi[s]] = -1;
+                }
+                pj[s] = (tab_ok & (xch[s] != 0) & ((p_e[s] >> 8) == ((unsigned)xch[s] >> LOG_TN))) ? (int)(p_e[s] & 0xffu) : -1;
             }
-            const double pnb_c = (last_i >= 0) ? pnb_i + lpc : -INFINITY;
-            const double pb_c = pp.x + lp_blank;
-            const double v = ((last_i == kk - 1) ? pp.y : pp.x) + lpc;
-            double c_pnb = is_copy ? pnb_c : v;
-            double c_pb = is_copy ? pb_c : -INFINITY;
-            double c_ptot = is_copy ? 0.0 : v;
-            int dcopy = is_copy ? bi : -1;
-            if (valid & is_copy) {
-                cpy_pnb[bi] = pnb_c;
-                cpy_pb[bi] = pb_c;
-                mb_q[bi] = -1;
-                newslot[bi] = -1;
-            }
-            int pj = (tab_ok & (xch != 0) & ((p_e >> 8) == ((unsigned)xch >> LOG_TN))) ? (int)(p_e & 0xffu) : -1;
             if (__any(!tab_ok)) {    // two kept beams of a half share a table entry (rare): that half compares against every beam
                 for (int j = 0; j < WM; j++) {
                     const int nj = os[j < nb ? j : 0].node;
-                    if (!tab_ok && j < nb && xch != 0 && nj == xch) pj = j;
+#pragma unroll
+                    for (int s = 0; s < R; s++)
+                        if (!tab_ok && j < nb && xch[s] != 0 && nj == xch[s]) pj[s] = j;
                 }
             }
-            const bool any_merge = __any(pj >= 0);          // in either half
+            bool any_merge = false;                         // in either half
+#pragma unroll
+            for (int s = 0; s < R; s++) any_merge |= __any(pj[s] >= 0) != 0;
             wave_sync();
 
             // ---------------- lae pass 1 / 2 (decode.py:174-175,199-201)
-            {
-                const bool mext = pj >= 0;
-                const double cp = cpy_pnb[mext ? pj : 0];
-                const double x = mext ? cp : c_pb;
-                const double y = mext ? c_ptot : c_pnb;
+#pragma unroll
+            for (int s = 0; s < R; s++) {
+                const bool mext = pj[s] >= 0;
+                const double cp = cpy_pnb[mext ? pj[s] : 0];
+                const double x = mext ? cp : c_pb[s];
+                const double y = mext ? c_ptot[s] : c_pnb[s];
                 const double r = GX ? lae_gx(x, y, gx_exp) : lae(x, y);
-                c_ptot = is_copy ? r : c_ptot;
+                c_ptot[s] = is_copy[s] ? r : c_ptot[s];
                 if (mext) {
-                    mb_q[pj] = q;
-                    mb_v[pj] = c_ptot;
-                    mQ[pj] = r;
+                    mb_q[pj[s]] = s * 32 + hl;
+                    mb_v[pj[s]] = c_ptot[s];
+                    mQ[pj[s]] = r;
                 }
             }
             if (any_merge) {
                 wave_sync();
-                {
-                    const int qe = mb_q[bi];
-                    const double mv = mb_v[bi];
-                    const bool m = valid & is_copy & (qe >= 0);
-                    const double r = GX ? lae_gx(c_ptot, m ? mv : -INFINITY, gx_exp) : lae(c_ptot, m ? mv : -INFINITY);
-                    if (m) mP[bi] = r;
+#pragma unroll
+                for (int s = 0; s < R; s++) {
+                    const int qe = mb_q[bi[s]];
+                    const double mv = mb_v[bi[s]];
+                    const bool m = valid[s] & is_copy[s] & (qe >= 0);
+                    const double r = GX ? lae_gx(c_ptot[s], m ? mv : -INFINITY, gx_exp) : lae(c_ptot[s], m ? mv : -INFINITY);
+                    if (m) mP[bi[s]] = r;
                 }
                 wave_sync();
-                {
-                    const int j = is_copy ? bi : (pj >= 0 ? pj : 0);
+#pragma unroll
+                for (int s = 0; s < R; s++) {
+                    const int q = s * 32 + hl;
+                    const int j = is_copy[s] ? bi[s] : (pj[s] >= 0 ? pj[s] : 0);
                     const int qe = mb_q[j];
                     const double P = mP[j], Q = mQ[j], cb = cpy_pb[j];
-                    const bool merged = valid & (is_copy ? qe >= 0 : pj >= 0);
-                    const int qother = is_copy ? qe : 5 * j;
+                    const bool merged = valid[s] & (is_copy[s] ? qe >= 0 : pj[s] >= 0);
+                    const int qother = is_copy[s] ? qe : 5 * j;
                     const bool mk = merged & (q < qother);
-                    const bool mke = mk & !is_copy;
-                    c_ptot = mk ? P : c_ptot;
-                    c_pnb = mk ? Q : c_pnb;
-                    c_pb = mke ? cb : c_pb;
-                    dcopy = mke ? j : dcopy;
-                    valid = valid & (!merged | mk);
+                    const bool mke = mk & !is_copy[s];
+                    c_ptot[s] = mk ? P : c_ptot[s];
+                    c_pnb[s] = mk ? Q : c_pnb[s];
+                    c_pb[s] = mke ? cb : c_pb[s];
+                    dcopy[s] = mke ? j : dcopy[s];
+                    valid[s] = valid[s] & (!merged | mk);
                 }
             }
 
             // ---------------- Phase D: rank by (pr_total desc, insertion order asc) among the candidates >= tau
-            const double key = valid ? c_ptot : __builtin_nan("");
+            double key[R];
+            bool surv[R];
+            int lidx[R], scnt[R];
+            int nvalid = 0;
             const double tau = (nb == W) ? ptot_last + lp_blank : -INFINITY;
-            const bool surv = valid && key >= tau;
-            const unsigned mv32 = (unsigned)((__ballot(valid) & hmask) >> (32 * h));
-            const unsigned ms32 = (unsigned)((__ballot(surv) & hmask) >> (32 * h));
-            const int vcnt = __popc(mv32), scnt = __popc(ms32);
-            const int lidx = __popc(ms32 & ((1u << hl) - 1u));
-            // the whole tail of the segment is padding (the other half may have more survivors and sets the loop's trip count)
-            if (hl >= scnt) keyC[hl] = -INFINITY;
-            if (hl < KG) keyC[32 + hl] = -INFINITY;
-            wave_sync();
-            if (surv) keyC[lidx] = key;
-            wave_sync();
-            const int scnt_o = __shfl_xor(scnt, 32);
-            const int smax = __builtin_amdgcn_readfirstlane(scnt > scnt_o ? scnt : scnt_o);
-            int rank = 0;
-            for (int j = 0; j < smax; j += KG) {
-                double2 kq[KG / 2];
 #pragma unroll
-                for (int u = 0; u < KG / 2; u++) kq[u] = *(const double2*)&keyC[j + 2 * u];
-#pragma unroll
-                for (int u = 0; u < KG / 4; u++) rank = count4_gt(rank, kq[2 * u].x, kq[2 * u].y, kq[2 * u + 1].x, kq[2 * u + 1].y, key);
+            for (int s = 0; s < R; s++) {
+                key[s] = valid[s] ? c_ptot[s] : __builtin_nan("");
+                surv[s] = valid[s] && key[s] >= tau;
+                const unsigned mv32 = (unsigned)((__ballot(valid[s]) & hmask) >> (32 * h));
+                const unsigned ms32 = (unsigned)((__ballot(surv[s]) & hmask) >> (32 * h));
+                nvalid += __popc(mv32);
+                scnt[s] = __popc(ms32);
+                lidx[s] = __popc(ms32 & ((1u << hl) - 1u));
+                // the whole tail of the segment is padding (the other half may have more survivors and sets the loop's trip count)
+                double* kseg = keyC + s * SEG;
+                if (hl >= scnt[s]) kseg[hl] = -INFINITY;
+                if (hl < KG) kseg[32 + hl] = -INFINITY;
             }
-            const int nb_new = vcnt < W ? vcnt : W;
+            wave_sync();
+#pragma unroll
+            for (int s = 0; s < R; s++)
+                if (surv[s]) keyC[s * SEG + lidx[s]] = key[s];
+            wave_sync();
+            int smax[R], rank[R];
+#pragma unroll
+            for (int s = 0; s < R; s++) {
+                const int scnt_o = __shfl_xor(scnt[s], 32);
+                smax[s] = __builtin_amdgcn_readfirstlane(scnt[s] > scnt_o ? scnt[s] : scnt_o);
+                rank[s] = 0;
+            }
+#pragma unroll
+            for (int g = 0; g < R; g++) {
+                const double* kseg = keyC + g * SEG;
+                for (int j = 0; j < smax[g]; j += KG) {
+                    double2 kq[KG / 2];
+#pragma unroll
+                    for (int u = 0; u < KG / 2; u++) kq[u] = *(const double2*)&kseg[j + 2 * u];
+#pragma unroll
+                    for (int u = 0; u < KG / 4; u++)
+#pragma unroll
+                        for (int s = 0; s < R; s++) rank[s] = count4_gt(rank[s], kq[2 * u].x, kq[2 * u].y, kq[2 * u + 1].x, kq[2 * u + 1].y, key[s]);
+                }
+            }
+            const int nb_new = nvalid < W ? nvalid : W;
 
             // ---------------- Phase E: the kept candidates move to their new beam slot
             auto scatter = [&](bool on) {
-                if (on && surv && rank < W) {
-                    const int r = rank;
-                    *(double2*)&ns[r].ptot = make_double2(c_ptot, c_pb);
-                    ns[r].pnb = c_pnb;
-                    d_sel[r] = (dcopy & 0xff) | (bi << 8) | (kk << 16);
-                    atomicAdd(&claims[r], 1u);
-                    if (dcopy >= 0) newslot[dcopy] = r;
+#pragma unroll
+                for (int s = 0; s < R; s++) {
+                    if (on && surv[s] && rank[s] < W) {
+                        const int r = rank[s];
+                        *(double2*)&ns[r].ptot = make_double2(c_ptot[s], c_pb[s]);
+                        ns[r].pnb = c_pnb[s];
+                        d_sel[r] = (dcopy[s] & 0xff) | (bi[s] << 8) | (kk[s] << 16);
+                        atomicAdd(&claims[r], 1u);
+                        if (dcopy[s] >= 0) newslot[dcopy[s]] = r;
+                    }
                 }
             };
             scatter(true);
@@ -1093,12 +1146,23 @@ __global__ __launch_bounds__(64) void beam_search2_kernel(DecodeArgs a, int n_se
             const bool tie_h = ((__ballot((hl < nb_new) & (n_claims != 1u)) & hmask) != 0ull);
             if (__any(tie_h)) {
                 // equal keys claimed one slot: redo the count with the insertion-order rule -- in the half that has the tie
-                int rank2 = 0;
-                for (int j = 0; j < smax; j++) {
-                    const double kv = keyC[j];
-                    rank2 += (j < scnt && ((kv > key) || (kv == key && j < lidx))) ? 1 : 0;
+                int rank2[R];
+#pragma unroll
+                for (int s = 0; s < R; s++) rank2[s] = 0;
+#pragma unroll
+                for (int g = 0; g < R; g++) {
+                    const double* kseg = keyC + g * SEG;
+                    for (int j = 0; j < smax[g]; j++) {
+                        const double kv = kseg[j];
+#pragma unroll
+                        for (int s = 0; s < R; s++) {
+                            const bool before = g < s || (g == s && j < lidx[s]);      // insertion order = (slot segment, index in segment)
+                            rank2[s] += (j < scnt[g] && ((kv > key[s]) || (kv == key[s] && before))) ? 1 : 0;
+                        }
+                    }
                 }
-                rank = tie_h ? rank2 : rank;
+#pragma unroll
+                for (int s = 0; s < R; s++) rank[s] = tie_h ? rank2[s] : rank[s];
                 if (tie_h && hl < nb) newslot[hl] = -1;
                 wave_sync();
                 scatter(tie_h);
@@ -1215,16 +1279,16 @@ int launch_r(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
     return a.glibc_math ? launch_g<PT, R, NW, true>(st, a, n_seq, lm) : launch_g<PT, R, NW, false>(st, a, n_seq, lm);
 }
 
-template <typename PT>
+template <typename PT, int R>
 int launch_two(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
 {
     const dim3 grid((unsigned)((n_seq + 1) / 2));
     if (lm) {
-        if (a.glibc_math) hipLaunchKernelGGL((beam_search2_kernel<PT, true, true>), grid, dim3(64), 0, st, a, n_seq);
-        else hipLaunchKernelGGL((beam_search2_kernel<PT, true, false>), grid, dim3(64), 0, st, a, n_seq);
+        if (a.glibc_math) hipLaunchKernelGGL((beam_search2_kernel<PT, true, true, R>), grid, dim3(64), 0, st, a, n_seq);
+        else hipLaunchKernelGGL((beam_search2_kernel<PT, true, false, R>), grid, dim3(64), 0, st, a, n_seq);
     } else {
-        if (a.glibc_math) hipLaunchKernelGGL((beam_search2_kernel<PT, false, true>), grid, dim3(64), 0, st, a, n_seq);
-        else hipLaunchKernelGGL((beam_search2_kernel<PT, false, false>), grid, dim3(64), 0, st, a, n_seq);
+        if (a.glibc_math) hipLaunchKernelGGL((beam_search2_kernel<PT, false, true, R>), grid, dim3(64), 0, st, a, n_seq);
+        else hipLaunchKernelGGL((beam_search2_kernel<PT, false, false, R>), grid, dim3(64), 0, st, a, n_seq);
     }
     RD_HIP(hipGetLastError());
     return RD_OK;
@@ -1237,8 +1301,15 @@ int launch_pt(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm, int n_sim
     // steps/s (glibc arithmetic 1.10 -> 1.55 G, soft rows 0.94 -> 1.32 G); 512 windows -- lone waves, the latency case -- 1.58 vs
     // 1.60 ms per launch: a step of the two-sequence wave is as short as the one-sequence wave's, so there is no case for the
     // latter (rd_set_decode_form 4 keeps it reachable for tests and A/B runs; 3 = the default's choice, spelled out)
+    if (a.W <= 6 && !(lm && a.hashed) && form != 4 && n_seq >= 2) return launch_two<PT, 1>(st, a, n_seq, lm);
+    // 7 <= W <= 12: two sequences per wave with two candidates per lane of the half exists (form 3) and is NOT the default's choice.
+    // Measured (round 4; tools/decode_r2.py, tools/bench_ab2.sh; profiles/r04_beam_search_two_r2.txt): 4096 windows x 1024 rows at
+    // W = 10 alone on the chip 1005 M time steps/s against 1190 M one per wave (glibc arithmetic 859 against 1079 M); the headline
+    // loop 26.2 against 26.6 M samples/s.  Its instruction stream is 1.62-1.70x the one-candidate form's for two sequences (0.82x
+    // per sequence), but it halves the waves that hide each other's LDS round trips, and at 131-145 VGPRs the wave no longer fits
+    // beside two conv waves of 206 on a SIMD (the one-sequence wave: 82-103).
+    if (a.W <= 12 && !(lm && a.hashed) && n_seq >= 2 && form == 3) return launch_two<PT, 2>(st, a, n_seq, lm);
     (void)n_simd;
-    if (a.W <= 6 && !(lm && a.hashed) && form != 4 && n_seq >= 2) return launch_two<PT>(st, a, n_seq, lm);
     if (a.W <= Cfg<1, 1>::WM) return form == 2 ? launch_r<PT, 2, 1>(st, a, n_seq, lm) : launch_r<PT, 1, 1>(st, a, n_seq, lm);   // (form 2 here: measurements only)
     // wide form while every wave still gets a SIMD of its own
     const bool mid = a.W <= Cfg<1, 2>::WM;

@@ -31,7 +31,7 @@ def run(rounds=20, seed=0, tmax=400, nseq=800, be=None, log=print):
             mats, off, lens = _mats(rng, nseq, tmax, kind, dtype)
             W = int(rng.choice([1, 2, 5, 6, 7, 9, 10, 12, 13, 25, 26, 40, 51]))
             s_thr, r_thr = float(rng.choice([0.0, 0.5, 0.8])), float(rng.choice([0.5, 0.9, 2.0]))
-            form = str(rng.choice(["auto", "waves", "lanes"]))     # launch shape for W > 12 (rd_set_decode_form)
+            form = str(rng.choice(["auto", "waves", "lanes", "two", "one"]))     # launch shape (rd_set_decode_form): waves / lanes for W > 12, two / one for W <= 12
             be.set_decode_form(form)
             math = str(rng.choice(["fast", "glibc"]))              # arithmetic of log / logaddexp (rd_set_decode_math)
             be.set_decode_math(math)

@@ -234,7 +234,8 @@ def test_sequence_too_long_for_the_backpointer_packing_is_refused():
 
 
 def test_two_sequences_per_wave_form(be, golden_dir, oracle):
-    """W <= 6 as two sequences per wave (beam_search2_kernel; rd_set_decode_form 3): every golden case of those widths -- no-LM
+    """W <= 12 as two sequences per wave (beam_search2_kernel: one candidate per lane of the half for W <= 6, two for 7 <= W <= 12 --
+    round 4; rd_set_decode_form 3): every golden case of those widths -- no-LM
     incl. the exact-0 / duplicated-row matrices, LM with k in {1, 3, 5} -- with bit-exact winner scores in glibc arithmetic; then
     batches against the oracle where the two halves of a wave carry sequences of different lengths (incl. empty ones and an odd
     sequence count), float32 / float64 / exact-tie ("quant") rows, both arithmetics, with and without an LM."""
@@ -243,8 +244,8 @@ def test_two_sequences_per_wave_form(be, golden_dir, oracle):
     try:
         g = json.load(open(os.path.join(golden_dir, "beam_nolm_cases.json")))
         mats = np.load(os.path.join(golden_dir, "beam_nolm_mats.npz"))
-        cases = [c for c in g["cases"] if c["W"] <= 6]
-        assert len(cases) >= 60
+        cases = [c for c in g["cases"] if c["W"] <= 12]
+        assert len(cases) >= 90 and any(c["W"] == 10 for c in cases)
         for math in ("glibc", "fast"):
             be.set_decode_math(math)
             # all cases of one width in ONE batch: neighbours share waves
@@ -264,7 +265,7 @@ def test_two_sequences_per_wave_form(be, golden_dir, oracle):
         be.set_decode_math("glibc")
         cur, n_lm = None, 0
         for c in gl["cases"]:
-            if c["W"] > 6:
+            if c["W"] > 12:
                 continue
             if cur != c["lm"]:
                 be.load_lm(ml[c["lm"]], c["k"])
@@ -276,14 +277,14 @@ def test_two_sequences_per_wave_form(be, golden_dir, oracle):
             got = be.decode_batch(rows, [0, T, 2 * T], [T, T, T], c["W"], use_lm=True, s_threshold=fdec(c["s_thr"]), r_threshold=fdec(c["r_thr"]))
             assert all(s_of(x) == c["seq"] for x in got), (c["mat"], c["k"], c["W"])
             n_lm += 1
-        assert n_lm >= 100
+        assert n_lm >= 200
         be.load_lm(None, 0)
         # random batches against the oracle: ragged lengths, so the halves of a wave end at different steps
         rng = np.random.default_rng(66)
         table = rng.dirichlet([0.3] * 4, size=4 ** 3)
         for kind in ("flat", "peaky", "blocky", "quant"):
             for dt in (np.float32, np.float64):
-                for W in (1, 2, 3, 6):
+                for W in (1, 2, 3, 6, 7, 10, 12):
                     m, off, lens = _mats(rng, 301, 260, kind, dt)
                     lens[::7] = 0
                     lens[5] = 1
@@ -322,7 +323,7 @@ def test_sparse_lm_reports_exactly_the_reads_the_reference_fails_on(be, golden_d
                 table[c["missing"]] = np.nan
                 be.load_lm(table, c["k"])
                 mat = mats[c["mat"]]
-                for form in (("auto", "one") if c["W"] <= 6 else ("auto",)):
+                for form in (("auto", "one", "two") if c["W"] <= 12 else ("auto",)):
                     be.set_decode_form(form)
                     # the case twice in one launch (both halves of a two-sequence wave) + a one-row sequence that cannot reach any context
                     rows = np.concatenate([mat, mat, mat[:1]])
