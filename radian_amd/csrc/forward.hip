@@ -1732,6 +1732,10 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl
     for (int li = 0; li < nl; li++) {
         const int b = li == nl - 1 ? m.nblocks : li / 2;
         const int kind = li == nl - 1 ? 3 : (li == 0 ? 0 : (li & 1 ? 2 : 1));
+#ifdef RD_EXPERIMENTS   // timing only (wrong results): what would a forward without its first-conv / head launch cost?
+        static const bool x_skip_in = getenv("RD_X_SKIP_IN") != nullptr, x_skip_head = getenv("RD_X_SKIP_HEAD") != nullptr;
+        if ((kind == 0 && x_skip_in) || (kind == 3 && x_skip_head)) continue;
+#endif
         if ((rc = launch_layer(ctx, x_alt && (li & 1) ? L->st2 : L->st, b, kind, tl.d[li], tl.n[li], (double)tl.rows[li], zero_row, d_signal, Xin, Xout, MID, (float*)d_probs, probs_f16))) return rc;
         if (kind == 2) {   // block finished: its output becomes the next block's input
             float* t = Xin;

@@ -65,13 +65,15 @@ inline int64_t chain_rows_default(int W, bool on_partition)
 // ends of every group's beam search (elapsed / longest chain).  Until a figure exists the constant stands in, scaled by the measured
 // forward rate when that is known.
 struct Calib {
-    static constexpr int NF = 16, WIN = 8, ND = 4;
-    hipEvent_t f_ev[NF] = {};
-    int64_t f_rows[NF] = {};
-    int f_prec[NF] = {};
-    int64_t f_next = 0;        // submits recorded so far
-    int64_t f_seen = 0;        // windows ending before this submit index have been looked at
-    double ns_row[3] = {0.0, 0.0, 0.0};   // per matrix-product mode; 0: not measured yet
+    static constexpr int NF = 16, ND = 4;
+    struct Fwd {
+        hipEvent_t e0 = nullptr, e1 = nullptr;   // both ends of a submit's lane work
+        int64_t rows = 0;
+        int prec = 0, lanes = 1;
+        bool pending = false;
+    } f[NF];
+    int64_t f_next = 0;
+    double ns_row[3] = {0.0, 0.0, 0.0};   // per matrix-product mode, all lanes together; 0: not measured yet
     struct Dec {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         int64_t longest = 0;
@@ -93,38 +95,26 @@ struct Calib {
 // completed measurements -> estimates (never blocks: an event that has not fired yet is looked at again later)
 void calib_harvest(Calib& c)
 {
-    while (c.f_seen < c.f_next) {
-        const int64_t j = c.f_seen;
-        if (j < Calib::WIN) {
-            c.f_seen++;
-            continue;
-        }
-        if (c.f_next - j >= Calib::NF - Calib::WIN) {   // its first event has been re-recorded since: skip
-            c.f_seen++;
-            continue;
-        }
-        hipEvent_t a = c.f_ev[(j - Calib::WIN) % Calib::NF], b = c.f_ev[j % Calib::NF];
-        if (hipEventQuery(b) != hipSuccess) {
+    // Forward pace: a submit's lane work took (e0 -> e1) on ONE of `lanes` streams that share the chip, so all lanes together
+    // produce its rows in duration / lanes.  Deliberately not the time between the completions of consecutive submits: that
+    // includes every pause of the pipeline (the host waiting for a group slot because a beam search was not covered), reads slow,
+    // shrinks the rule, covers less -- a runaway seen on the reference-defaults job (80 ns per row "measured", groups a third of
+    // the constants', 13 M samples/s instead of 28 M).  A lane that runs while the others pause finishes sooner than its share,
+    // so under pauses this estimate errs towards a FASTER forward, i.e. towards larger groups, which removes the pauses.
+    for (auto& f : c.f) {
+        if (!f.pending || hipEventQuery(f.e1) != hipSuccess) {
             (void)hipGetLastError();
-            break;
+            continue;
         }
         float ms = 0.f;
-        bool same = true;
-        int64_t rows = 0;
-        for (int64_t k = j - Calib::WIN + 1; k <= j; k++) {
-            rows += c.f_rows[k % Calib::NF];
-            same = same && c.f_prec[k % Calib::NF] == c.f_prec[j % Calib::NF];
-        }
-        same = same && c.f_prec[(j - Calib::WIN) % Calib::NF] == c.f_prec[j % Calib::NF];
-        if (same && rows > 0 && hipEventElapsedTime(&ms, a, b) == hipSuccess && ms > 0.f) {
-            const double ns = (double)ms * 1e6 / (double)rows;
-            double& e = c.ns_row[c.f_prec[j % Calib::NF]];
-            // a window that held a pause of the host reads slow: such samples are taken with a small weight only
-            e = e == 0.0 ? ns : (ns < e ? 0.5 * e + 0.5 * ns : 0.9 * e + 0.1 * ns);
+        if (f.rows > 0 && hipEventElapsedTime(&ms, f.e0, f.e1) == hipSuccess && ms > 0.f) {
+            const double ns = (double)ms * 1e6 / ((double)f.rows * (double)f.lanes);
+            double& e = c.ns_row[f.prec];
+            e = e == 0.0 ? ns : 0.75 * e + 0.25 * ns;
         } else {
             (void)hipGetLastError();
         }
-        c.f_seen++;
+        f.pending = false;
     }
     for (auto& d : c.d) {
         if (!d.pending || hipEventQuery(d.e1) != hipSuccess) {
@@ -156,14 +146,12 @@ int64_t chain_rows(const rd_ctx* ctx, Calib& c, int W, bool on_partition, int us
     if (ns <= 0.0) return def;
     const double scaled = (double)def * kDefaultNsPerRow / ns;   // the constant, for the forward this context really runs
     double rows = scaled;
-    if (us) {
-        rows = *us * 1e3 / ns * 1.3;          // measured chain pace over measured forward pace, + 30 %
-        // Beside conv waves (no partition) a group's search time depends on the group's own size -- thousands of slow waves
-        // hide each other -- so elapsed / longest chain of a SMALL group under-states what coverage needs: there the measurement
-        // may only raise the rule (measured with the constants: 512 reads x 4096 per step 30.2 M samples/s, 29.1 M when the
-        // measured figure was allowed to shrink the groups; profiles/r04_policy_ab.txt)
-        if (!on_partition && rows < scaled) rows = scaled;
-    }
+    // The measured chain pace is used on the decode partition only: there every sequence of the group has a wave slot of its own and
+    // elapsed / longest chain IS the pace of a chain.  Beside conv waves (no partition, thousands of sequences) a group's search time
+    // is its total work over the chip's rate -- proportional to the group's size -- so elapsed / longest grows with the group, the rule
+    // with it, the next group with the rule: a runaway to the row cap (seen on the reference-defaults job of 16 384 ragged reads:
+    // 13.4 M samples/s instead of 27.9 M).  There the rule is the constant for the beam width, scaled by the measured forward rate.
+    if (us && on_partition) rows = *us * 1e3 / ns * 1.3;          // measured chain pace over measured forward pace, + 30 %
     const double lo = (double)def / 3.0, hi = (double)def * 6.0;
     rows = rows < lo ? lo : rows > hi ? hi : rows;
     return (int64_t)rows;
@@ -281,7 +269,10 @@ int rpipe_get(rd_ctx* ctx, ReadsPipe** out)
         RD_HIP(hipStreamCreateWithPriority(&p->s_dec, hipStreamNonBlocking, hi));
         for (int i = 0; i < 2; i++) RD_HIP(hipEventCreateWithFlags(&p->slot[i].dec_done, hipEventDisableTiming));
         RD_HIP(hipEventCreateWithFlags(&p->ev_switch, hipEventDisableTiming));
-        for (auto& e : p->calib.f_ev) RD_HIP(hipEventCreate(&e));          // (timing events: the policy's measurements)
+        for (auto& f : p->calib.f) {                                       // (timing events: the policy's measurements)
+            RD_HIP(hipEventCreate(&f.e0));
+            RD_HIP(hipEventCreate(&f.e1));
+        }
         for (auto& d : p->calib.d) {
             RD_HIP(hipEventCreate(&d.e0));
             RD_HIP(hipEventCreate(&d.e1));
@@ -716,6 +707,15 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
     }
 
     // ---- the lane's work, in stream order: copies out of the staging block, normalise, forward, assembly
+    Calib::Fwd* cf = nullptr;
+    {
+        Calib::Fwd& f = p->calib.f[p->calib.f_next % Calib::NF];
+        if (!f.pending) {
+            cf = &f;
+            p->calib.f_next++;
+            RD_HIP(hipEventRecord(f.e0, L->st));
+        }
+    }
     const float* sig = d_signal;
     if (raw) {
         memcpy(hs, read_off, (size_t)(n_reads + 1) * 8);
@@ -743,14 +743,12 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
     if (raw)
         RD_HIP(hipMemcpyAsync((char*)s->status.p + (size_t)s->n_reads * 4, (char*)R.raw.p + d_st, (size_t)n_reads * 4, hipMemcpyDeviceToDevice, L->st));
     RD_HIP(hipEventRecord(L->done, L->st));   // the decode stream waits for this before it reads the group
-    {   // the policy's forward-rate measurement: the end of this submit's lane work
-        Calib& c = p->calib;
-        const int i = (int)(c.f_next % Calib::NF);
-        RD_HIP(hipEventRecord(c.f_ev[i], L->st));
-        c.f_rows[i] = P.total_rows;
-        c.f_prec[i] = ctx->precision;
-        c.f_next++;
-        if (c.f_seen + Calib::NF - Calib::WIN < c.f_next) c.f_seen = c.f_next - (Calib::NF - Calib::WIN);   // (windows whose first event is gone)
+    if (cf) {   // the policy's forward-rate measurement: the end of this submit's lane work
+        RD_HIP(hipEventRecord(cf->e1, L->st));
+        cf->rows = P.total_rows;
+        cf->prec = ctx->precision;
+        cf->lanes = n_lanes;
+        cf->pending = true;
     }
 
     // ---- the batch is part of the group
@@ -837,8 +835,10 @@ void rd_rpipe_destroy(rd_ctx* ctx)
     if (p->s_dec) (void)hipStreamSynchronize(p->s_dec);
     rd_masked_stream_release(p->s_part);   // (CU-masked streams are pooled, never destroyed: forward.hip)
     if (p->ev_switch) (void)hipEventDestroy(p->ev_switch);
-    for (auto& e : p->calib.f_ev)
-        if (e) (void)hipEventDestroy(e);
+    for (auto& f : p->calib.f) {
+        if (f.e0) (void)hipEventDestroy(f.e0);
+        if (f.e1) (void)hipEventDestroy(f.e1);
+    }
     for (auto& d : p->calib.d) {
         if (d.e0) (void)hipEventDestroy(d.e0);
         if (d.e1) (void)hipEventDestroy(d.e1);
