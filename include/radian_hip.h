@@ -278,8 +278,10 @@ int rd_pipe_progress(rd_ctx* ctx, int64_t wait_for, int64_t* delivered);
  * beam search of this group's longest read will take (a read's search is one serial chain; radian/basecall.py:99-109 runs it
  * inline, here it runs under the next reads' forwards).  Both sides of that rule are measured by the context itself with HIP
  * events -- ns per forward row (per matrix-product mode) and us per time step of a group's longest chain (per beam width,
- * arithmetic, LM, with / without the decode partition) -- starting from built-in figures for the exact-fp32 mode.  Read-out for
- * tools and tests: 0 = not measured yet; *rows_per_step = the rule in force (forward rows per time step of the longest read). */
+ * arithmetic, LM, and per occupancy of the decode partition: on_partition = 1..3 waves per SIMD, 0 = the whole chip, where the
+ * built-in figure stays in force, scaled by the measured forward pace) -- starting from built-in figures for the exact-fp32
+ * mode.  Read-out for tools and tests: 0 = not measured yet; *rows_per_step = the rule in force (forward rows per time step
+ * of the longest read). */
 int rd_pipe_policy_read(rd_ctx* ctx, int beam_width, int on_partition, int use_lm, double* ns_per_row, double* us_per_step,
                         int64_t* rows_per_step);
 /* Batches submitted to the reads-level pipeline so far: right after a submit, the number rd_pipe_progress must reach for

@@ -464,9 +464,10 @@ class Backend:
 
     def pipe_policy(self, beam_width, on_partition, use_lm=False):
         """what the context has measured for its global-mode group policy (rd_pipe_policy_read): ns per forward row, us per time
-        step of a group's longest chain (0.0: not measured yet) and the rule in force, forward rows per chain step"""
+        step of a group's longest chain (0.0: not measured yet) and the rule in force, forward rows per chain step.  on_partition:
+        1..3 = waves per SIMD of the decode partition, 0 = the whole chip"""
         ns, us, rows = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
-        self._check(self._L.rd_pipe_policy_read(self._h, int(beam_width), 1 if on_partition else 0, 1 if use_lm else 0, ctypes.byref(ns),
+        self._check(self._L.rd_pipe_policy_read(self._h, int(beam_width), int(on_partition), 1 if use_lm else 0, ctypes.byref(ns),
                                                 ctypes.byref(us), ctypes.byref(rows)))
         return {"ns_per_row": ns.value, "us_per_step": us.value, "rows_per_step": rows.value}
 

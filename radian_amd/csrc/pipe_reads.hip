@@ -65,14 +65,14 @@ inline int64_t chain_rows_default(int W, bool on_partition)
 // ends of every group's beam search (elapsed / longest chain).  Until a figure exists the constant stands in, scaled by the measured
 // forward rate when that is known.
 struct Calib {
-    static constexpr int NF = 16, ND = 4;
+    static constexpr int NF = 16, WIN = 6, ND = 4;
     struct Fwd {
         hipEvent_t e0 = nullptr, e1 = nullptr;   // both ends of a submit's lane work
         int64_t rows = 0;
-        int prec = 0, lanes = 1;
-        bool pending = false;
+        int prec = 0;
     } f[NF];
-    int64_t f_next = 0;
+    int64_t f_next = 0;        // submits recorded so far (sample i lives in f[i % NF])
+    int64_t f_seen = 0;        // samples before this index have been used or dropped
     double ns_row[3] = {0.0, 0.0, 0.0};   // per matrix-product mode, all lanes together; 0: not measured yet
     struct Dec {
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -83,7 +83,8 @@ struct Calib {
     int64_t d_next = 0;
     std::vector<std::pair<uint32_t, double>> us_step;   // (key, us per time step of the longest chain), few entries
 
-    static uint32_t key_of(int W, bool on_part, int math, int prec, int lm) { return (uint32_t)W | (on_part ? 1u << 8 : 0u) | (uint32_t)math << 9 | (uint32_t)prec << 10 | (uint32_t)lm << 12; }
+    // m = waves per SIMD of the decode partition that the measured group put there (1..3), 0 = the whole chip beside conv waves
+    static uint32_t key_of(int W, int m, int math, int prec, int lm) { return (uint32_t)W | (uint32_t)m << 8 | (uint32_t)math << 11 | (uint32_t)prec << 12 | (uint32_t)lm << 14; }
     double* find(uint32_t key)
     {
         for (auto& e : us_step)
@@ -92,29 +93,80 @@ struct Calib {
     }
 };
 
+// waves a group of n sequences puts on every SIMD of a decode partition of part_cus CUs per XCD (a sequence is half a wave at W <= 6,
+// one wave up to 12, two up to 25, four beyond)
+inline int part_waves_per_simd(int part_cus, int W, int64_t n_seq)
+{
+    const int64_t simds = (int64_t)RD_XCDS * part_cus * 4;
+    const int64_t waves = W <= 6 ? (n_seq + 1) / 2 : W <= 12 ? n_seq : W <= 25 ? 2 * n_seq : 4 * n_seq;
+    const int64_t m = (waves + simds - 1) / simds;
+    return (int)(m < 1 ? 1 : m);
+}
+
 // completed measurements -> estimates (never blocks: an event that has not fired yet is looked at again later)
 void calib_harvest(Calib& c)
 {
-    // Forward pace: a submit's lane work took (e0 -> e1) on ONE of `lanes` streams that share the chip, so all lanes together
-    // produce its rows in duration / lanes.  Deliberately not the time between the completions of consecutive submits: that
-    // includes every pause of the pipeline (the host waiting for a group slot because a beam search was not covered), reads slow,
-    // shrinks the rule, covers less -- a runaway seen on the reference-defaults job (80 ns per row "measured", groups a third of
-    // the constants', 13 M samples/s instead of 28 M).  A lane that runs while the others pause finishes sooner than its share,
-    // so under pauses this estimate errs towards a FASTER forward, i.e. towards larger groups, which removes the pauses.
-    for (auto& f : c.f) {
-        if (!f.pending || hipEventQuery(f.e1) != hipSuccess) {
-            (void)hipGetLastError();
+    // Forward pace = the time during which AT LEAST ONE lane was working on a forward, over the rows those forwards produced: the
+    // union of the (e0, e1) intervals of WIN consecutive submits.  Not the time between the completions of consecutive submits --
+    // that contains every pause of the pipeline (the host waiting for a group slot because a beam search was not covered), reads
+    // slow, shrinks the rule, covers less: a runaway seen on the reference-defaults job (80 ns per row "measured", 13 M samples/s
+    // instead of 28 M) -- and not a lane's own duration over the lane count either, which reads 20-25 % fast whenever the lanes
+    // overlap only partly (configs[4] leg: 27 ns "measured" against 36).
+    while (c.f_next - c.f_seen >= Calib::WIN) {
+        if (c.f_next - c.f_seen >= Calib::NF) {         // (older than the ring: overwritten, or about to be by the submit in progress)
+            c.f_seen = c.f_next - Calib::NF + 1;
             continue;
         }
-        float ms = 0.f;
-        if (f.rows > 0 && hipEventElapsedTime(&ms, f.e0, f.e1) == hipSuccess && ms > 0.f) {
-            const double ns = (double)ms * 1e6 / ((double)f.rows * (double)f.lanes);
-            double& e = c.ns_row[f.prec];
-            e = e == 0.0 ? ns : 0.75 * e + 0.25 * ns;
+        const int64_t j0 = c.f_seen;
+        if (hipEventQuery(c.f[(j0 + Calib::WIN - 1) % Calib::NF].e1) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        double a[Calib::WIN], b[Calib::WIN];
+        int64_t rows = 0;
+        bool ok = true;
+        const Calib::Fwd& ref = c.f[j0 % Calib::NF];
+        for (int k = 0; k < Calib::WIN && ok; k++) {
+            const Calib::Fwd& f = c.f[(j0 + k) % Calib::NF];
+            float ms0 = 0.f, ms1 = 0.f;
+            ok = f.prec == ref.prec && f.rows > 0 && hipEventElapsedTime(&ms0, ref.e0, f.e0) == hipSuccess &&
+                 hipEventElapsedTime(&ms1, ref.e0, f.e1) == hipSuccess && ms1 > ms0;
+            a[k] = ms0;
+            b[k] = ms1;
+            rows += f.rows;
+        }
+        if (ok) {
+            // busy time between the END of the window's first forward and the end of its last, for the rows of all but the first:
+            // (counted from the first one's START the window would hold its ramp -- with two lanes, seven slots for six forwards)
+            const double t0 = b[0];
+            rows -= ref.rows;
+            for (int k = 1; k < Calib::WIN; k++) a[k] = a[k] < t0 ? t0 : a[k];
+            for (int i = 2; i < Calib::WIN; i++)          // by start time (a handful of intervals)
+                for (int k = i; k > 1 && a[k] < a[k - 1]; k--) {
+                    std::swap(a[k], a[k - 1]);
+                    std::swap(b[k], b[k - 1]);
+                }
+            double busy = 0.0, lo = a[1], hi = b[1] > a[1] ? b[1] : a[1];
+            for (int k = 2; k < Calib::WIN; k++) {
+                if (b[k] <= a[k]) continue;               // (ended before the first one did: nothing inside the window)
+                if (a[k] > hi) {
+                    busy += hi - lo;
+                    lo = a[k];
+                    hi = b[k];
+                } else if (b[k] > hi) {
+                    hi = b[k];
+                }
+            }
+            busy += hi - lo;
+            if (rows > 0 && busy > 0.0) {
+                const double ns = busy * 1e6 / (double)rows;
+                double& e = c.ns_row[ref.prec];
+                e = e == 0.0 ? ns : 0.6 * e + 0.4 * ns;
+            }
         } else {
             (void)hipGetLastError();
         }
-        f.pending = false;
+        c.f_seen += Calib::WIN / 2;      // (windows overlap by half)
     }
     for (auto& d : c.d) {
         if (!d.pending || hipEventQuery(d.e1) != hipSuccess) {
@@ -133,26 +185,33 @@ void calib_harvest(Calib& c)
     }
 }
 
-// forward rows a group must hold per time step of its longest read before it closes
-int64_t chain_rows(const rd_ctx* ctx, Calib& c, int W, bool on_partition, int use_lm)
+// Forward rows a group must hold per time step of its longest read before it closes.  m = waves per SIMD that the group's sequences
+// put on the decode partition (part_waves_per_simd), 0 = the group decodes on the whole chip beside conv waves.
+//  * On the partition the rule is measured: (us per step of a chain at THIS occupancy m) / (ns per forward row) + 5 %.  The pace
+//    is keyed by m because it depends on it (W = 25: 3.3 us at one wave per SIMD, 4.9 at three): a rule fed with "elapsed / longest"
+//    of whatever group ran last feeds back on itself -- larger groups, slower chains, larger groups -- until the partition's
+//    sequence limit flips the group onto the whole chip (configs[4] leg 26.3 -> 21-24 M samples/s; profiles/r04_policy_ab.txt).
+//    Until a pace has been measured at an occupancy, the round-3 constant stands in as a pace (96 rows x 34 ns = 3.3 us, ...).
+//  * Beside conv waves a group's search time is its total work over the chip's rate -- proportional to the group's own size --
+//    so there is no pace to measure (following elapsed / longest ran away to the row cap: reference-defaults job 27.9 -> 13.4 M);
+//    the constant for the beam width is scaled by the measured forward pace.
+int64_t chain_rows(const rd_ctx* ctx, Calib& c, int W, int m, int use_lm)
 {
+    const bool on_partition = m > 0;
     const int64_t def = chain_rows_default(W, on_partition);
 #ifdef RD_EXPERIMENTS
     static const bool no_calib = getenv("RD_NO_CALIB") != nullptr;   // A/B against the constants (tools only)
     if (no_calib) return def;
 #endif
     const double ns = c.ns_row[ctx->precision];
-    const double* us = c.find(Calib::key_of(W, on_partition, ctx->decode_math, ctx->precision, use_lm));
     if (ns <= 0.0) return def;
-    const double scaled = (double)def * kDefaultNsPerRow / ns;   // the constant, for the forward this context really runs
-    double rows = scaled;
-    // The measured chain pace is used on the decode partition only: there every sequence of the group has a wave slot of its own and
-    // elapsed / longest chain IS the pace of a chain.  Beside conv waves (no partition, thousands of sequences) a group's search time
-    // is its total work over the chip's rate -- proportional to the group's size -- so elapsed / longest grows with the group, the rule
-    // with it, the next group with the rule: a runaway to the row cap (seen on the reference-defaults job of 16 384 ragged reads:
-    // 13.4 M samples/s instead of 27.9 M).  There the rule is the constant for the beam width, scaled by the measured forward rate.
-    if (us && on_partition) rows = *us * 1e3 / ns * 1.3;          // measured chain pace over measured forward pace, + 30 %
-    const double lo = (double)def / 3.0, hi = (double)def * 6.0;
+    double rows = (double)def * kDefaultNsPerRow / ns;   // the constant, for the forward this context really runs
+    if (on_partition) {
+        const int mm = m > 3 ? 3 : m;
+        const double* us = c.find(Calib::key_of(W, mm, ctx->decode_math, ctx->precision, use_lm));
+        if (us) rows = *us * 1e3 / ns * 1.05;
+    }
+    const double lo = (double)def / 3.0, hi = (double)def * 8.0;
     rows = rows < lo ? lo : rows > hi ? hi : rows;
     return (int64_t)rows;
 }
@@ -389,7 +448,7 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
             cd = &d;
             p->calib.d_next++;
             d.longest = s.longest;
-            d.key = Calib::key_of(s.W, on_part, ctx->decode_math, ctx->precision, s.use_lm);
+            d.key = Calib::key_of(s.W, on_part ? std::min(3, part_waves_per_simd(s.part, s.W, (int64_t)n)) : 0, ctx->decode_math, ctx->precision, s.use_lm);
             RD_HIP(hipEventRecord(d.e0, ds));
         }
     }
@@ -625,7 +684,7 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
         int64_t longest_b = 0;
         for (int r = 0; r < n_reads; r++) longest_b = std::max<int64_t>(longest_b, read_off[r + 1] - read_off[r]);
         calib_harvest(p->calib);
-        expect_rows = std::min<int64_t>(kGroupRowsCap, chain_rows(ctx, p->calib, W, part != 0, use_lm) * longest_b + 2 * P.total_rows);
+        expect_rows = std::min<int64_t>(kGroupRowsCap, chain_rows(ctx, p->calib, W, part ? 2 : 0, use_lm) * longest_b + 2 * P.total_rows);
     }
     if ((rc = open_slot(ctx, p, mode, W, f16, use_lm, s_thr, r_thr, part, P.total_rows, expect_rows, &s))) return rc;
 
@@ -708,13 +767,10 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
 
     // ---- the lane's work, in stream order: copies out of the staging block, normalise, forward, assembly
     Calib::Fwd* cf = nullptr;
-    {
-        Calib::Fwd& f = p->calib.f[p->calib.f_next % Calib::NF];
-        if (!f.pending) {
-            cf = &f;
-            p->calib.f_next++;
-            RD_HIP(hipEventRecord(f.e0, L->st));
-        }
+    if (mode == 1) {   // (the policy exists for global-mode groups; chunk-mode groups close by a batch count)
+        calib_harvest(p->calib);
+        cf = &p->calib.f[p->calib.f_next % Calib::NF];
+        RD_HIP(hipEventRecord(cf->e0, L->st));
     }
     const float* sig = d_signal;
     if (raw) {
@@ -743,12 +799,11 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
     if (raw)
         RD_HIP(hipMemcpyAsync((char*)s->status.p + (size_t)s->n_reads * 4, (char*)R.raw.p + d_st, (size_t)n_reads * 4, hipMemcpyDeviceToDevice, L->st));
     RD_HIP(hipEventRecord(L->done, L->st));   // the decode stream waits for this before it reads the group
-    if (cf) {   // the policy's forward-rate measurement: the end of this submit's lane work
+    if (cf) {   // the policy's forward-pace measurement: the end of this submit's lane work
         RD_HIP(hipEventRecord(cf->e1, L->st));
         cf->rows = P.total_rows;
         cf->prec = ctx->precision;
-        cf->lanes = n_lanes;
-        cf->pending = true;
+        p->calib.f_next++;
     }
 
     // ---- the batch is part of the group
@@ -766,7 +821,12 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
     if (mode == 1) {
         // global mode: by coverage of the longest read's chain (see chain_rows), not by a batch count
         const bool few = part && (int)s->seqs.size() <= part_seq_limit(part, W);
-        close = s->rows >= chain_rows(ctx, p->calib, W, few, use_lm) * s->longest || s->rows >= kGroupRowsCap;
+        const int m = few ? part_waves_per_simd(part, W, (int64_t)s->seqs.size()) : 0;
+        close = s->rows >= chain_rows(ctx, p->calib, W, m, use_lm) * s->longest || s->rows >= kGroupRowsCap;
+        // A group of partition-lane batches closes when another batch of this size would take it past what the partition decodes
+        // at chain pace, covered or not: past that point the group would decode on the whole chip beside the next group's conv
+        // waves -- a different regime that needs 5-6x the rows (configs[4] leg: 26.3 M samples/s closing here, 20.6 M flipping).
+        if (few && (int)s->seqs.size() + n_reads > part_seq_limit(part, W)) close = true;
         // (the very first group of a context closes with its first batch: nothing is decoding yet, and its chains start one
         // group's forward time earlier -- a quarter of a second on a job of long reads)
         close = close || p->launches == 0;
@@ -786,15 +846,16 @@ extern "C" int rd_pipe_policy_read(rd_ctx* ctx, int beam_width, int on_partition
 {
     RD_REQUIRE(ctx && ns_per_row && us_per_step && rows_per_step, "rd_pipe_policy_read: null argument");
     RD_REQUIRE(beam_width >= 1 && beam_width <= rd_decode_max_width(), "beam_width %d out of range", beam_width);
+    RD_REQUIRE(on_partition >= 0 && on_partition <= 3, "rd_pipe_policy_read: on_partition %d (0 = whole chip, 1..3 = waves per SIMD of the decode partition)", on_partition);
     RD_HIP(hipSetDevice(ctx->device));
     ReadsPipe* p = nullptr;
     int rc = rpipe_get(ctx, &p);
     if (rc) return rc;
     calib_harvest(p->calib);
     *ns_per_row = p->calib.ns_row[ctx->precision];
-    const double* us = p->calib.find(Calib::key_of(beam_width, on_partition != 0, ctx->decode_math, ctx->precision, use_lm != 0));
+    const double* us = p->calib.find(Calib::key_of(beam_width, on_partition, ctx->decode_math, ctx->precision, use_lm != 0));
     *us_per_step = us ? *us : 0.0;
-    *rows_per_step = chain_rows(ctx, p->calib, beam_width, on_partition != 0, use_lm != 0);
+    *rows_per_step = chain_rows(ctx, p->calib, beam_width, on_partition, use_lm != 0);
     return RD_OK;
 }
 

@@ -46,6 +46,7 @@ def main():
             be.pipe_flush(); be.sync()
         run(8)
         t0 = time.perf_counter(); run(64); dt = time.perf_counter() - t0
-        print(f"group {group:2d}: {64 * n * L / dt / 1e6:6.2f} M samples/s  ({dt / 64 * 1e3:.2f} ms per {n}-read step, {dt / 64 / (n * L) * 1e9:.2f} ns per row)", flush=True)
+        print(f"group {group:2d}: {64 * n * L / dt / 1e6:6.2f} M samples/s  ({dt / 64 * 1e3:.2f} ms per {n}-read step, {dt / 64 / (n * L) * 1e9:.2f} ns per row)"
+              f"   policy: {[(m, round(q['ns_per_row'], 1), round(q['us_per_step'], 2), q['rows_per_step']) for m in (1, 2, 3, 0) for q in [be.pipe_policy(W, m, True)]]}", flush=True)
     be.close()
 main()

@@ -41,7 +41,7 @@ for prec in ("fp32", "bf16x3", "f16x3"):
         t0 = time.perf_counter()
         run(steps)
         dt = time.perf_counter() - t0
-        pol = " | ".join(f"{'part' if op else 'chip'}: {q['us_per_step']:.2f} us/step -> {q['rows_per_step']} rows/step" for op in (1, 0) for q in [be.pipe_policy(W, op, True)])
+        pol = " | ".join(f"{'part m=%d' % op if op else 'chip'}: {q['us_per_step']:.2f} us/step -> {q['rows_per_step']} rows/step" for op in (1, 2, 3, 0) for q in [be.pipe_policy(W, op, True)])
         print(f"{tag:10s} W={W} {math} {prec:7s} {n:5d} reads x {L:6d}: {steps * n * L / dt / 1e6:6.2f} M samples/s ({dt / steps * 1e3:.2f} ms per step)"
               f"   [{be.pipe_policy(W, 1, True)['ns_per_row']:.1f} ns/row | {pol}]", flush=True)
         for d in bufs:

@@ -12,7 +12,7 @@ _close = _bk.Backend.close
 def _close_and_tell(self):
     if self._h is not None:
         try:
-            print("policy at close:", {("part" if op else "chip"): self.pipe_policy(6, op, True) for op in (1, 0)}, flush=True)
+            print("policy at close:", {op: self.pipe_policy(6, op, True) for op in (1, 2, 3, 0)}, flush=True)
         except Exception as e:
             print("policy read failed:", e)
     _close(self)
