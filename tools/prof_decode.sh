@@ -17,6 +17,8 @@ for LIBTAG in $ARMS; do
   if [ $LIBTAG = new ] || [ -n "${OLD_HAS_GLIBC:-}" ]; then CFGS+=("512 10 0 glibc" "512 10 1 glibc" "4096 10 0 glibc" "512 25 1 glibc"); fi
   # round 3: the reference's default width as one and as two sequences per wave (this round's library only)
   if [ $LIBTAG = new ] && [ -n "${W6:-}" ]; then CFGS=("4096 6 0 glibc one" "4096 6 0 glibc two" "4096 6 1 glibc one" "4096 6 1 glibc two" "512 6 1 glibc one" "512 6 1 glibc two"); fi
+  # round 4: the metric's width as one and as two sequences per wave (two candidates per lane of a half-wave)
+  if [ $LIBTAG = new ] && [ -n "${W10:-}" ]; then CFGS=("4096 10 0 glibc one" "4096 10 0 glibc two" "4096 10 1 glibc one" "4096 10 1 glibc two" "4096 10 0 fast one" "4096 10 0 fast two"); fi
   for CFG in "${CFGS[@]}"; do
     NAME=${LIBTAG}_$(echo $CFG | tr ' ' '_')
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$NAME -- python3 tools/decode_prof_run.py $CFG > $OUT/trace_$NAME.log 2>&1
