@@ -598,6 +598,25 @@ def main():
                 be.set_precision("fp32")
             sec[key] = {"precision": desc, "value": world * args.steps * samples_per_step / el2, "unit": "samples/s",
                         "ms_per_step": el2 / args.steps * 1e3, "accuracy": acc}
+    if world == 1 and args.precision == "fp32" and not args.no_secondary and not args.windowed:
+        # BASELINE configs[1] "forward only": the headline's batches through the signal model alone (rd_forward_reads_resident: the
+        # streamed evaluation, no beam search), on the same rotating forward lanes.  Beside the headline it splits the step into its
+        # forward and what the beam search adds (co-running hides none of the search's SIMD time).
+        note("secondary_forward_only")
+        try:
+            k = [0]
+
+            def fwd(i):
+                be.forward_reads_resident(batches[i % n_batches][3], read_off, reads_per_batch, CHUNK, STEP, "chunk", lane=k[0] % args.lanes)
+                k[0] += 1
+            el_f = timed(fwd)
+            sec["secondary_forward_only"] = {
+                "value": world * args.steps * samples_per_step / el_f, "unit": "samples/s", "ms_per_step": el_f / args.steps * 1e3,
+                "config": "BASELINE configs[1]: the signal model's forward alone on the headline's batches (64 reads x 4096, chunk 1024 / "
+                          f"step 512, every time step once + the window heads), {args.lanes} forward lanes, no beam search",
+                "beam_search_adds_ms_per_step": elapsed / args.steps * 1e3 - el_f / args.steps * 1e3}
+        except Exception as e:
+            print(f"[bench] secondary_forward_only failed: {e}", file=sys.stderr)
     if secondaries:
         norms = [np.stack([synthetic.mad_normalise(r, 4) for r in synthetic.synthetic_reads(reads_per_batch, READ_LEN, seed=1000 * rank + b)]).astype(np.float32)
                  for b in range(n_batches)]

@@ -187,7 +187,9 @@ void calib_harvest(Calib& c)
 
 // Forward rows a group must hold per time step of its longest read before it closes.  m = waves per SIMD that the group's sequences
 // put on the decode partition (part_waves_per_simd), 0 = the group decodes on the whole chip beside conv waves.
-//  * On the partition the rule is measured: (us per step of a chain at THIS occupancy m) / (ns per forward row) + 5 %.  The pace
+//  * On the partition the rule is measured: (us per step of a chain at THIS occupancy m) / (ns per forward row) + 20 % (with + 5 % a
+//    64-read step of saturated rows closed a group of its own, 8.6 ms of search under 9.2 ms of forward, and every jitter stalled the
+//    lanes: secondary_global_lm 28.3 -> 26.2 M samples/s; with + 30 % the soft-head leg took a third step per group: 28.2 -> 26.4 M).  The pace
 //    is keyed by m because it depends on it (W = 25: 3.3 us at one wave per SIMD, 4.9 at three): a rule fed with "elapsed / longest"
 //    of whatever group ran last feeds back on itself -- larger groups, slower chains, larger groups -- until the partition's
 //    sequence limit flips the group onto the whole chip (configs[4] leg 26.3 -> 21-24 M samples/s; profiles/r04_policy_ab.txt).
@@ -209,7 +211,7 @@ int64_t chain_rows(const rd_ctx* ctx, Calib& c, int W, int m, int use_lm)
     if (on_partition) {
         const int mm = m > 3 ? 3 : m;
         const double* us = c.find(Calib::key_of(W, mm, ctx->decode_math, ctx->precision, use_lm));
-        if (us) rows = *us * 1e3 / ns * 1.05;
+        if (us) rows = *us * 1e3 / ns * 1.2;
     }
     const double lo = (double)def / 3.0, hi = (double)def * 8.0;
     rows = rows < lo ? lo : rows > hi ? hi : rows;
