@@ -221,6 +221,13 @@ int rd_forward_resident(rd_ctx* ctx, const float* d_windows, int n_windows, int 
  * workspace; *total_rows (nullable) = their number.  rd_sync waits for every lane. */
 int rd_forward_reads_resident(rd_ctx* ctx, const float* d_signal, const int64_t* read_off, int n_reads, int chunk_len,
                               int step, int decode_type, int lane, int64_t* total_rows);
+/* The same forward with the reference's shapes: `signal` holds the normalised reads back to back (host), probs_out receives
+ * [*n_windows][chunk_len][5] float32 -- what `sig_model.predict(windows)` returns for get_windows() of every read in turn
+ * (radian/basecall.py:83-93), window rows the pad trim at basecall.py:96 drops are zero.  Every time step is evaluated once
+ * (plus each later window's first 252 rows, which see that window's own zero padding) and the rows are gathered into
+ * windows on the device: bit-identical to rd_forward on the same windows.  Blocking. */
+int rd_forward_reads(rd_ctx* ctx, const float* signal, const int64_t* read_off, int n_reads, int chunk_len, int step,
+                     float* probs_out, int64_t windows_cap, int64_t* n_windows);
 int rd_basecall_chunk_resident(rd_ctx* ctx, const float* d_windows, int n_windows, int chunk_len,
                                const int32_t* valid_len, int beam_width, uint8_t* labels_out, int32_t* label_len);
 int rd_decode_resident(rd_ctx* ctx, const float* d_probs, int n_windows, int chunk_len, const int32_t* valid_len,

@@ -63,6 +63,7 @@ SIGNATURES = {
     "rd_memcpy_d2h": (c_i, [c_vp, c_vp, c_vp, c_sz]),
     "rd_forward_resident": (c_i, [c_vp, c_vp, c_i, c_i, c_vp]),
     "rd_forward_reads_resident": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "rd_forward_reads": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_i64, c_vp]),
     "rd_basecall_chunk_resident": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_i, c_vp, c_vp]),
     "rd_decode_resident": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_i, c_vp, c_vp]),
     "rd_pipe_config": (c_i, [c_vp, c_i]),

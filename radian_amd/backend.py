@@ -206,6 +206,25 @@ class Backend:
         out = out[: n_rows.value]
         return out if is64.value else out.astype(np.float32)
 
+    def forward_reads(self, signals, chunk_len, step):
+        """sig_model.predict over the windows of whole normalised reads (radian/basecall.py:83-93) through the streamed
+        evaluation (rd_forward_reads): -> per read an array [nW, chunk_len, 5] float32 (rows the pad trim drops are zero)"""
+        sigs = [np.ascontiguousarray(s_, dtype=np.float32) for s_ in signals]
+        off = np.zeros(len(sigs) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([s_.shape[0] for s_ in sigs])
+        nws = [self.count_windows(int(s_.shape[0]), chunk_len, step) for s_ in sigs]
+        tot = int(sum(nws))
+        flat = np.concatenate(sigs) if sigs else np.zeros(0, dtype=np.float32)
+        out = np.zeros((tot, chunk_len, 5), dtype=np.float32)
+        n = ctypes.c_int64(0)
+        self._check(self._L.rd_forward_reads(self._h, _p(flat), _p(off), len(sigs), int(chunk_len), int(step), _p(out), tot, ctypes.byref(n)))
+        assert n.value == tot
+        res, w = [], 0
+        for k in nws:
+            res.append(out[w:w + k])
+            w += k
+        return res
+
     def decode_batch(self, mats, seq_off, seq_len, beam_width, use_lm=False, s_threshold=0.0, r_threshold=0.0,
                      with_scores=False):
         """beam_search over a batch of sequences given as concatenated rows (radian/decode.py:100-212).

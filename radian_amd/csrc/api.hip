@@ -1378,6 +1378,42 @@ extern "C" int rd_forward_reads_resident(rd_ctx* ctx, const float* d_signal, con
     return rd_forward_tiles_dev(ctx, d_signal, *tl, P->total_rows, ctx->ws_probs.p, lane, ctx->logits_f16);
 }
 
+// sig_model.predict for the windows of whole reads (basecall.py:83-93) through the streamed evaluation: host signal in, window-shaped
+// probabilities out -- bit-identical to rd_forward on the same reads' windows for the rows basecall.py:96 keeps.
+extern "C" int rd_forward_reads(rd_ctx* ctx, const float* signal, const int64_t* read_off, int n_reads, int chunk_len, int step,
+                                float* probs_out, int64_t windows_cap, int64_t* n_windows)
+{
+    int rc = check_reads_args(ctx, signal, read_off, n_reads, chunk_len, step, 1);
+    if (rc) return rc;
+    RD_REQUIRE(probs_out && n_windows, "rd_forward_reads: null output");
+    RD_REQUIRE(!ctx->logits_f16, "rd_forward_reads: float32 rows only (rd_set_logits 0)");
+    RD_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)read_off[n_reads];
+    if (ctx->ws_in.reserve(n * 4 + 16)) return RD_ERR_NOMEM;
+    RD_HIP(hipMemcpyAsync(ctx->ws_in.p, signal, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    const ReadsPlan* P = nullptr;
+    const TileLists* tl = nullptr;
+    if ((rc = get_plan(ctx, read_off, n_reads, chunk_len, step, 0, &P, &tl, nullptr))) return rc;
+    *n_windows = P->n_windows;
+    RD_REQUIRE(P->n_windows <= windows_cap, "rd_forward_reads: %d windows, room for %lld", P->n_windows, (long long)windows_cap);
+    if (ctx->ws_probs.reserve((size_t)P->total_rows * 20)) return RD_ERR_NOMEM;
+    if ((rc = rd_forward_tiles_dev(ctx, ctx->ws_in.as<float>(), *tl, P->total_rows, ctx->ws_probs.p, 0, 0))) return rc;
+    const size_t nw = (size_t)P->n_windows, a8 = align_up(nw * 8, 256), a4 = align_up(nw * 4, 256);
+    const size_t out_bytes = nw * chunk_len * 20;
+    if (ctx->ws_misc.reserve(2 * a8 + 2 * a4) || ctx->ws_mat.reserve(out_bytes + 16)) return RD_ERR_NOMEM;
+    char* dm = (char*)ctx->ws_misc.p;
+    RD_HIP(hipMemcpyAsync(dm, P->off1.data(), nw * 8, hipMemcpyHostToDevice, ctx->stream));
+    RD_HIP(hipMemcpyAsync(dm + a8, P->off2.data(), nw * 8, hipMemcpyHostToDevice, ctx->stream));
+    RD_HIP(hipMemcpyAsync(dm + 2 * a8, P->split.data(), nw * 4, hipMemcpyHostToDevice, ctx->stream));
+    RD_HIP(hipMemcpyAsync(dm + 2 * a8 + a4, P->valid.data(), nw * 4, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = rd_gather_windows_dev(ctx->stream, ctx->ws_probs.as<float>(), (const int64_t*)dm, (const int64_t*)(dm + a8), (const int32_t*)(dm + 2 * a8),
+                                    (const int32_t*)(dm + 2 * a8 + a4), P->n_windows, chunk_len, (float*)ctx->ws_mat.p)))
+        return rc;
+    RD_HIP(hipMemcpyAsync(probs_out, ctx->ws_mat.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    return RD_OK;
+}
+
 extern "C" int rd_basecall_reads_chunk(rd_ctx* ctx, const float* signal, const int64_t* read_off, int n_reads, int chunk_len,
                                        int step, int beam_width, uint8_t* labels_out, int32_t* label_len)
 {

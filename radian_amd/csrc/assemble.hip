@@ -92,6 +92,37 @@ int rd_assemble_batch_dev(hipStream_t st, const void* d_probs, const AsmRead* d_
     return RD_OK;
 }
 
+// windows of a read out of the streamed evaluation's rows: window w, time step t < valid[w] comes from row off1[w] + t (its head) for
+// t < split[w] and from row off2[w] + t (the read's stream) beyond; rows t >= valid[w] are zero
+__global__ __launch_bounds__(256) void gather_windows_kernel(const float* __restrict__ rows, const int64_t* __restrict__ off1, const int64_t* __restrict__ off2,
+                                                             const int32_t* __restrict__ split, const int32_t* __restrict__ valid, int T, float* __restrict__ out)
+{
+    const int w = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    float* o = out + ((size_t)w * T + t) * 5;
+    if (t >= valid[w]) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) o[c] = 0.f;
+        return;
+    }
+    const float* r = rows + ((t < split[w] ? off1[w] : off2[w]) + t) * 5;
+#pragma unroll
+    for (int c = 0; c < 5; c++) o[c] = r[c];
+}
+
+int rd_gather_windows_dev(hipStream_t st, const float* d_rows, const int64_t* d_off1, const int64_t* d_off2, const int32_t* d_split,
+                          const int32_t* d_valid, int n_windows, int T, float* d_out)
+{
+    for (int w0 = 0; w0 < n_windows; w0 += 65535) {
+        const int nw = n_windows - w0 < 65535 ? n_windows - w0 : 65535;
+        hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)nw), dim3(256), 0, st, d_rows, d_off1 + w0, d_off2 + w0,
+                           d_split + w0, d_valid + w0, T, d_out + (size_t)w0 * T * 5);
+        RD_HIP(hipGetLastError());
+    }
+    return RD_OK;
+}
+
 int rd_assemble_dev(rd_ctx* ctx, const void* d_probs, int nW, int T, int pad, int step, double* d_out, int64_t N, int streamed, int in_f16)
 {
     if (N <= 0) return RD_OK;

@@ -208,6 +208,8 @@ struct AsmRead {
 };
 int rd_assemble_batch_dev(hipStream_t st, const void* d_probs, const AsmRead* d_reads, int n_reads, int64_t max_n, int T, int step,
                           double* d_out, int streamed, int in_f16);
+int rd_gather_windows_dev(hipStream_t st, const float* d_rows, const int64_t* d_off1, const int64_t* d_off2, const int32_t* d_split,
+                          const int32_t* d_valid, int n_windows, int T, float* d_out);
 int rd_assemble_dev(rd_ctx* ctx, const void* d_probs, int nW, int T, int pad, int step, double* d_out, int64_t N,
                     int streamed = 0 /* 1: d_probs is the streamed forward [N][5]; row t is taken from row t */,
                     int in_f16 = 0 /* 1: d_probs rows are _Float16 */);

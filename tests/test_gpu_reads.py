@@ -231,3 +231,28 @@ def test_clone_artifacts_gives_an_identical_context():
         if src is not None:
             src.close()
         dst.close()
+
+
+@pytest.mark.parametrize("chunk,step", [(1024, 512), (1024, 128), (1024, 1024), (1024, 772), (1024, 773), (300, 100), (128, 64)])
+def test_forward_reads_equals_predict_on_windows_bitwise(be, oracle, chunk, step):
+    """rd_forward_reads (round 4; BASELINE configs[1] "forward only"): sig_model.predict over get_windows() of whole reads
+    (basecall.py:83-93) through the streamed evaluation and a gather into window shape -- bit-identical to rd_forward on the
+    windows themselves for every row the pad trim (basecall.py:96) keeps, zero beyond; and within 1e-4 of the oracle."""
+    rng = np.random.default_rng(chunk + 13 * step)
+    lens = [3000, chunk, chunk - 1, chunk + 1, 1, chunk + step, 5 * step + 7, 2500]
+    sigs = _reads(rng, lens)
+    got = be.forward_reads(sigs, chunk, step)
+    assert len(got) == len(sigs)
+    for sig, g in zip(sigs, got):
+        w, valid, pad = _windows(sig, chunk, step)
+        ref = be.forward(w)
+        assert g.shape == ref.shape
+        for i in range(w.shape[0]):
+            assert np.array_equal(g[i, : valid[i]], ref[i, : valid[i]]), (len(sig), i)
+            assert not g[i, valid[i]:].any()
+    # the oracle on the first read's windows (forward parity: |dp| <= 1e-4, the tolerance north_star states)
+    from radian_amd import weights
+    w, valid, _ = _windows(sigs[0], chunk, step)
+    o = oracle.tcn_forward(weights.synthetic_weights(seed=1234), w)
+    for i in range(w.shape[0]):
+        assert float(np.abs(got[0][i, : valid[i]] - o[i, : valid[i]]).max(initial=0.0)) <= 1e-4
