@@ -60,7 +60,8 @@ int rd_sync(rd_ctx* ctx);             /* wait for the context's stream */
 int rd_set_precision(rd_ctx* ctx, int mode);
 /* Workgroup shape of the fp32 matrix-product kernels (no effect on results; for measurements): 0 (default) = 128 time steps x 256
  * channels per 256-thread workgroup, two workgroups per CU; 1 = 256 x 256 per 512-thread workgroup, one per CU (the weight
- * tile is shared by twice the rows: a third less LDS-DMA volume per FLOP, no second workgroup to run under an epilogue). */
+ * tile is shared by twice the rows: a third less LDS-DMA volume per FLOP, no second workgroup to run under an epilogue).
+ * Applies to the exact-fp32 mode only: the split-f16 kernels exist in shape 0, the bf16x3 kernels in shape 1 (rd_set_precision). */
 int rd_set_conv_shape(rd_ctx* ctx, int shape);
 /* Diagnostic of mode 2: split n fp32 values on the device exactly as the kernels do; terms_out[t * n + i] is the bf16 bit
  * pattern of term t (0 hi, 1 mid, 2 lo) of values[i]. */

@@ -1436,6 +1436,10 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
     Model& m = ctx->model;
     const bool split = ctx->precision == 1;
     const bool bf3 = ctx->precision == 2;
+    // the 512-thread kernels (bf16x3; fp32 under rd_set_conv_shape 1) own TWO 128-row tiles per workgroup and are launched over n / 2:
+    // every tile list is padded to eight sub-tiles (plan_pad_tiles, rd_uniform_tiles) -- checked here, not assumed
+    if (kind != 0 && (bf3 || (!split && ctx->conv_shape == 1)))
+        RD_REQUIRE(n % 2 == 0, "internal: %d tiles in a layer of 256-row workgroups (lists are padded to pairs)", n);
     int rc;
     ZeroRows zr = {};
     if (kind == 0) {
