@@ -514,3 +514,75 @@ def test_driver_raises_reference_keyerror_at_the_read_that_reaches_a_missing_con
         # (reads that do not reach the context decode exactly as with the dense model: the absent row is never read for them)
         assert seen == full[: bad[0]]
     capsys.readouterr()
+
+
+def test_read_ahead_preserves_order_bounds_memory_and_propagates_errors():
+    """basecall._read_ahead (round 4): the reader thread hands reads over in order, never runs more than max_reads / max_samples
+    ahead of the consumer, re-raises the producer's exception at the position where it happened, and stops (closing the source
+    generator on its own thread) when the consumer leaves early."""
+    import threading
+    import time
+    from radian_amd import basecall
+
+    class R:
+        def __init__(self, i, n, boom=False):
+            self.read_id, self.n, self.boom = f"r{i}", n, boom
+
+        def get_raw_data(self):
+            if self.boom:
+                raise OSError("disk on fire")
+            return np.full(self.n, 7, dtype=np.int16)
+
+    state = {"made": 0, "closed_on": None}
+
+    def source(n, boom_at=None):
+        try:
+            for i in range(n):
+                state["made"] = i + 1
+                yield i, R(i, 10 + i % 5, boom=(i == boom_at))
+        finally:
+            state["closed_on"] = threading.current_thread().name
+
+    got = list(basecall._read_ahead(source(1000), max_reads=64, max_samples=1 << 20, block=16))
+    assert [k for k, _, _ in got] == list(range(1000)) and [rid for _, rid, _ in got] == [f"r{i}" for i in range(1000)]
+    assert all(raw.shape[0] == 10 + i % 5 for i, (_, _, raw) in enumerate(got))
+    assert state["closed_on"] == "radian-read-ahead"
+    # bounded run-ahead: a slow consumer never finds the producer more than max_reads (+ one block in the making) ahead
+    state["made"] = 0
+    it = basecall._read_ahead(source(2000), max_reads=64, max_samples=1 << 20, block=16)
+    for n_taken, _ in enumerate(it, 1):
+        if n_taken % 100 == 0:
+            time.sleep(0.02)
+            assert state["made"] - n_taken <= 64 + 16 + 16, (state["made"], n_taken)
+        if n_taken == 900:
+            break
+    it.close()                                   # the consumer leaves early: the producer stops and closes its generator
+    assert state["closed_on"] == "radian-read-ahead" and state["made"] < 2000
+    # the producer's error arrives after the reads before it
+    seen = []
+    with pytest.raises(OSError, match="disk on fire"):
+        for k, _, _ in basecall._read_ahead(source(300, boom_at=137), block=16):
+            seen.append(k)
+    assert seen == list(range(137 - 137 % 16))   # (whole blocks before the failing one; the failing block is not delivered)
+
+
+def test_artifact_cache_roundtrip_for_multi_gpu_ranks(tmp_path):
+    """basecall.save_artifacts / load_artifacts(cache_dir): what the multi-GPU launcher parsed once is what the broadcasting rank
+    loads -- weights, dilations, a SPARSE RNA table (rows of NaN survive), the hashed-context order."""
+    from radian_amd import basecall, weights
+    w = weights.synthetic_weights(seed=4, dilations=(1, 2, 4))
+    table = np.random.default_rng(2).dirichlet([0.5] * 4, size=64)
+    table[[3, 40]] = np.nan
+    for art in ({"dilations": (1, 2, 4), "weights": w, "lm_table": table, "lm_k": 3},
+                {"dilations": (1, 2, 4), "weights": w, "lm_table": None, "lm_k": 0},
+                {"dilations": (1, 2, 4), "weights": w, "lm_table": table, "lm_k": 40, "lm_hashed_order": 3}):
+        d = tmp_path / f"c{art['lm_k']}"
+        d.mkdir()
+        basecall.save_artifacts(art, str(d))
+        got = basecall.load_artifacts(None, cache_dir=str(d))
+        assert got["dilations"] == (1, 2, 4) and np.array_equal(got["weights"], w) and got["lm_k"] == art["lm_k"]
+        assert got.get("lm_hashed_order") == art.get("lm_hashed_order")
+        if art["lm_table"] is None:
+            assert got["lm_table"] is None
+        else:
+            assert np.array_equal(got["lm_table"], table, equal_nan=True) and np.isnan(got["lm_table"][3]).all()
