@@ -24,16 +24,24 @@ def main():
     ring = [(np.zeros(n * L + 1, np.uint8), np.zeros(n, np.int32)) for _ in range(40)]
     parts = [int(a[4:]) for a in sys.argv[1:] if a.startswith("part")] or [0, 4, 8]
     chunk = "chunk" in sys.argv      # the headline's loop instead: chunk-mode W = 10 (or "w1"), beam search on the whole chip beside the forwards
+    fwdonly = "fwdonly" in sys.argv  # round 4: the forward alone on two lanes (rd_forward_reads_resident), no beam search anywhere
+    if fwdonly:
+        parts = [-1]
     if chunk:
         parts = [-1]
         Wc = 1 if "w1" in sys.argv else 10
         be.pipe_config(8); be.pipe_set_lanes(2)
         outs = [(np.zeros((n * 8, 1024), dtype=np.uint8), np.full(n * 8, -1, dtype=np.int32)) for _ in range(16)]
     for part in parts:
-        if not chunk:
+        if not chunk and not fwdonly:
             be.pipe_flush(); be.set_decode_partition(part); be.pipe_config(3)
 
         def run(k):
+            if fwdonly:
+                for i in range(k):
+                    be.forward_reads_resident(bufs[i % 4], off, n, 1024, 512, "chunk", lane=i % 2)
+                be.sync()
+                return
             if chunk:
                 th, tmin = 0.0, []
                 for i in range(k):
