@@ -219,7 +219,9 @@ int rd_forward_resident(rd_ctx* ctx, const float* d_windows, int n_windows, int 
  * reads resident in HBM: the streamed evaluation of rd_basecall_reads_chunk (decode_type 0: one row per time step + the
  * rows of every window's zero-padded head) or rd_basecall_reads_global (1) without the decode, asynchronous on forward
  * lane `lane` (0..3; lanes are independent streams with their own activations).  Rows go to the context's probability
- * workspace; *total_rows (nullable) = their number.  rd_sync waits for every lane. */
+ * workspace -- ONE workspace per context: calls on several lanes overwrite each other's rows (the entry point exists for the
+ * forward's timing, BASELINE configs[1]; rd_forward_reads returns rows); *total_rows (nullable) = their number.  rd_sync
+ * waits for every lane. */
 int rd_forward_reads_resident(rd_ctx* ctx, const float* d_signal, const int64_t* read_off, int n_reads, int chunk_len,
                               int step, int decode_type, int lane, int64_t* total_rows);
 /* The same forward with the reference's shapes: `signal` holds the normalised reads back to back (host), probs_out receives
