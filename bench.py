@@ -327,6 +327,8 @@ def main():
                     help="untimed cross-checks on batch 0: streamed labels == windowed labels == the oracle's; probabilities within 1e-4 of the oracle's")
     ap.add_argument("--decode-group", type=int, default=8, help="batches per beam-search launch in the two-stream pipeline")
     ap.add_argument("--lanes", type=int, default=2, help="forward streams the pipelined batches rotate over (1..4)")
+    ap.add_argument("--conv-fuse", type=int, default=1, choices=[0, 1],
+                    help="block 0's first conv inside its second conv's kernel (1, default) or as a kernel of its own (rd_set_conv_fuse; same bits): A/B runs")
     ap.add_argument("--decode-form", default="auto", choices=["auto", "one", "two", "waves", "lanes"],
                     help="launch shape of the beam search (rd_set_decode_form; no effect on results): A/B runs")
     ap.add_argument("--conv-shape", type=int, default=0, choices=[0, 1],
@@ -387,6 +389,7 @@ def main():
     be.set_decode_math(args.decode_math)
     be.set_conv_shape(args.conv_shape)
     be.set_decode_form(args.decode_form)
+    be.set_conv_fuse(args.conv_fuse)
 
     # ---- synthetic input, resident in HBM: 4 distinct batches of 64 reads per rank, cycled
     reads_per_batch = BATCH_WINDOWS // 8

@@ -63,6 +63,10 @@ int rd_set_precision(rd_ctx* ctx, int mode);
  * tile is shared by twice the rows: a third less LDS-DMA volume per FLOP, no second workgroup to run under an epilogue).
  * Applies to the exact-fp32 mode only: the split-f16 kernels exist in shape 0, the bf16x3 kernels in shape 1 (rd_set_precision). */
 int rd_set_conv_shape(rd_ctx* ctx, int shape);
+/* Block 0's first conv (one input channel: three multiply-adds and a ReLU per output; model.py:71, keras-tcn conv1D_0 of
+ * residual_block_0) computed inside the kernel of the block's second conv instead of by a kernel of its own (no effect on
+ * results: bit-identical; exact-fp32 mode, dilation <= 2): 1 (default) / 0.  For measurements and the identity test. */
+int rd_set_conv_fuse(rd_ctx* ctx, int on);
 /* Diagnostic of mode 2: split n fp32 values on the device exactly as the kernels do; terms_out[t * n + i] is the bf16 bit
  * pattern of term t (0 hi, 1 mid, 2 lo) of values[i]. */
 int rd_split3(rd_ctx* ctx, const float* values, size_t n, uint16_t* terms_out);

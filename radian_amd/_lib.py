@@ -26,6 +26,7 @@ SIGNATURES = {
     "rd_destroy": (c_i, [c_vp]),
     "rd_sync": (c_i, [c_vp]),
     "rd_set_precision": (c_i, [c_vp, c_i]),
+    "rd_set_conv_fuse": (c_i, [c_vp, c_i]),
     "rd_set_conv_shape": (c_i, [c_vp, c_i]),
     "rd_split3": (c_i, [c_vp, c_vp, c_sz, c_vp]),
     "rd_load_weights": (c_i, [c_vp, c_vp, c_sz]),

@@ -167,6 +167,10 @@ class Backend:
         """'f32' (default) or 'f16': storage of the softmax rows on the reads-level paths (rd_set_logits)."""
         self._check(self._L.rd_set_logits(self._h, {"f32": 0, "f16": 1}[mode] if isinstance(mode, str) else int(mode)))
 
+    def set_conv_fuse(self, on):
+        """block 0's first conv inside its second conv's kernel (default) or as a kernel of its own (rd_set_conv_fuse); same bits"""
+        self._check(self._L.rd_set_conv_fuse(self._h, 1 if on else 0))
+
     def set_decode_form(self, form):
         """'auto' (default); 'waves' / 'lanes': launch shape for widths above 12; 'two' / 'one': widths up to 12 always / never as
         two sequences per wave (rd_set_decode_form)."""

@@ -582,6 +582,14 @@ extern "C" int rd_set_conv_shape(rd_ctx* ctx, int shape)
     return RD_OK;
 }
 
+extern "C" int rd_set_conv_fuse(rd_ctx* ctx, int on)
+{
+    RD_REQUIRE(ctx, "rd_set_conv_fuse: null context");
+    RD_REQUIRE(on == 0 || on == 1, "rd_set_conv_fuse: %d (1 = block 0's first conv inside its second, 0 = its own kernel)", on);
+    ctx->conv_fuse = on;
+    return RD_OK;
+}
+
 extern "C" int rd_set_decode_partition(rd_ctx* ctx, int cus_per_xcd)
 {
     RD_REQUIRE(ctx, "rd_set_decode_partition: null context");

@@ -144,6 +144,7 @@ struct rd_ctx {
     int precision = 0;   // 0: exact fp32 MFMA (default); 1: split-f16 (f16x3); 2: three-term bf16 split (bf16x3) matrix products
     int decode_form = 0; // rd_set_decode_form
     int decode_math = 1; // rd_set_decode_math (default: glibc's operation sequence -- scores bit-identical to the reference's)
+    int conv_fuse = 1;   // rd_set_conv_fuse: 1 = block 0's first conv is computed inside its second (forward.hip, FIN), 0 = its own kernel
     int conv_shape = 0;  // rd_set_conv_shape: 0 = 128-row tiles, two 256-thread workgroups per CU; 1 = 256-row tiles, one 512-thread workgroup
     int logits_f16 = 0;  // 1: the reads-level paths keep the softmax rows as f16 in HBM (10 B per time step), the decoder widens them
     hipStream_t stream = nullptr;

@@ -45,6 +45,22 @@ constexpr int BK = 16;        // K-chunk depth (64-B LDS rows)
 
 enum { EPI_RELU = 0, EPI_RES_IDENT = 1, EPI_RES_MATCH = 2, EPI_HEAD = 3 };
 
+// The zero rows of a forward's three activation tensors (the source of the causal left padding, one row behind the batch's last).
+// The first kernel of a forward clears them with its workgroup 0 -- nothing reads them before the second kernel, nothing ever
+// writes them, and their place moves with the batch's row count.  (They were three hipMemsetAsync launches in front of every
+// forward: on a lane of the two-lane pipeline every launch boundary costs 0.1-0.35 ms before the next kernel's first
+// workgroup runs -- profiles/r03h_conv_slots.txt -- so three empty launches were ~0.6 ms of lane time per step.)
+struct ZeroRows {
+    uint4* row[3];
+    int n16;   // 16-byte pieces per row
+};
+__device__ __forceinline__ void clear_zero_rows(const ZeroRows& z)
+{
+    if (blockIdx.x != 0) return;
+    for (int r = 0; r < 3; r++)
+        for (int i = threadIdx.x; i < z.n16; i += blockDim.x) z.row[r][i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 struct ConvArgs {
     const float* in;      // [nW][T][256]
     float* out;           // [nW][T][256]     (EPI_HEAD: unused)
@@ -62,7 +78,19 @@ struct ConvArgs {
     float* sink;          // 1024 floats nobody reads: target of the stores past a segment's end
     const TileDesc* tiles; // one per workgroup
     int dil;
+    // FIN variant (block 0's second conv with the first conv folded in): the first conv's parameters and the zero rows to clear
+    const float* w_in;    // [3][256]
+    const float* b_in;    // [256]
+    ZeroRows zr;
 };
+
+// block 0, first conv, one output: relu(b + w0 x[t - 2d] + w1 x[t - d] + w2 x[t]) as ONE fma chain in this order -- written out so that
+// tcn_in_kernel and the conv kernel that computes these values on the fly (FIN) produce the same bits
+__device__ __forceinline__ float conv_in_value(float b, float w0, float w1, float w2, float x0, float x1, float x2)
+{
+    const float v = __builtin_fmaf(x2, w2, __builtin_fmaf(x1, w1, __builtin_fmaf(x0, w0, b)));
+    return v > 0.f ? v : 0.f;
+}
 
 // LDS image of a K-chunk tile: [row][16 floats] (64-B rows, no padding -- LDS-DMA writes 1 KiB per wave-instruction
 // contiguously), with the four 16-B slots of each row XOR-swizzled by (row >> 2) & 3: the 16 lanes of a ds_read_b128
@@ -99,10 +127,12 @@ __device__ __forceinline__ void glds16_uncounted_saddr(unsigned lane_off, const 
 }
 // All but the newest LEAVE LDS-DMA instructions of this wave have landed (loads return in order); then the workgroup
 // barrier: everyone's pieces of that chunk are in LDS and every wave is past its reads of the stage overwritten next.
-template <int LEAVE>
+template <int LEAVE, bool LGKM = false>
 __device__ __forceinline__ void wait_dma_and_barrier()
 {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LEAVE) : "memory");
+    // LGKM: this wave's LDS stores (the FIN variant writes A tiles with ds_write) have completed too
+    if constexpr (LGKM) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LEAVE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LEAVE) : "memory");
 }
 
 // Diagnostic build only (-DRD_CLOCK_STAMPS, tools/conv_clock.py): every conv workgroup stamps the shader clock and the 100-MHz
@@ -176,21 +206,35 @@ __device__ __forceinline__ void gstore16(void* sbase, unsigned byte_off, float4 
 // 4 -> a 512-thread, 256-row tile, one workgroup per CU: the B (weight) tile is shared by twice the rows, so a CU moves
 // (256 + 256) x 64 B = 32 KiB per chunk by LDS-DMA instead of 2 x (128 + 256) x 64 B = 48 KiB for the same FLOPs
 // (measured, DESIGN.md 4.1: rd_set_conv_shape / tools/conv_shape.py).
-template <int NT, int TAPS, int EPI, int WM = 2>
+//
+// FIN (round 4): block 0's second conv with the block's FIRST conv folded in.  That conv has one input channel -- three fmas and a
+// ReLU per output -- so instead of a kernel that writes its 1 KiB per time step to HBM (tcn_in_kernel) and a DMA that reads it back
+// three times, the A tiles are computed in LDS from the raw samples: per 16-channel slice one region of 4 x (32 + 2 dil) rows (each
+// 32-row sub-tile with the 2 dil rows in front of it that the three taps reach back to), written by ds_write_b128 in the chunk
+// layout (same 16-B slot swizzle) while the previous slice is being multiplied; the three taps of a slice read it at row offsets
+// 0, dil, 2 dil.  Only the weight tiles travel by LDS-DMA.  Values are tcn_in_kernel's bit for bit (conv_in_value), so the layer's
+// output is too (tests/test_gpu_forward.py::test_first_conv_fused_is_bit_identical).
+constexpr int FIN_DMAX = 2;               // dilations of block 0 the FIN variant is built for (sig2seq.yaml: 1)
+template <int NT, int TAPS, int EPI, int WM = 2, bool FIN = false>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(ConvArgs a)
 {
+    static_assert(!FIN || (EPI == EPI_RES_MATCH && WM == 2 && TAPS == 3 && NT == 4), "FIN: block 0's second conv, product shape");
     constexpr int BM = 64 * WM;           // time steps per workgroup tile (shadows the file-scope 128)
     constexpr int NWAVE = 2 * WM;
     constexpr int BN = 2 * NT * 32;       // output channels per workgroup (2 waves along N)
     constexpr int NCHUNK = TAPS * (RD_C / BK);
-    constexpr int STAGE_FLOATS = (BM + BN) * BK;   // one K-chunk of A and B
+    constexpr int A_FLOATS = FIN ? 0 : BM * BK;    // FIN: no A part in the DMA stages
+    constexpr int STAGE_FLOATS = A_FLOATS + BN * BK;   // one K-chunk of A and B
     constexpr int HEAD_FLOATS = BM * (RD_H + 1) + RD_H * 5 + 8;
     constexpr int NSTAGE = 3;
-    constexpr int SMEM_FLOATS = (EPI == EPI_HEAD && HEAD_FLOATS > NSTAGE * STAGE_FLOATS) ? HEAD_FLOATS : NSTAGE * STAGE_FLOATS;
+    constexpr int MIDROWS = 4 * (32 + 2 * FIN_DMAX);                      // rows of a slice's A region
+    constexpr int FIN_FLOATS = FIN ? 2 * MIDROWS * BK + 4 * RD_C : 0;     // two regions + the first conv's [w0 | w1 | w2 | b] x 256
+    constexpr int SMEM_FLOATS = (EPI == EPI_HEAD && HEAD_FLOATS > NSTAGE * STAGE_FLOATS) ? HEAD_FLOATS : NSTAGE * STAGE_FLOATS + FIN_FLOATS;
 
-    __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];  // 3 x 24 KiB (conv, WM = 2) / 3 x 32 KiB (WM = 4) / 67 KiB (head)
+    __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];  // 3 x 24 KiB (conv, WM = 2) / 3 x 32 KiB (WM = 4) / 67 KiB (head) / 70 KiB (FIN)
 
     RD_STAMP_BEGIN()
+    if constexpr (FIN) clear_zero_rows(a.zr);   // (this kernel is then the forward's first)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -230,19 +274,21 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
     // one piece (wave-instruction) of a chunk's staging: pieces 0,1 = this wave's two 16-row pieces of A, 2.. = its
     // BN/64 consecutive 1-KiB pieces of B.  `tap` is the chunk's tap (a literal at every call site).
     constexpr int PB = BN / (16 * NWAVE);   // 1-KiB pieces (16 rows) of B per wave
-    constexpr int NPIECE = 2 + PB;
+    constexpr int NA = FIN ? 0 : 2;         // A pieces per wave (FIN: the A tiles are computed, not loaded)
+    constexpr int NPIECE = NA + PB;
     auto stage_piece = [&](int chunk, int tap, float* st, int pc) {
         // chunk order: input-channel slice outer, tap inner -> the three shifted reads of the same rows are adjacent in time
-        if (pc < 2) {
+        if (pc < NA) {
             const int cc = chunk / TAPS;
             const char* src = lanebase + (size_t)cc * (BK * 4) + (uint64_t)(unsigned)arow[tap][pc] * (RD_C * 4);
             glds16_uncounted((const float*)src, st + (wave * 2 + pc) * 256);   // 1 KiB piece = tile rows 16*piece .. 16*piece+15
         } else {
             const float* wb = a.wpk + (size_t)chunk * BN * BK + wave * PB * 256;   // pre-swizzled on the host: linear copy
-            float* dst = st + BM * BK + wave * PB * 256;
-            if (pc == 2) glds16_uncounted_saddr<0>(lane_off, wb, dst);
-            else if (pc == 3) glds16_uncounted_saddr<1024>(lane_off, wb, dst);
-            else if (pc == 4) glds16_uncounted_saddr<2048>(lane_off, wb, dst);
+            float* dst = st + A_FLOATS + wave * PB * 256;
+            const int pb = pc - NA;
+            if (pb == 0) glds16_uncounted_saddr<0>(lane_off, wb, dst);
+            else if (pb == 1) glds16_uncounted_saddr<1024>(lane_off, wb, dst);
+            else if (pb == 2) glds16_uncounted_saddr<2048>(lane_off, wb, dst);
             else glds16_uncounted_saddr<3072>(lane_off, wb, dst);
         }
     };
@@ -250,6 +296,53 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
 #pragma unroll
         for (int pc = 0; pc < NPIECE; pc++) stage_piece(chunk, tap, st, pc);
     };
+
+    // ---- FIN: the A tiles computed from the raw samples.  Wave w computes sub-tile w's region rows i = 0 .. 31 + 2 dil (time step
+    //      d_t0 - 2 dil + i) in three passes of 16 rows; a lane owns row dma_r of a pass and the four channels dma_ps * 4 .. + 3 of the slice.
+    float* const midb = smem + NSTAGE * STAGE_FLOATS;          // [2][MIDROWS][16]
+    float* const wins = midb + 2 * MIDROWS * BK;               // [4][256]: w0 | w1 | w2 | bias of the first conv
+    const int RS = 32 + 2 * a.dil;                             // region rows per sub-tile
+    float xs[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};   // per pass: x[t - 2 dil], x[t - dil], x[t] (0 before the segment)
+    bool rowv[3] = {false, false, false};                      // the row exists as conv input (else it is a zero row: causal padding / past the end)
+    if constexpr (FIN) {
+        *(float4*)(wins + tid * 4) = tid < 192 ? *(const float4*)(a.w_in + tid * 4) : *(const float4*)(a.b_in + (tid - 192) * 4);
+        const float* __restrict__ xw = a.x + sst.src_row;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const int i = dma_r + 16 * p;
+            const int t = d_t0 - 2 * a.dil + i;
+            rowv[p] = i < RS && t >= 0 && t < d_len;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int u = t - (2 - j) * a.dil;
+                xs[p][j] = (rowv[p] && u >= 0) ? xw[u] : 0.f;
+            }
+        }
+        __syncthreads();
+    }
+    auto fin_pass = [&](int cc, int p) {        // pass p of slice cc into region cc & 1
+        const int i = dma_r + 16 * p;
+        if (i < RS) {
+            const int c0 = cc * BK + dma_ps * 4;
+            const float4 w0 = *(const float4*)(wins + c0), w1 = *(const float4*)(wins + RD_C + c0), w2 = *(const float4*)(wins + 2 * RD_C + c0),
+                         bb = *(const float4*)(wins + 3 * RD_C + c0);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rowv[p]) {
+                v.x = conv_in_value(bb.x, w0.x, w1.x, w2.x, xs[p][0], xs[p][1], xs[p][2]);
+                v.y = conv_in_value(bb.y, w0.y, w1.y, w2.y, xs[p][0], xs[p][1], xs[p][2]);
+                v.z = conv_in_value(bb.z, w0.z, w1.z, w2.z, xs[p][0], xs[p][1], xs[p][2]);
+                v.w = conv_in_value(bb.w, w0.w, w1.w, w2.w, xs[p][0], xs[p][1], xs[p][2]);
+            }
+            const int rho = wave * RS + i;
+            *(float4*)(midb + (cc & 1) * (MIDROWS * BK) + rho * BK + ((dma_ps ^ ((rho >> 2) & 3)) * 4)) = v;
+        }
+    };
+    if constexpr (FIN) {
+        // slice 0's region now, BEFORE the first weight DMA goes out: the sample loads above are the compiler's own loads, and its wait
+        // for them would also wait for every hand-counted DMA issued in between (visible behind the first chunk's barrier)
+#pragma unroll
+        for (int p = 0; p < 3; p++) fin_pass(0, p);
+    }
 
     const int fr = lane & 31;
     const int fh = lane >> 5;
@@ -270,14 +363,27 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
 #pragma unroll
     for (int g = 0; g < BK / 8; g++) koff[g] = ((2 * g + fh) ^ swz) * 4;
     const int a_off = (wm * 64 + fr) * BK;
-    const int b_off = BM * BK + (wn * NT * 32 + fr) * BK;
+    const int b_off = A_FLOATS + (wn * NT * 32 + fr) * BK;
 
     // One chunk: multiply the landed stage while the chunk after next is issued into the stage that was read last.  The
     // DMA pieces go out one by one between groups of 2 x NT MFMAs, so their address arithmetic issues in the shadow of
     // the matrix pipe instead of in front of it; the second k-group's fragments are requested after the first group of
     // MFMAs (their LDS latency sits under the other 3 groups).  sched_barrier pins that order.
     const bool work = mval[0] || mval[1];   // (tiles are packed, so a wave with work almost always has both sub-tiles)
-    auto chunk_step = [&](const float* st, int next, int next_tap, float* nst) {
+    // FIN: this lane's fragment rows in a slice region, per tap and sub-tile: region row = (sub-tile) * RS + fr + tap * dil
+    int frow[3][2] = {{0, 0}, {0, 0}, {0, 0}}, fswz[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    if constexpr (FIN) {
+#pragma unroll
+        for (int tap = 0; tap < 3; tap++)
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const int rho = (wm * 2 + m) * RS + fr + tap * a.dil;
+                frow[tap][m] = rho * BK;
+                fswz[tap][m] = (rho >> 2) & 3;
+            }
+    }
+    // (cur = this chunk's index, cur_tap = its tap: literals at every call site)
+    auto chunk_step = [&](const float* st, int cur, int cur_tap, int next, int next_tap, float* nst) {
         // MFMA order: k-group g, then N tile n, then (kr, m): 8 MFMAs per (g, n) step on two accumulators.  A step needs
         // the A fragments of its k-group (8 registers) and ONE B fragment (4): the next step's B fragment and, during the
         // last step of a group, the next group's A fragments are requested before the step's MFMAs, so 24 fragment
@@ -285,11 +391,15 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
         // wave (96) beside two of these on a SIMD.
         const float* Ab = st + a_off;
         const float* Bb = st + b_off;
+        const float* Mb = midb + ((cur / TAPS) & 1) * (MIDROWS * BK);     // FIN: the region of this chunk's slice
         constexpr int NSTEP = (BK / 8) * NT;
         float4 af[2][2], bq[2];
         auto rdA = [&](int g) {
 #pragma unroll
-            for (int m = 0; m < 2; m++) af[g & 1][m] = *(const float4*)(Ab + m * 32 * BK + koff[g]);
+            for (int m = 0; m < 2; m++) {
+                if constexpr (FIN) af[g & 1][m] = *(const float4*)(Mb + frow[cur_tap][m] + (((2 * g + fh) ^ fswz[cur_tap][m]) * 4));
+                else af[g & 1][m] = *(const float4*)(Ab + m * 32 * BK + koff[g]);
+            }
         };
         auto rdB = [&](int sidx) { bq[sidx & 1] = *(const float4*)(Bb + (sidx % NT) * 32 * BK + koff[sidx / NT]); };
         const bool st_ok = next < NCHUNK;
@@ -319,6 +429,11 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
             }
             __builtin_amdgcn_sched_barrier(0);
             if (st_ok && sidx < NPIECE) stage_piece(next, next_tap, nst, sidx);
+            if constexpr (FIN) {
+                // pass cur_tap of the NEXT slice's region, behind the weight pieces: its ~20 vector instructions issue in the shadow
+                // of the matrix pipe like the DMA's address arithmetic (the region it writes was last read two slices ago)
+                if (sidx == NPIECE && cur / TAPS + 1 < RD_C / BK) fin_pass(cur / TAPS + 1, cur_tap);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -334,14 +449,14 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
     static_assert(TAPS == 3 || TAPS == 1, "tap of a chunk is a literal in the unrolled loop");
     stage(0, 0, st0);
     stage(1, T3 ? 1 : 0, st1);
-    auto step = [&](int c, const float* st, int tap2, float* nst) {
-        if (c + 1 < NCHUNK) wait_dma_and_barrier<NPIECE>(); else wait_dma_and_barrier<0>();
-        chunk_step(st, c + 2, tap2, nst);
+    auto step = [&](int c, int tap, const float* st, int tap2, float* nst) {
+        if (c + 1 < NCHUNK) wait_dma_and_barrier<NPIECE, FIN>(); else wait_dma_and_barrier<0, FIN>();
+        chunk_step(st, c, tap, c + 2, tap2, nst);
     };
     for (int chunk = 0; chunk < NCHUNK; chunk += 3) {
-        step(chunk, st0, T3 ? 2 : 0, st2);
-        if (chunk + 1 < NCHUNK) step(chunk + 1, st1, 0, st0);
-        if (chunk + 2 < NCHUNK) step(chunk + 2, st2, T3 ? 1 : 0, st1);
+        step(chunk, 0, st0, T3 ? 2 : 0, st2);
+        if (chunk + 1 < NCHUNK) step(chunk + 1, T3 ? 1 : 0, st1, 0, st0);
+        if (chunk + 2 < NCHUNK) step(chunk + 2, T3 ? 2 : 0, st2, T3 ? 1 : 0, st1);
     }
     __syncthreads();   // every wave is done with the staging LDS: the epilogues reuse it
 
@@ -520,22 +635,6 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
     RD_STAMP_END()
 }
 
-// The zero rows of a forward's three activation tensors (the source of the causal left padding, one row behind the batch's last).
-// The first kernel of a forward clears them with its workgroup 0 -- nothing reads them before the second kernel, nothing ever
-// writes them, and their place moves with the batch's row count.  (They were three hipMemsetAsync launches in front of every
-// forward: on a lane of the two-lane pipeline every launch boundary costs 0.1-0.35 ms before the next kernel's first
-// workgroup runs -- profiles/r03h_conv_slots.txt -- so three empty launches were ~0.6 ms of lane time per step.)
-struct ZeroRows {
-    uint4* row[3];
-    int n16;   // 16-byte pieces per row
-};
-__device__ __forceinline__ void clear_zero_rows(const ZeroRows& z)
-{
-    if (blockIdx.x != 0) return;
-    for (int r = 0; r < 3; r++)
-        for (int i = threadIdx.x; i < z.n16; i += blockDim.x) z.row[r][i] = make_uint4(0u, 0u, 0u, 0u);
-}
-
 // Block 0, first conv: C_in = 1 (VALU; memory-bound 1 KiB write per time step), fused bias + ReLU.
 // One workgroup per tile descriptor: 4 rows per pass (64 lanes x float4 = one 1 KiB row per wave).
 __global__ __launch_bounds__(256) void tcn_in_kernel(const float* __restrict__ x, const float* __restrict__ w /*[3][256]*/,
@@ -555,14 +654,10 @@ __global__ __launch_bounds__(256) void tcn_in_kernel(const float* __restrict__ x
         const float x1 = t - dil >= 0 ? xw[t - dil] : 0.f;
         const float x0 = t - 2 * dil >= 0 ? xw[t - 2 * dil] : 0.f;
         float4 v;
-        v.x = bb.x + x0 * w0.x + x1 * w1.x + x2 * w2.x;
-        v.y = bb.y + x0 * w0.y + x1 * w1.y + x2 * w2.y;
-        v.z = bb.z + x0 * w0.z + x1 * w1.z + x2 * w2.z;
-        v.w = bb.w + x0 * w0.w + x1 * w1.w + x2 * w2.w;
-        v.x = v.x > 0.f ? v.x : 0.f;
-        v.y = v.y > 0.f ? v.y : 0.f;
-        v.z = v.z > 0.f ? v.z : 0.f;
-        v.w = v.w > 0.f ? v.w : 0.f;
+        v.x = conv_in_value(bb.x, w0.x, w1.x, w2.x, x0, x1, x2);
+        v.y = conv_in_value(bb.y, w0.y, w1.y, w2.y, x0, x1, x2);
+        v.z = conv_in_value(bb.z, w0.z, w1.z, w2.z, x0, x1, x2);
+        v.w = conv_in_value(bb.w, w0.w, w1.w, w2.w, x0, x1, x2);
         *(float4*)(ow + (size_t)t * RD_C + c4) = v;
     }
 }
@@ -1429,6 +1524,14 @@ int timer_end(hipStream_t st, KernelTimer& tm, double flops, double bytes)
 // MID.
 namespace {
 
+// block 0's first conv folded into its second (tcn_gemm_kernel<..., FIN>): exact-fp32 mode, product workgroup shape, dilation within what
+// the variant's LDS regions hold; rd_set_conv_fuse(ctx, 0) turns it off (A/B runs, the bit-identity test)
+bool fuse_first_conv(const rd_ctx* ctx)
+{
+    return ctx->conv_fuse && ctx->precision == 0 && ctx->conv_shape == 0 && ctx->model.nblocks >= 1 && ctx->model.dil[0] >= 1 &&
+           ctx->model.dil[0] <= FIN_DMAX;
+}
+
 int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2 conv1, 3 head*/, const TileDesc* tiles, int n,
                 double rows, int zero_row, const float* d_signal, float* Xin, float* Xout, float* MID, float* d_probs, int probs_f16)
 {
@@ -1442,13 +1545,15 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
         RD_REQUIRE(n % 2 == 0, "internal: %d tiles in a layer of 256-row workgroups (lists are padded to pairs)", n);
     int rc;
     ZeroRows zr = {};
-    if (kind == 0) {
+    const bool fin = kind == 2 && b == 0 && fuse_first_conv(ctx);
+    if (kind == 0 || fin) {
         const size_t row_bytes = (size_t)RD_C * (bf3 ? 6 : 4);
         zr.n16 = (int)(row_bytes / 16);
         zr.row[0] = (uint4*)((char*)Xin + (size_t)zero_row * row_bytes);
         zr.row[1] = (uint4*)((char*)Xout + (size_t)zero_row * row_bytes);
         zr.row[2] = (uint4*)((char*)MID + (size_t)zero_row * row_bytes);
     }
+    if (kind == 0 && fuse_first_conv(ctx)) return RD_OK;   // (computed on the fly by block 0's second conv)
     if (bf3) {
         Bf3Args h = {};
         h.zero_row = zero_row;
@@ -1579,8 +1684,15 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
         else if (ctx->conv_shape == 1) hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RELU, 4>), dim3(n / 2), dim3(512), 0, st, a);
         else hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RELU>), dim3(n), dim3(256), 0, st, a);
     } else if (b == 0) {
+        if (fin) {
+            a.w_in = m.w_in;
+            a.b_in = m.b_in;
+            a.zr = zr;
+            a.in = nullptr;      // (the A tiles come from a.x)
+        }
         if (split) hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RES_MATCH>), dim3(n), dim3(256), 0, st, sa);
         else if (ctx->conv_shape == 1) hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_MATCH, 4>), dim3(n / 2), dim3(512), 0, st, a);
+        else if (fin) hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_MATCH, 2, true>), dim3(n), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_MATCH>), dim3(n), dim3(256), 0, st, a);
     } else {
         if (split) hipLaunchKernelGGL((tcn_gemm_split_kernel<4, 3, EPI_RES_IDENT>), dim3(n), dim3(256), 0, st, sa);

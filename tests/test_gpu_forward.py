@@ -386,3 +386,32 @@ def test_conv_workgroup_shapes_are_bit_identical():
         assert all(np.array_equal(a, b) for a, b in zip(res[0][2], res[1][2]))
     finally:
         be.close()
+
+
+def test_first_conv_fused_is_bit_identical(oracle):
+    """Round 4: block 0's first conv (one input channel) is computed inside the kernel of the block's second conv -- its A tiles are
+    built in LDS from the raw samples instead of being written to HBM by tcn_in_kernel and loaded back (tcn_gemm_kernel<..., FIN>).
+    Same fma chain per value, same MFMA sequence per output: probabilities equal bit for bit with the first conv as its own
+    kernel (rd_set_conv_fuse 0) -- uniform windows, whole ragged reads through the streamed forward with per-layer head tiles (reads
+    shorter than a tile, lengths around the 32-row sub-tile and 128-row tile edges), dilation 1 and 2 in block 0; a model whose block-0
+    dilation is beyond what the variant holds (4) takes the unfused kernels either way; and the fused path is within 1e-4 of the oracle."""
+    from radian_amd import Backend, synthetic, weights
+    be = Backend(0)
+    try:
+        for dil in ((1, 2, 4, 8, 16, 32), (2, 4, 1), (4, 1)):
+            w = weights.synthetic_weights(seed=11 + dil[0], dilations=dil)
+            be.load_weights(w, dil)
+            win = synthetic.reads_to_windows(synthetic.synthetic_reads(5, 3000, seed=4), 1024, 300)[0]
+            sigs = [np.clip(np.random.default_rng(n).normal(size=n), -4, 4).astype(np.float32)
+                    for n in (1, 2, 3, 31, 32, 33, 127, 128, 129, 700, 1024, 1500, 4097, 6000)]
+            res = []
+            for fuse in (0, 1):
+                be.set_conv_fuse(fuse)
+                res.append((be.forward(win), be.forward_reads(sigs, 1024, 512), be.forward_reads(sigs, 300, 77)))
+            assert np.array_equal(res[0][0], res[1][0]), dil
+            for k in (1, 2):
+                assert all(np.array_equal(a, b) for a, b in zip(res[0][k], res[1][k])), (dil, k)
+            ref = oracle.tcn_forward(w, win[:3], dilations=dil)
+            assert float(np.abs(res[1][0][:3] - ref).max()) <= 1e-4, dil
+    finally:
+        be.close()

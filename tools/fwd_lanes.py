@@ -22,6 +22,7 @@ bes, bufs = [], []
 for _ in range(nctx):
     be = Backend(0)
     be.load_weights(w)
+    be.set_conv_fuse(int(os.environ.get("RD_FUSE", "1")))
     d = be.dev_alloc(sig.nbytes)
     be.h2d(d, sig)
     bes.append(be)
@@ -52,7 +53,7 @@ for rep in range(3):
     [t.join() for t in ths]
     dt = time.time() - t0
     per = dt / (nctx * iters)
-    print(f"{mode} lanes={lanes} contexts={nctx} reads={n_reads}: {per * 1e3:.3f} ms per forward = {n_reads * N / per / 1e6:.2f} M samples/s "
+    print(f"fuse={os.environ.get('RD_FUSE', '1')} {mode} lanes={lanes} contexts={nctx} reads={n_reads}: {per * 1e3:.3f} ms per forward = {n_reads * N / per / 1e6:.2f} M samples/s "
           f"({rows} rows evaluated at the head layer)", flush=True)
 for be in bes:
     be.close()
