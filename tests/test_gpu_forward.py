@@ -393,12 +393,13 @@ def test_first_conv_fused_is_bit_identical(oracle):
     built in LDS from the raw samples instead of being written to HBM by tcn_in_kernel and loaded back (tcn_gemm_kernel<..., FIN>).
     Same fma chain per value, same MFMA sequence per output: probabilities equal bit for bit with the first conv as its own
     kernel (rd_set_conv_fuse 0) -- uniform windows, whole ragged reads through the streamed forward with per-layer head tiles (reads
-    shorter than a tile, lengths around the 32-row sub-tile and 128-row tile edges), dilation 1 and 2 in block 0; a model whose block-0
-    dilation is beyond what the variant holds (4) takes the unfused kernels either way; and the fused path is within 1e-4 of the oracle."""
+    shorter than a tile, lengths around the 32-row sub-tile and 128-row tile edges), dilations 1 and 2 in block 0; models whose
+    block-0 dilation is beyond what the variant's LDS regions hold (4, 8, 16) take the two kernels either way; and the fused path is within
+    1e-4 of the oracle."""
     from radian_amd import Backend, synthetic, weights
     be = Backend(0)
     try:
-        for dil in ((1, 2, 4, 8, 16, 32), (2, 4, 1), (4, 1)):
+        for dil in ((1, 2, 4, 8, 16, 32), (2, 4, 1), (4, 1), (8, 2), (16, 1)):
             w = weights.synthetic_weights(seed=11 + dil[0], dilations=dil)
             be.load_weights(w, dil)
             win = synthetic.reads_to_windows(synthetic.synthetic_reads(5, 3000, seed=4), 1024, 300)[0]
