@@ -173,7 +173,10 @@ __device__ __forceinline__ double log_m(double x)
     else return log(x);
 }
 template <bool GX>
-__device__ __forceinline__ double safe_log(double x) { return x == 0.0 ? -INFINITY : log_m<GX>(x); }
+// decode.py:16-17: log(0) = -inf.  A value that is no probability -- negative, NaN: the output of a model with non-finite weights, or a
+// caller's own matrix; +inf -- is treated as probability 0 too: math.log raises on the first and sorts NaN scores arbitrarily on the second; here
+// a NaN score would leave beam slots unclaimed in the ranking and the trie ids behind them undefined.  (Valid rows: the same bits.)
+__device__ __forceinline__ double safe_log(double x) { return (x > 0.0 && x <= 1.79769313486231570815e+308) ? log_m<GX>(x) : -INFINITY; }   // (+inf too: inf - inf later would be a NaN score)
 
 // One kept labeling, 64 B in LDS: a candidate lane fetches its parent with three 16-B reads.  (The 64-B stride makes the
 // 4-B / 8-B reads of one field of beams i and i + 2 / i + 4 share banks -- 27 % of the kernel's LDS cycles are conflict

@@ -177,3 +177,45 @@ def test_long_global_sequences_match_oracle(be, oracle):
         exp = oracle.beam_search_batch(mats, off, lens, W)
         for i in range(len(lens)):
             assert np.array_equal(got[i], exp[i]), (W, i)
+
+
+def softmax_rows(z):
+    z = z - z.max(axis=1, keepdims=True)
+    e = np.exp(z)
+    return e / e.sum(axis=1, keepdims=True)
+
+
+def test_rows_that_are_not_probabilities_do_not_derail_the_search(be, oracle):
+    """Robustness (round 4): NaN, negative and infinite entries in a probability matrix -- what a model with non-finite weights
+    produces, or a caller's own matrix -- count as probability 0 (+inf stays +inf) instead of poisoning the ranking with NaN scores:
+    every sequence finishes with a labeling of legal length, sequences made of valid rows in the same launch decode exactly as the
+    oracle, and the oracle -- which applies the same rule -- agrees on the damaged ones.  Every launch form, float32 and float64, LM on/off."""
+    rng = np.random.default_rng(31)
+    k = 2
+    table = rng.dirichlet([0.3] * 4, size=4 ** k)
+    for dtype in (np.float32, np.float64):
+        lens = [int(x) for x in rng.integers(1, 120, size=96)]
+        rows = np.concatenate([softmax_rows(rng.normal(size=(n, 5)) * 1.5) for n in lens]).astype(dtype)
+        off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        damaged = set(range(0, len(lens), 3))
+        for i in damaged:
+            seg = rows[off[i]: off[i] + lens[i]]
+            m = rng.random(seg.shape)
+            seg[m < 0.10] = np.nan
+            seg[(m >= 0.10) & (m < 0.15)] = -0.25
+            seg[(m >= 0.15) & (m < 0.17)] = np.inf
+            if i % 2 == 0:
+                seg[:] = np.nan                      # a whole sequence of NaN
+        for W in (1, 6, 10, 13, 25, 40):
+            for form in ("auto", "two", "one", "waves", "lanes"):
+                for lm in (False, True):
+                    be.set_decode_form(form)
+                    be.load_lm(table if lm else None, k if lm else 0)
+                    got = be.decode_batch(rows, off, lens, W, use_lm=lm, s_threshold=0.3, r_threshold=1.0)
+                    exp = oracle.beam_search_batch(rows, off, lens, W, table if lm else None, 0.3, 1.0, k if lm else 0)
+                    for i in range(len(lens)):
+                        assert got[i] is not None and 0 <= len(got[i]) <= lens[i] and (len(got[i]) == 0 or got[i].max() <= 3)
+                        if not (lm and i in damaged):     # (with an LM the gate's entropy / mixing arithmetic sees the raw NaNs: legal output is the claim there)
+                            assert np.array_equal(got[i], exp[i]), (dtype.__name__, W, form, lm, i, i in damaged)
+    be.set_decode_form("auto")
+    be.load_lm(None, 0)
