@@ -358,30 +358,28 @@ def main():
     comm = None
     rccl_nranks = 1
     per_rank_ms = None
+    json_fd = None
     if world > 1:
         from radian_amd import dist
-        # RCCL prints a version banner on the C-level stdout; stdout must carry the one JSON line only
+        # RCCL prints (version banner, warnings) on the C-level stdout; stdout must carry the one JSON line only: for the
+        # whole run file descriptor 1 points at stderr, and the line goes to the saved descriptor at the end.
+        os.environ.setdefault("NCCL_DEBUG", "WARN")    # a transport problem on a node this never ran on should say what it is
         sys.stdout.flush()
-        saved_fd1 = os.dup(1)
+        json_fd = os.dup(1)
         os.dup2(2, 1)
+        # the one collective of the job: rank 0 loads + repacks the weights, RCCL broadcasts the 8.8 MB device image
+        # over xGMI; the 128-byte RCCL id goes through a file keyed by the launcher's pid (no PyTorch in this process).
+        # All ranks agree on the transport before anyone uses it (dist.connect: RCCL on every rank, or the file
+        # transport on every rank -- never a mix, which would leave one side inside ncclBroadcast forever).
+        uid_file = dist.uid_path(directory=os.environ.get("RD_BENCH_RDV"))   # own launcher: its scratch; foreign: /tmp, by launcher pid
         try:
-            # the one collective of the job: rank 0 loads + repacks the weights, RCCL broadcasts the 8.8 MB device image
-            # over xGMI; the 128-byte RCCL id goes through a file keyed by the launcher's pid (no PyTorch in this process).
-            # All ranks agree on the transport before anyone uses it (dist.connect: RCCL on every rank, or the file
-            # transport on every rank -- never a mix, which would leave one side inside ncclBroadcast forever).
-            uid_file = dist.uid_path(directory=os.environ.get("RD_BENCH_RDV"))   # own launcher: its scratch; foreign: /tmp, by launcher pid
-            try:
-                comm, comm_kind = dist.connect(be, rank, world, uid_file)
-            except dist.StartupFailed as e:
-                print(f"[bench] rank {rank}: {e}", file=sys.stderr)
-                sys.stderr.flush()
-                os._exit(3)   # a helper thread is stuck inside ncclCommInitRank: no interpreter shutdown, the launcher stops the job
-            comm.bcast_artifacts(be, lambda b: b.load_weights(weights.synthetic_weights(seed=1234)))
-            rccl_nranks = comm.nranks_seen()   # collective on the file transport, local on RCCL (ncclCommCount)
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_fd1, 1)
-            os.close(saved_fd1)
+            comm, comm_kind = dist.connect(be, rank, world, uid_file)
+        except dist.StartupFailed as e:
+            print(f"[bench] rank {rank}: {e}", file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(3)   # a helper thread is stuck inside a collective: no interpreter shutdown, the launcher stops the job
+        comm.bcast_artifacts(be, lambda b: b.load_weights(weights.synthetic_weights(seed=1234)))
+        rccl_nranks = comm.nranks_seen()   # collective on the file transport, local on RCCL (ncclCommCount)
     else:
         be.load_weights(weights.synthetic_weights(seed=1234))
 
@@ -737,7 +735,11 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = value / cpu["value"]
-        print(json.dumps(out))
+        if json_fd is None:
+            print(json.dumps(out))
+        else:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.close()
         if "RD_BENCH_RDV" not in os.environ:

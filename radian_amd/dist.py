@@ -223,6 +223,38 @@ class FileComm:
                 pass
 
 
+def _run_watched(fn, rdv, phase, what, rank, timeout, stuck_grace):
+    """Run one collective start-up step on a helper thread while this thread watches the rendezvous -> 'ok' | 'fail: ...'.
+    A collective cannot be cancelled: when a peer has published a failure for this phase (or the time is up) while fn is still
+    running, StartupFailed(stuck=True) is raised -- the caller leaves the process without interpreter shutdown."""
+    box = {}
+
+    def run():
+        try:
+            fn()
+            box["out"] = "ok"
+        except Exception as e:
+            box["out"] = f"fail: {e}"
+
+    th = threading.Thread(target=run, name=f"rccl-{phase}", daemon=True)
+    th.start()
+    t0, seen_fail = time.time(), None
+    while th.is_alive():
+        th.join(0.02)
+        if not th.is_alive():
+            break
+        now = time.time()
+        failed = {r: v for r, v in rdv.peek(phase).items() if v.startswith("fail")}
+        if failed and seen_fail is None:
+            seen_fail = now
+        if seen_fail is not None and now - seen_fail > stuck_grace:
+            raise StartupFailed("RCCL start-up failed on " + "; ".join(f"rank {r}: {v[5:].strip()}" for r, v in sorted(failed.items()))
+                                + f"; rank {rank} is still inside {what} and cannot leave it", stuck=True)
+        if now - t0 > timeout:
+            raise StartupFailed(f"rank {rank}: {what} did not return within {timeout:.0f} s", stuck=True)
+    return box["out"]
+
+
 def connect(be, rank, world, uid_file, allow_file_fallback=True, timeout=120.0, force_collective=False, stuck_grace=10.0):
     """Collective choice of the transport -> (comm, kind) with kind 'rccl' | 'file-fallback' | 'single'.
 
@@ -234,6 +266,8 @@ def connect(be, rank, world, uid_file, allow_file_fallback=True, timeout=120.0, 
         (this is what two ranks on one GPU do: RCCL refuses the duplicate device on both sides at once);
       * a peer published a failure (or vanished) while this rank is STILL inside ncclCommInitRank -- the collective cannot
         complete and cannot be cancelled -> StartupFailed after `stuck_grace` seconds: fail fast, the launcher stops the job.
+    Phase 3: the communicator's first collective (a max-reduction of the rank numbers, result checked), watched the same way
+    and with the same three outcomes: RCCL builds its transports lazily, so this is where a broken one shows.
     With allow_file_fallback=False every failure raises instead (the launcher reports and stops the job)."""
     if world == 1 and not force_collective:   # (force_collective: a one-rank RCCL communicator, for the worker-route test)
         return SingleComm(), "single"
@@ -252,41 +286,28 @@ def connect(be, rank, world, uid_file, allow_file_fallback=True, timeout=120.0, 
     errors = [f"rank {r}: {v[5:].strip()}" for r, v in enumerate(phase1) if v.startswith("fail")]
     if not errors:
         uid0 = bytes.fromhex(phase1[0][3:])
-        box = {}
 
-        def init():
-            try:
-                be.rccl_init(rank, world, uid0)
-                box["out"] = "ok"
-            except Exception as e:
-                box["out"] = f"fail: {e}"
+        def first_collective():
+            # RCCL sets its transports up lazily: a communicator that initialised can still fail (or answer wrongly) in its
+            # first collective.  One max-reduction of the rank numbers, watched like the init, before anything depends on it.
+            got = be.rccl_allreduce_max([float(rank)])
+            if int(got[0]) != world - 1:
+                raise RuntimeError(f"first all-reduce returned {got[0]!r}, expected {world - 1}")
 
-        th = threading.Thread(target=init, name="rccl-init", daemon=True)
-        th.start()
-        t0, seen_fail = time.time(), None
-        while th.is_alive():
-            th.join(0.02)
-            if not th.is_alive():
+        for phase, what, fn in (("init", "ncclCommInitRank", lambda: be.rccl_init(rank, world, uid0)),
+                                ("first", "the first collective", first_collective)):
+            mine = _run_watched(fn, rdv, phase, what, rank, timeout, stuck_grace)
+            outcome = rdv.gather(phase, mine)
+            errors = [f"rank {r}: {v[5:].strip()}" for r, v in enumerate(outcome) if v.startswith("fail")]
+            if errors:
+                if phase == "first" or mine == "ok":    # this rank holds a communicator: give it back
+                    try:
+                        be.rccl_finalize()
+                    except Exception:
+                        pass
                 break
-            now = time.time()
-            failed = {r: v for r, v in rdv.peek("init").items() if v.startswith("fail")}
-            if failed and seen_fail is None:
-                seen_fail = now
-            if seen_fail is not None and now - seen_fail > stuck_grace:
-                raise StartupFailed("RCCL start-up failed on " + "; ".join(f"rank {r}: {v[5:].strip()}" for r, v in sorted(failed.items()))
-                                    + f"; rank {rank} is still inside ncclCommInitRank and cannot leave it", stuck=True)
-            if now - t0 > timeout:
-                raise StartupFailed(f"rank {rank}: ncclCommInitRank did not return within {timeout:.0f} s", stuck=True)
-        mine = box["out"]
-        phase2 = rdv.gather("init", mine)
-        errors = [f"rank {r}: {v[5:].strip()}" for r, v in enumerate(phase2) if v.startswith("fail")]
         if not errors:
             return RcclComm(be, rank, world), "rccl"
-        if mine == "ok":
-            try:
-                be.rccl_finalize()
-            except Exception:
-                pass
     msg = "RCCL start-up failed on " + "; ".join(errors)
     if not allow_file_fallback:
         raise RuntimeError(msg)

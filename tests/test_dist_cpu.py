@@ -203,7 +203,8 @@ def test_world8_file_queue_order_and_fasta_rotation(tmp_path):
 def test_transport_agreement(tmp_path):
     """dist.connect with stand-in rccl_* calls, 3 ranks: (a) all fine -> 'rccl' everywhere; (b) rank 1's
     ncclCommInitRank fails -> every rank drops RCCL and the file transport's barrier / max work; (c) rank 2 cannot even
-    load librccl -> NO rank calls ncclCommInitRank.  Never a mix."""
+    load librccl -> NO rank calls ncclCommInitRank; (d) every init succeeds but rank 0's first collective returns an error,
+    (e) ... or a wrong answer -> every rank gives its communicator back, file transport everywhere.  Never a mix."""
     script = tmp_path / "c.py"
     script.write_text(
         "import os, sys, json\n"
@@ -222,14 +223,18 @@ def test_transport_agreement(tmp_path):
         "        if case == 'b' and rank == 1: raise RuntimeError('ncclCommInitRank: invalid usage')\n"
         "    def rccl_finalize(self): Be.finals += 1\n"
         "    def rccl_barrier(self): pass\n"
-        "    def rccl_allreduce_max(self, v): return v\n"
+        "    def rccl_allreduce_max(self, v):\n"
+        "        if case == 'd' and rank == 0 and Be.finals == 0: raise RuntimeError('ncclAllReduce: unhandled cuda error')\n"
+        "        if case == 'e' and rank == 2 and Be.finals == 0: return [0.0]\n"
+        "        return [float(world - 1)]\n"
         f"comm, kind = dist.connect(Be(), rank, world, os.path.join({str(tmp_path)!r}, 'uid_' + case), timeout=60)\n"
         "comm.barrier()\n"
         "m = comm.allreduce_max([float(rank)])\n"
         "if kind != 'rccl': assert m[0] == world - 1\n"
         "comm.close()\n"
         f"json.dump([kind, type(comm).__name__, Be.inits, Be.finals], open(os.path.join({str(tmp_path)!r}, f'res_{{case}}_{{rank}}.json'), 'w'))\n")
-    for case, exp_kind, exp_inits in (("a", "rccl", 1), ("b", "file-fallback", 1), ("c", "file-fallback", 0)):
+    for case, exp_kind, exp_inits in (("a", "rccl", 1), ("b", "file-fallback", 1), ("c", "file-fallback", 0), ("d", "file-fallback", 1),
+                                      ("e", "file-fallback", 1)):
         procs, outs = _spawn([str(script), case], 3, timeout=120)
         assert all(p.returncode == 0 for p in procs), outs
         res = [json.load(open(tmp_path / f"res_{case}_{r}.json")) for r in range(3)]
@@ -237,6 +242,8 @@ def test_transport_agreement(tmp_path):
         assert [r[2] for r in res] == [exp_inits] * 3, res
         if case == "b":   # the ranks whose init had succeeded gave their communicator back
             assert [r[3] for r in res] == [1, 0, 1], res
+        if case in "de":  # every rank held one
+            assert [r[3] for r in res] == [1, 1, 1], res
     # without the fallback the failure is raised on every rank (the launcher then stops the job)
     from radian_amd import dist
 
