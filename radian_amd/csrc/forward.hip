@@ -1767,7 +1767,16 @@ int rd_lane_get(rd_ctx* ctx, int lane, FwdLane** out)
     FwdLane& L = ctx->lanes[lane];
     if (!L.st) {
         if (lane == 0) L.st = ctx->stream;
-        else if (lane < RD_MAX_LANES) RD_HIP(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
+        else if (lane < RD_MAX_LANES) {
+#ifdef RD_EXPERIMENTS
+            if (getenv("RD_X_LANE_PRIO")) {     // lanes >= 1 at the lowest queue priority: they fill what lane 0 leaves (measurement)
+                int lo = 0, hi = 0;
+                RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                RD_HIP(hipStreamCreateWithPriority(&L.st, hipStreamNonBlocking, lo));
+            } else
+#endif
+            RD_HIP(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
+        }
         else {
             if (ctx->part_cus < 1 || ctx->part_cus > 31) {
                 rd_set_error("internal: partitioned lane %d without a decode partition", lane);

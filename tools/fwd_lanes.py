@@ -14,6 +14,7 @@ iters = int(sys.argv[3]) if len(sys.argv) > 3 else 80
 nctx = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 n_reads = int(sys.argv[5]) if len(sys.argv) > 5 else 64
 N, chunk, step = 4096, 1024, 512
+pattern = [int(x) for x in os.environ["LANE_PATTERN"].split(",")] if os.environ.get("LANE_PATTERN") else None   # e.g. 0,0,0,1
 w = weights.synthetic_weights(seed=1234)
 rng = np.random.default_rng(0)
 sig = np.clip(rng.normal(size=n_reads * N), -4, 4).astype(np.float32)
@@ -34,7 +35,7 @@ def loop(i, n):
     rows = 0
     for k in range(n):
         if mode == "reads":
-            rows = bes[i].forward_reads_resident(bufs[i], off, n_reads, chunk, step, "chunk", lane=k % lanes)
+            rows = bes[i].forward_reads_resident(bufs[i], off, n_reads, chunk, step, "chunk", lane=(pattern[k % len(pattern)] if pattern else k % lanes))
         else:
             bes[i].forward_resident(bufs[i], nW, chunk)
             rows = nW * chunk
@@ -53,7 +54,7 @@ for rep in range(3):
     [t.join() for t in ths]
     dt = time.time() - t0
     per = dt / (nctx * iters)
-    print(f"fuse={os.environ.get('RD_FUSE', '1')} {mode} lanes={lanes} contexts={nctx} reads={n_reads}: {per * 1e3:.3f} ms per forward = {n_reads * N / per / 1e6:.2f} M samples/s "
+    print(f"fuse={os.environ.get('RD_FUSE', '1')} prio={os.environ.get('RD_X_LANE_PRIO', '-')} pattern={os.environ.get('LANE_PATTERN', '-')} {mode} lanes={lanes} contexts={nctx} reads={n_reads}: {per * 1e3:.3f} ms per forward = {n_reads * N / per / 1e6:.2f} M samples/s "
           f"({rows} rows evaluated at the head layer)", flush=True)
 for be in bes:
     be.close()
