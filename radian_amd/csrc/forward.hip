@@ -225,7 +225,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
     constexpr int NCHUNK = TAPS * (RD_C / BK);
     constexpr int A_FLOATS = FIN ? 0 : BM * BK;    // FIN: no A part in the DMA stages
     constexpr int STAGE_FLOATS = A_FLOATS + BN * BK;   // one K-chunk of A and B
-    constexpr int HEAD_FLOATS = BM * (RD_H + 1) + RD_H * 5 + 8;
+    constexpr int HEAD_FLOATS = BM * (RD_H + 1) + RD_H * 5 + 8 + BM * 5;
     constexpr int NSTAGE = 3;
     constexpr int MIDROWS = 4 * (32 + 2 * FIN_DMAX);                      // rows of a slice's A region
     constexpr int FIN_FLOATS = FIN ? 2 * MIDROWS * BK + 4 * RD_C : 0;     // two regions + the first conv's [w0 | w1 | w2 | b] x 256
@@ -598,19 +598,32 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
         for (int i = tid; i < RD_H * 5; i += 64 * NWAVE) w2s[i] = a.w2[i];
         if (tid < 5) w2s[RD_H * 5 + tid] = a.b2[tid];
         __syncthreads();
+        // two threads per row: each sums one half of the 128 hidden units (waves 0..NWAVE/2-1: units 0..63 on top of the bias; the
+        // others: units 64..127 from zero), the second half's sums go through LDS, the first half's thread adds them and does the softmax
+        float* part = w2s + RD_H * 5 + 8;          // [BM][5]
+        static_assert(64 * NWAVE == 2 * BM, "head epilogue: two threads per row");
+        const int hrow = tid < BM ? tid : tid - BM;
+        const int j0 = tid < BM ? 0 : RD_H / 2;
+        float lg[5];
+#pragma unroll
+        for (int o = 0; o < 5; o++) lg[o] = tid < BM ? w2s[RD_H * 5 + o] : 0.f;
+        for (int j = j0; j < j0 + RD_H / 2; j++) {
+            const float h = hs[hrow * LDH + j];
+#pragma unroll
+            for (int o = 0; o < 5; o++) lg[o] += h * w2s[j * 5 + o];
+        }
+        if (tid >= BM) {
+#pragma unroll
+            for (int o = 0; o < 5; o++) part[hrow * 5 + o] = lg[o];
+        }
+        __syncthreads();
         if (tid < BM) {
             const TileDesc sd = tds[tid >> 5];
             const int t = sd.t0 + (tid & 31);
             const int64_t seg_row = sd.seg_row;
             if (t < sd.seg_len) {
-                float lg[5];
 #pragma unroll
-                for (int o = 0; o < 5; o++) lg[o] = w2s[RD_H * 5 + o];
-                for (int j = 0; j < RD_H; j++) {
-                    const float h = hs[tid * LDH + j];
-#pragma unroll
-                    for (int o = 0; o < 5; o++) lg[o] += h * w2s[j * 5 + o];
-                }
+                for (int o = 0; o < 5; o++) lg[o] += part[tid * 5 + o];
                 float mx = lg[0];
 #pragma unroll
                 for (int o = 1; o < 5; o++) mx = lg[o] > mx ? lg[o] : mx;
