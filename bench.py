@@ -352,7 +352,8 @@ def main():
     secondaries = world == 1 and not args.no_secondary and not args.windowed and args.precision == "fp32"
     stitch_pool = None   # (the pipelined driver stitches natively on host threads: no worker processes to start)
 
-    device = int(os.environ.get("RD_BENCH_DEVICE", local_rank))   # override only for rehearsals on a 1-GPU box
+    from radian_amd.backend import device_for_rank
+    device = int(os.environ["RD_BENCH_DEVICE"]) if "RD_BENCH_DEVICE" in os.environ else device_for_rank(local_rank)   # (override: rehearsals on a 1-GPU box)
     be = Backend(device)
     comm_kind = "single"
     comm = None

@@ -33,6 +33,24 @@ def _labels_of(labels, off, n):
     return labels[off: off + n].copy()
 
 
+def device_count():
+    """visible HIP devices (rd_device_count)"""
+    n = ctypes.c_int(0)
+    L = _lib.load()
+    if L.rd_device_count(ctypes.byref(n)) != 0:
+        raise RadianHipError(L.rd_last_error().decode())
+    return n.value
+
+
+def device_for_rank(local_rank):
+    """The device of a rank of a one-process-per-GPU job: its local rank -- or, when the launcher has narrowed every process's
+    view (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES with fewer devices than local ranks), the local rank modulo what is visible."""
+    n = device_count()
+    if n < 1:
+        raise RadianHipError("no HIP device is visible to this process")
+    return local_rank if local_rank < n else local_rank % n
+
+
 class PipeTicket:
     """One batch queued on a Backend's reads-level pipeline (Backend.pipe_submit_raw).  The arrays the library writes into
     live here until the batch is delivered."""

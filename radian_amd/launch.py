@@ -282,7 +282,8 @@ def worker(scratch, argv):
     args = build_parser().parse_args(argv)
     rank, local_rank, world = env_rank_world()
     pool = make_stitch_pool(args.stitch_workers) if args.decode_type == "chunk" and args.no_pipeline else None   # before the GPU is touched
-    device = int(os.environ.get("RD_CLI_DEVICE", local_rank))   # override only for rehearsals on a 1-GPU box
+    from .backend import device_for_rank
+    device = int(os.environ["RD_CLI_DEVICE"]) if "RD_CLI_DEVICE" in os.environ else device_for_rank(local_rank)   # (override: rehearsals on a 1-GPU box)
     be = Backend(device)
     # every rank uses RCCL or none does (dist.connect); the rendezvous lives in the launcher's private scratch directory
     try:

@@ -50,3 +50,12 @@ def test_cli_two_ranks_equal_single_process(tmp_path, mode):
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         outs[g] = open(out / "reads-0.fasta").read()
     assert outs[1] == outs[2] and outs[1].count(">") == 150
+
+
+def test_device_for_rank_follows_visibility():
+    """a rank's device is its local rank, or -- when the launcher narrowed every process's view to fewer devices than local ranks --
+    the local rank modulo what is visible (a one-GPU box sees one device: every local rank maps to device 0)"""
+    from radian_amd.backend import device_count, device_for_rank
+    n = device_count()
+    assert n >= 1 and device_for_rank(0) == 0
+    assert [device_for_rank(r) for r in range(n, n + 3)] == [r % n for r in range(n, n + 3)]
