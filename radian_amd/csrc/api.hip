@@ -42,6 +42,7 @@ int DevBuf::reserve(size_t bytes)
     hipError_t e = hipMalloc(&np, want);
     if (e != hipSuccess && p) {
         (void)hipGetLastError();
+        (void)hipDeviceSynchronize();   // (see below)
         (void)hipFree(p);
         p = nullptr;
         cap = 0;
@@ -53,7 +54,13 @@ int DevBuf::reserve(size_t bytes)
         rd_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
         return -1;
     }
-    if (p) (void)hipFree(p);
+    if (p) {
+        // A workspace can be regrown while kernels launched earlier on another stream still use the old block (the pipeline's shared
+        // trie workspace while the previous group's search runs): wait for the device explicitly rather than lean on hipFree's own
+        // synchronisation.  Growth is geometric (+ 1/8), so this happens a handful of times in a context's life.
+        (void)hipDeviceSynchronize();
+        (void)hipFree(p);
+    }
     p = np;
     cap = want;
     return 0;
