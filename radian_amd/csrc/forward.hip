@@ -202,6 +202,59 @@ __device__ __forceinline__ void gstore16(void* sbase, unsigned byte_off, float4 
     *(__attribute__((address_space(1))) f32x4*)(sgpr_base(sbase) + byte_off) = f32x4{v.x, v.y, v.z, v.w};
 }
 
+// Dense(5) + softmax of a head tile (model.py:73-75), shared by the three matrix-product modes.  hs = the tile's Dense(128) + ReLU rows
+// in LDS, [ROWS][RD_H + 1]; w2s = Dense(5)'s [128][5] kernel + [5] bias in LDS; part = [ROWS][5] floats of LDS.  TWO threads per row
+// (2 x ROWS threads): threads < ROWS sum hidden units 0..63 on top of the bias, the others units 64..127 from zero and pass their sums
+// through `part`; the first half's thread adds them and writes the softmax row (float32 or, in f16-logits mode, float16).
+template <int ROWS, typename Args>
+__device__ __forceinline__ void head_dense5_softmax(const float* hs, const float* w2s, float* part, const TileDesc* __restrict__ tds,
+                                                    const Args& a, int tid)
+{
+    constexpr int LDH = RD_H + 1;
+    const int hrow = tid < ROWS ? tid : tid - ROWS;
+    const int j0 = tid < ROWS ? 0 : RD_H / 2;
+    float lg[5];
+#pragma unroll
+    for (int o = 0; o < 5; o++) lg[o] = tid < ROWS ? w2s[RD_H * 5 + o] : 0.f;
+    for (int j = j0; j < j0 + RD_H / 2; j++) {
+        const float h = hs[hrow * LDH + j];
+#pragma unroll
+        for (int o = 0; o < 5; o++) lg[o] += h * w2s[j * 5 + o];
+    }
+    if (tid >= ROWS) {
+#pragma unroll
+        for (int o = 0; o < 5; o++) part[hrow * 5 + o] = lg[o];
+    }
+    __syncthreads();
+    if (tid < ROWS) {
+        const TileDesc sd = tds[tid >> 5];
+        const int t = sd.t0 + (tid & 31);
+        const int64_t seg_row = sd.seg_row;
+        if (t < sd.seg_len) {
+#pragma unroll
+            for (int o = 0; o < 5; o++) lg[o] += part[tid * 5 + o];
+            float mx = lg[0];
+#pragma unroll
+            for (int o = 1; o < 5; o++) mx = lg[o] > mx ? lg[o] : mx;
+            float e[5], sum = 0.f;
+#pragma unroll
+            for (int o = 0; o < 5; o++) {
+                e[o] = expf(lg[o] - mx);
+                sum += e[o];
+            }
+            if (a.probs_f16) {
+                _Float16* pr = (_Float16*)a.probs + ((size_t)seg_row + t) * 5;
+#pragma unroll
+                for (int o = 0; o < 5; o++) pr[o] = (_Float16)(e[o] / sum);   // round to nearest even
+            } else {
+                float* pr = a.probs + ((size_t)seg_row + t) * 5;
+#pragma unroll
+                for (int o = 0; o < 5; o++) pr[o] = e[o] / sum;
+            }
+        }
+    }
+}
+
 // WM = waves along M (64 time steps each): 2 -> the 256-thread, 128-row tile, two workgroups per CU (the product's shape);
 // 4 -> a 512-thread, 256-row tile, one workgroup per CU: the B (weight) tile is shared by twice the rows, so a CU moves
 // (256 + 256) x 64 B = 32 KiB per chunk by LDS-DMA instead of 2 x (128 + 256) x 64 B = 48 KiB for the same FLOPs
@@ -598,52 +651,8 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
         for (int i = tid; i < RD_H * 5; i += 64 * NWAVE) w2s[i] = a.w2[i];
         if (tid < 5) w2s[RD_H * 5 + tid] = a.b2[tid];
         __syncthreads();
-        // two threads per row: each sums one half of the 128 hidden units (waves 0..NWAVE/2-1: units 0..63 on top of the bias; the
-        // others: units 64..127 from zero), the second half's sums go through LDS, the first half's thread adds them and does the softmax
-        float* part = w2s + RD_H * 5 + 8;          // [BM][5]
         static_assert(64 * NWAVE == 2 * BM, "head epilogue: two threads per row");
-        const int hrow = tid < BM ? tid : tid - BM;
-        const int j0 = tid < BM ? 0 : RD_H / 2;
-        float lg[5];
-#pragma unroll
-        for (int o = 0; o < 5; o++) lg[o] = tid < BM ? w2s[RD_H * 5 + o] : 0.f;
-        for (int j = j0; j < j0 + RD_H / 2; j++) {
-            const float h = hs[hrow * LDH + j];
-#pragma unroll
-            for (int o = 0; o < 5; o++) lg[o] += h * w2s[j * 5 + o];
-        }
-        if (tid >= BM) {
-#pragma unroll
-            for (int o = 0; o < 5; o++) part[hrow * 5 + o] = lg[o];
-        }
-        __syncthreads();
-        if (tid < BM) {
-            const TileDesc sd = tds[tid >> 5];
-            const int t = sd.t0 + (tid & 31);
-            const int64_t seg_row = sd.seg_row;
-            if (t < sd.seg_len) {
-#pragma unroll
-                for (int o = 0; o < 5; o++) lg[o] += part[tid * 5 + o];
-                float mx = lg[0];
-#pragma unroll
-                for (int o = 1; o < 5; o++) mx = lg[o] > mx ? lg[o] : mx;
-                float e[5], s = 0.f;
-#pragma unroll
-                for (int o = 0; o < 5; o++) {
-                    e[o] = expf(lg[o] - mx);
-                    s += e[o];
-                }
-                if (a.probs_f16) {
-                    _Float16* pr = (_Float16*)a.probs + ((size_t)seg_row + t) * 5;
-#pragma unroll
-                    for (int o = 0; o < 5; o++) pr[o] = (_Float16)(e[o] / s);   // round to nearest even
-                } else {
-                    float* pr = a.probs + ((size_t)seg_row + t) * 5;
-#pragma unroll
-                    for (int o = 0; o < 5; o++) pr[o] = e[o] / s;
-                }
-            }
-        }
+        head_dense5_softmax<BM>(hs, w2s, w2s + RD_H * 5 + 8, tds, a, tid);
     }
     RD_STAMP_END()
 }
@@ -723,7 +732,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
     constexpr int NCHUNK = TAPS * (RD_C / BKC);
     constexpr int STAGE_FLOATS = (BM + BN) * 16;  // 64 B per row
     constexpr int NSTAGE = 3;
-    constexpr int HEAD_FLOATS = BM * (RD_H + 1) + RD_H * 5 + 8;
+    constexpr int HEAD_FLOATS = BM * (RD_H + 1) + RD_H * 5 + 8 + BM * 5;
     constexpr int SMEM_FLOATS = (EPI == EPI_HEAD && HEAD_FLOATS > NSTAGE * STAGE_FLOATS) ? HEAD_FLOATS : NSTAGE * STAGE_FLOATS;
 
     __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
@@ -963,39 +972,7 @@ __global__ __launch_bounds__(256, 2) void tcn_gemm_split_kernel(SplitArgs a)
         for (int i = tid; i < RD_H * 5; i += 256) w2s[i] = a.w2[i];
         if (tid < 5) w2s[RD_H * 5 + tid] = a.b2[tid];
         __syncthreads();
-        if (tid < BM) {
-            const TileDesc sd = tds[tid >> 5];
-            const int t = sd.t0 + (tid & 31);
-            const int64_t seg_row = sd.seg_row;
-            if (t < sd.seg_len) {
-                float lg[5];
-#pragma unroll
-                for (int o = 0; o < 5; o++) lg[o] = w2s[RD_H * 5 + o];
-                for (int j = 0; j < RD_H; j++) {
-                    const float h = hs[tid * LDH + j];
-#pragma unroll
-                    for (int o = 0; o < 5; o++) lg[o] += h * w2s[j * 5 + o];
-                }
-                float mx = lg[0];
-#pragma unroll
-                for (int o = 1; o < 5; o++) mx = lg[o] > mx ? lg[o] : mx;
-                float e[5], s = 0.f;
-#pragma unroll
-                for (int o = 0; o < 5; o++) {
-                    e[o] = expf(lg[o] - mx);
-                    s += e[o];
-                }
-                if (a.probs_f16) {
-                    _Float16* pr = (_Float16*)a.probs + ((size_t)seg_row + t) * 5;
-#pragma unroll
-                    for (int o = 0; o < 5; o++) pr[o] = (_Float16)(e[o] / s);   // round to nearest even
-                } else {
-                    float* pr = a.probs + ((size_t)seg_row + t) * 5;
-#pragma unroll
-                    for (int o = 0; o < 5; o++) pr[o] = e[o] / s;
-                }
-            }
-        }
+        head_dense5_softmax<BM>(hs, w2s, w2s + RD_H * 5 + 8, tds, a, tid);
     }
 }
 
@@ -1111,7 +1088,7 @@ __global__ __launch_bounds__(512, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
     constexpr int RB = 96;                                   // bytes per LDS row (16 channels x 3 terms x 2 B)
     constexpr int STAGE_BYTES = (BM3 + BN) * RB;             // 48 KiB (conv) / 36 KiB (head)
     constexpr int NSTAGE = 3;
-    constexpr int HEAD_FLOATS = BM3 * (RD_H + 1) + RD_H * 5 + 8;
+    constexpr int HEAD_FLOATS = BM3 * (RD_H + 1) + RD_H * 5 + 8 + BM3 * 5;
     constexpr int EPI_FLOATS = 8 * 32 * 64;
     constexpr int STG_FLOATS = NSTAGE * STAGE_BYTES / 4;
     constexpr int SMEM_FLOATS = (EPI == EPI_HEAD && HEAD_FLOATS > STG_FLOATS) ? HEAD_FLOATS : (STG_FLOATS > EPI_FLOATS ? STG_FLOATS : EPI_FLOATS);
@@ -1427,39 +1404,7 @@ __global__ __launch_bounds__(512, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
         for (int i = tid; i < RD_H * 5; i += 512) w2s[i] = a.w2[i];
         if (tid < 5) w2s[RD_H * 5 + tid] = a.b2[tid];
         __syncthreads();
-        if (tid < BM3) {
-            const TileDesc sd = tds[tid >> 5];
-            const int t = sd.t0 + (tid & 31);
-            const int64_t seg_row = sd.seg_row;
-            if (t < sd.seg_len) {
-                float lg[5];
-#pragma unroll
-                for (int o = 0; o < 5; o++) lg[o] = w2s[RD_H * 5 + o];
-                for (int j = 0; j < RD_H; j++) {
-                    const float h = hs[tid * LDH + j];
-#pragma unroll
-                    for (int o = 0; o < 5; o++) lg[o] += h * w2s[j * 5 + o];
-                }
-                float mx = lg[0];
-#pragma unroll
-                for (int o = 1; o < 5; o++) mx = lg[o] > mx ? lg[o] : mx;
-                float e[5], s = 0.f;
-#pragma unroll
-                for (int o = 0; o < 5; o++) {
-                    e[o] = expf(lg[o] - mx);
-                    s += e[o];
-                }
-                if (a.probs_f16) {
-                    _Float16* pr = (_Float16*)a.probs + ((size_t)seg_row + t) * 5;
-#pragma unroll
-                    for (int o = 0; o < 5; o++) pr[o] = (_Float16)(e[o] / s);   // round to nearest even
-                } else {
-                    float* pr = a.probs + ((size_t)seg_row + t) * 5;
-#pragma unroll
-                    for (int o = 0; o < 5; o++) pr[o] = e[o] / s;
-                }
-            }
-        }
+        head_dense5_softmax<BM3>(hs, w2s, w2s + RD_H * 5 + 8, tds, a, tid);
     }
 }
 
