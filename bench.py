@@ -375,11 +375,11 @@ def main():
         uid_file = dist.uid_path(directory=os.environ.get("RD_BENCH_RDV"))   # own launcher: its scratch; foreign: /tmp, by launcher pid
         try:
             comm, comm_kind = dist.connect(be, rank, world, uid_file)
+            comm.bcast_artifacts(be, lambda b: b.load_weights(weights.synthetic_weights(seed=1234)))
         except dist.StartupFailed as e:
             print(f"[bench] rank {rank}: {e}", file=sys.stderr)
             sys.stderr.flush()
             os._exit(3)   # a helper thread is stuck inside a collective: no interpreter shutdown, the launcher stops the job
-        comm.bcast_artifacts(be, lambda b: b.load_weights(weights.synthetic_weights(seed=1234)))
         rccl_nranks = comm.nranks_seen()   # collective on the file transport, local on RCCL (ncclCommCount)
     else:
         be.load_weights(weights.synthetic_weights(seed=1234))

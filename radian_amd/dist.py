@@ -155,11 +155,27 @@ class RcclComm:
     def allreduce_max(self, values):
         return self.be.rccl_allreduce_max(values)
 
-    def bcast_artifacts(self, be, load_fn):
-        """rank 0 loads + repacks weights / LM, then one broadcast puts the device images on every rank."""
+    def bcast_artifacts(self, be, load_fn, timeout=600.0):
+        """rank 0 loads + repacks weights / LM, then one broadcast puts the device images on every rank.  The broadcast runs on a
+        helper thread under a deadline: a rank that a peer left alone inside the collective (its load failed, it ran out of memory)
+        raises StartupFailed(stuck=True) instead of waiting for ever; an error of this rank's own call is re-raised as it is."""
         if self.rank == 0:
             load_fn(be)
-        be.rccl_bcast_model(0)
+        box = {}
+
+        def run():
+            try:
+                be.rccl_bcast_model(0)
+            except BaseException as e:
+                box["err"] = e
+
+        th = threading.Thread(target=run, name="rccl-bcast", daemon=True)
+        th.start()
+        th.join(timeout)
+        if th.is_alive():
+            raise StartupFailed(f"rank {self.rank}: the artefact broadcast did not finish within {timeout:.0f} s", stuck=True)
+        if "err" in box:
+            raise box["err"]
 
     def allgather(self, value):
         return _allgather_by_max(self, value)

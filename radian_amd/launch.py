@@ -288,13 +288,13 @@ def worker(scratch, argv):
     # every rank uses RCCL or none does (dist.connect); the rendezvous lives in the launcher's private scratch directory
     try:
         comm, kind = connect(be, rank, world, uid_path(directory=scratch), force_collective=True)
+        # rank 0 parses / repacks the artefacts; everyone gets the device images by one broadcast (file transport: each
+        # rank loads them itself).  The parent has validated them already, so rank 0 cannot fail here for a bad argument.
+        comm.bcast_artifacts(be, lambda b: apply_artifacts(args, b, load_artifacts(args, cache_dir=scratch)))
     except StartupFailed as e:
         print(f"[radian_amd.launch] rank {rank}: {e}", file=sys.stderr)
         sys.stderr.flush()
-        os._exit(3)   # a helper thread is stuck inside ncclCommInitRank; the parent stops the other ranks
-    # rank 0 parses / repacks the artefacts; everyone gets the device images by one broadcast (file transport: each
-    # rank loads them itself).  The parent has validated them already, so rank 0 cannot fail here for a bad argument.
-    comm.bcast_artifacts(be, lambda b: apply_artifacts(args, b, load_artifacts(args, cache_dir=scratch)))
+        os._exit(3)   # a helper thread is stuck inside a collective; the parent stops the other ranks
     # the rank's further device contexts (--device-contexts, as in a single-GPU run: one context's forward overlaps the
     # other's beam search) take the images from the one that received the broadcast -- a device copy, no second parse
     backends = [be] + [Backend(device) for _ in range(n_contexts(args) - 1)]
