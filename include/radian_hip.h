@@ -33,6 +33,7 @@ extern "C" {
 #define RD_ERR_STATE (-3) /* call order (e.g. forward before weights) */
 #define RD_ERR_NOMEM (-4) /* device allocation failed */
 #define RD_ERR_RCCL (-5)  /* RCCL error / librccl not loadable */
+#define RD_ERR_FORMAT (-6) /* rd_lm_json_*: the text is not of the one shape the fast reader handles (no verdict: use a full JSON parser) */
 /* Not an error code: the value of label_len[i] for a sequence whose beam search looked up a context that a SPARSE RNA model
  * does not hold (rd_load_lm, rows of NaN).  The reference raises KeyError at radian/decode.py:83 on such a read; the caller
  * does the same when it reaches that read (radian_amd/basecall.py).  The sequence's labels are not written. */
@@ -301,6 +302,20 @@ int rd_pipe_policy_read(rd_ctx* ctx, int beam_width, int on_partition, int use_l
 /* Batches submitted to the reads-level pipeline so far: right after a submit, the number rd_pipe_progress must reach for
  * that batch to have been delivered. */
 int rd_pipe_submitted(rd_ctx* ctx, int64_t* submitted);
+
+/* RNA model file -> dense table, without a JSON object tree.  radian/basecall.py:48-57 (json.load, then every "ACGT..." key re-keyed as a
+ * tuple of label indices).  The reference's default model has 4^11 keys in ~420 MB of text; these two calls scan the one shape such a
+ * file has -- an object of k-character keys over ACGT, each with an array of four JSON numbers -- straight into the [4^k][4] float64 table
+ * rd_load_lm takes (row = base-4 number of the context, first character most significant):
+ *   rd_lm_json_probe: k = length of the first key (1..13);
+ *   rd_lm_json_fill:  the caller has filled table with NaN; every key's row is written (a repeated key keeps its last value, like a Python
+ *                     dict), rows of contexts the file does not hold stay NaN (sparse model: see rd_load_lm); *n_entries = pairs read,
+ *                     *n_contexts = distinct contexts.
+ * Anything else in the text (escapes, another alphabet, a key of another length, NaN / Infinity, nested values, trailing text) returns
+ * RD_ERR_FORMAT and decides nothing: the caller falls back to a full JSON parser, whose errors are the reference's.  Numbers are
+ * converted correctly rounded and locale-independently (the double Python's float() gives).  No GPU is touched, no context is needed. */
+int rd_lm_json_probe(const char* buf, size_t n, int* k_out);
+int rd_lm_json_fill(const char* buf, size_t n, int k, double* table, int64_t* n_entries, int64_t* n_contexts);
 
 /* ---- the step after the hot path in chunk mode, on the HOST's cores: simple_assembly + argmax --
  * radian/sequence_assembly.py:19-48, radian/basecall.py:122-123.  labels / label_len as the chunk-mode entry points return

@@ -57,6 +57,8 @@ SIGNATURES = {
     "rd_basecall_raw_chunk": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
     "rd_basecall_raw_global": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp, c_vp]),
     "rd_stitch_chunk": (c_i, [c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_i]),
+    "rd_lm_json_probe": (c_i, [c_vp, ctypes.c_size_t, ctypes.POINTER(c_i)]),
+    "rd_lm_json_fill": (c_i, [c_vp, ctypes.c_size_t, c_i, c_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "rd_dev_alloc": (c_i, [c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "rd_mem_info": (c_i, [c_vp, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)]),
     "rd_dev_free": (c_i, [c_vp, c_vp]),

@@ -8,8 +8,10 @@ A model that does not hold every one of the 4^k contexts (a sparse JSON) loads l
 contexts are NaN, which rd_load_lm turns into the "absent" mask the beam search checks; a read whose search reaches one
 fails with the reference's KeyError (decode.py:83) -- and only such a read.
 
-The real model has 4^11 = 4 194 304 keys: the keys are converted to table rows in one vectorised pass (the JSON parse itself
-is the standard library's)."""
+The real model has 4^11 = 4 194 304 keys (~420 MB of text).  load_json first hands the file to the library's one-pass reader
+(csrc/lmjson.hip: the one shape such a file has, straight into the table); whatever that reader does not recognise -- and every
+dict handed in by a caller -- goes through the standard parser and table_from_dict, which converts the keys to table rows in one
+vectorised pass."""
 import json
 
 import numpy as np
@@ -80,8 +82,42 @@ def n_missing(table):
     return int(np.isnan(table[:, 0]).sum())
 
 
-def load_json(path):
-    """basecall.py:48-57.  Returns (table, k)."""
+def _load_json_native(path):
+    """The file scanned straight into the table by the library's reader (rd_lm_json_probe / rd_lm_json_fill: no Python object per
+    key or number) -> (table, k), or None when the text is not of the one shape that reader handles -- the caller then uses
+    json.load, whose errors are the reference's."""
+    import ctypes
+    import mmap
+    from . import _lib
+    L = _lib.load()
+    with open(path, "rb") as f:
+        size = f.seek(0, 2)
+        if size == 0:
+            return None
+        with mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+            view = np.frombuffer(mm, dtype=np.uint8)          # (zero-copy: a pointer into the mapping)
+            try:
+                ptr = ctypes.c_void_p(view.ctypes.data)
+                k = ctypes.c_int(0)
+                if L.rd_lm_json_probe(ptr, size, ctypes.byref(k)) != 0:
+                    return None
+                table = np.full((4 ** k.value, 4), np.nan, dtype=np.float64)
+                n_entries, n_contexts = ctypes.c_int64(0), ctypes.c_int64(0)
+                rc = L.rd_lm_json_fill(ptr, size, k.value, table.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n_entries), ctypes.byref(n_contexts))
+            finally:
+                del view                                        # (the mapping cannot close under an exported buffer)
+    if rc != 0 or n_entries.value == 0:
+        return None
+    return table, k.value
+
+
+def load_json(path, native=True):
+    """basecall.py:48-57.  Returns (table, k).  native: try the library's one-pass reader first (the 4^11-key model: ~2 s instead of
+    ~25 s, no 2-GB object tree); any text it does not recognise goes through json.load + table_from_dict."""
+    if native:
+        got = _load_json_native(path)
+        if got is not None:
+            return got
     with open(path, "r") as f:
         raw = json.load(f)
     return table_from_dict(raw)

@@ -586,3 +586,41 @@ def test_artifact_cache_roundtrip_for_multi_gpu_ranks(tmp_path):
             assert got["lm_table"] is None
         else:
             assert np.array_equal(got["lm_table"], table, equal_nan=True) and np.isnan(got["lm_table"][3]).all()
+
+
+def test_lm_json_native_reader_equals_the_standard_parser(tmp_path):
+    """lm.load_json's first route (rd_lm_json_probe / rd_lm_json_fill: the model file scanned straight into the table) gives the
+    table json.load + table_from_dict gives, bit for bit -- dense and sparse models, any whitespace, integer / exponent / subnormal
+    numbers, a repeated key (last value wins, as in a dict) -- and declines (None -> the standard parser decides and raises the
+    reference's errors) on everything that is not an object of equal-length ACGT keys with four finite JSON numbers each."""
+    import json
+    from radian_amd import lm
+    rng = np.random.default_rng(5)
+    for k, frac, indent, seps in [(1, 1.0, None, None), (3, 1.0, None, None), (5, 0.6, 2, None), (4, 1.0, None, (",", ":")), (6, 0.9, 1, None)]:
+        keys = ["".join("ACGT"[(i >> (2 * (k - 1 - j))) & 3] for j in range(k)) for i in range(4 ** k)]
+        rng.shuffle(keys)
+        keys = keys[: max(1, int(len(keys) * frac))]
+        d = {c: [float(x) for x in rng.dirichlet([0.3] * 4)] for c in keys}
+        d[keys[0]] = [0, 1, 1e-310, 2.5E-7]
+        p = tmp_path / f"m{k}.json"
+        p.write_text(json.dumps(d, indent=indent, separators=seps))
+        nat, std = lm._load_json_native(str(p)), lm.load_json(str(p), native=False)
+        assert nat is not None and nat[1] == std[1] == k and nat[0].tobytes() == std[0].tobytes(), (k, frac)
+        got = lm.load_json(str(p))
+        assert got[1] == k and got[0].tobytes() == std[0].tobytes()
+        assert lm.n_missing(got[0]) == 4 ** k - len(keys)
+    p = tmp_path / "dup.json"
+    p.write_text('{"A":[1,0,0,0],"C":[0,1,0,0],"A":[0.5,0.5,0,-0.0],"G":[0,0,1,0],"T":[0,0,0,1]}')
+    nat, std = lm._load_json_native(str(p)), lm.load_json(str(p), native=False)
+    assert nat[0].tobytes() == std[0].tobytes() and nat[0][0, 0] == 0.5
+    declined = ['{"ACGU":[0.1,0.2,0.3,0.4]}', '{"AC":[0.1,0.2,0.3,0.4],"A":[1,0,0,0]}', '{"AC":[0.1,0.2,0.3]}', '{"AC":[0.1,0.2,0.3,NaN]}',
+                '{"AC":[0.1,0.2,0.3,0.4]} x', '[]', '{}', '', '{"AC":[0.1,0.2,0.3,0.4,0.5]}', '{"A\\u0043":[0.1,0.2,0.3,0.4]}', '{"AC":[1e999,0,0,0]}',
+                '{"AC":[.5,0,0,0]}', '{"AC":[01,0,0,0]}', '{"AC":[1,0,0,0],}', '{"AC":{"x":1}}', '{"AC":[1,0,0,0]', '{"ac":[1,0,0,0]}']
+    for text in declined:
+        p = tmp_path / "d.json"
+        p.write_text(text)
+        assert lm._load_json_native(str(p)) is None, text
+    # ... and the standard route then speaks: the reference's ValueError for a non-ACGT key (bases.index, basecall.py:56)
+    p.write_text('{"ACGU":[0.1,0.2,0.3,0.4]}')
+    with pytest.raises(ValueError, match="is not in list"):
+        lm.load_json(str(p))

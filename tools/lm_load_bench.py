@@ -26,6 +26,13 @@ if not os.path.exists(path):
             f.write(("," if lo else "") + ",".join(f'"{c}": [{v[0]!r}, {v[1]!r}, {v[2]!r}, {v[3]!r}]' for c, v in zip(keys, vals[idx].tolist())))
         f.write("}")
     print(f"wrote {path}: {os.path.getsize(path) / 1e6:.0f} MB in {time.time() - t0:.1f} s", flush=True)
+# the library's one-pass reader first (peak RSS is a high-water mark: this leg must run before the object-tree leg)
+rss00 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024
+t0 = time.time()
+nat = lm._load_json_native(path)
+t_nat = time.time() - t0
+rss_nat = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024
+print(json.dumps({"native_reader_s": round(t_nat, 2), "peak_rss_MB": round(rss_nat), "rss_before_MB": round(rss00), "recognised": nat is not None}), flush=True)
 rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024
 t0 = time.time()
 with open(path) as f:
@@ -37,4 +44,4 @@ del raw
 rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024
 print(json.dumps({"k": kk, "contexts": int(table.shape[0]), "file_MB": round(os.path.getsize(path) / 1e6), "json_load_s": round(t1 - t0, 2),
                   "table_from_dict_s": round(t2 - t1, 2), "total_s": round(t2 - t0, 2), "peak_rss_MB": round(rss), "rss_before_MB": round(rss0),
-                  "missing": lm.n_missing(table)}))
+                  "missing": lm.n_missing(table), "native_equals_standard": bool(nat is not None and nat[1] == kk and nat[0].tobytes() == table.tobytes())}))
