@@ -1,0 +1,117 @@
+"""The product's N > 1 code with N > 1 on the one GPU that is reachable.
+
+Real RCCL refuses two ranks on one device, so on a one-GPU box tests/test_gpu_two_ranks.py can only show the ranks agreeing on the
+file transport.  Here the ranks find tests/standin_rccl.cpp (TEST INFRASTRUCTURE: the seven RCCL entry points the product resolves,
+with rccl.h's signatures and semantics, over a shared-memory segment) as `librccl.so.1` through LD_LIBRARY_PATH.  Everything on the
+product's side of the seam then runs as it will on the 8-GPU node: rd_rccl_unique_id on rank 0, the three-phase transport agreement
+(load, ncclCommInitRank, the watched first collective), rd_rccl_bcast_model with rank 0 as the sender and the OTHER ranks executing the
+receiver's half (header -> storage reserved and bound -> weight images -> LM table, entropies, sparse mask), the barriers and the
+max-reductions of the timed region, ncclCommCount -- and the receivers then basecall with what they received:
+  * `python bench.py --gpus 3`: one JSON line, startup_comm == "rccl", rccl_nranks == 3, every rank's step time;
+  * `python -m radian_amd.basecall ... --gpus 3`, chunk mode and global mode with an RNA model (dense, and sparse: the "absent" mask is
+    part of the broadcast image): FASTA identical to the single-process run, every worker reporting the rccl transport.
+What this does NOT show is RCCL itself (its transports over xGMI): that needs the 8-GPU node.
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def standin_env(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc is needed to build the stand-in library")
+    d = tmp_path_factory.mktemp("standin_rccl")
+    lib = d / "librccl.so.1"
+    r = subprocess.run([HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-I/opt/rocm/include", "-o", str(lib), os.path.join(ROOT, "tests", "standin_rccl.cpp")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0 and lib.exists(), r.stderr.decode()[-3000:]
+    env = dict(os.environ, PYTHONPATH=ROOT, LD_LIBRARY_PATH=str(d) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    env.pop("RD_BENCH_DEVICE", None)     # ranks map their local rank onto the one visible device themselves (backend.device_for_rank)
+    env.pop("RD_CLI_DEVICE", None)
+    return env
+
+
+def test_bench_three_ranks_broadcast_through_the_collective_seam(standin_env):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "4", "--warmup", "1", "--preheat-ms", "0", "--check"],
+                       env=standin_env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-4000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["startup_comm"] == "rccl" and d["rccl_nranks"] == 3, {k: d[k] for k in ("n_gpus", "startup_comm", "rccl_nranks")}
+    assert len(d["ms_per_step_per_rank"]) == 3 and all(x > 0 for x in d["ms_per_step_per_rank"])
+    assert abs(d["ms_per_step"] - max(d["ms_per_step_per_rank"])) < 1e-6 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+@pytest.mark.parametrize("mode,model", [("chunk", "none"), ("global", "dense"), ("global", "sparse")])
+def test_cli_three_ranks_receive_the_artefacts_by_broadcast(tmp_path, standin_env, monkeypatch, mode, model):
+    from radian_amd import fast5, synthetic
+    reads = synthetic.synthetic_reads(120, 3000, seed=5)
+    rng = np.random.default_rng(2)
+    in_dir = tmp_path / "in"
+    in_dir.mkdir()
+    for f in range(3):
+        lo, hi = [0, 30, 90][f], [30, 90, 120][f]
+        fast5.write_multi_fast5(str(in_dir / f"r{f}.fast5"), {f"{i:06d}": reads[i][: int(rng.integers(1200, 3000))] for i in range(lo, hi)})
+    from radian_amd import basecall, launch
+    k = 3
+    keys = ["".join("ACGT"[(i >> (2 * (k - 1 - j))) & 3] for j in range(k)) for i in range(4 ** k)]
+    table = rng.dirichlet([0.3] * 4, size=4 ** k)
+    dense = {c: [float(x) for x in table[i]] for i, c in enumerate(keys)}
+
+    def common_args(lm_path):
+        lm_args = ["--rna-model", "None"] if lm_path is None else ["--rna-model", lm_path, "--context-len", str(k), "--rna-threshold", "5.0",
+                                                                  "--sig-threshold", "0.0"]
+        return ["--decode-type", mode, "--step-size", "512", "--beam-width", "6", "--sig-model", "synthetic:1234", "--sig-config", "none",
+                "--queue-block", "16", "--gpu-batch-windows", "64"] + lm_args
+
+    def single(lm_path, tag):
+        out = tmp_path / f"out1_{tag}"
+        out.mkdir()
+        basecall.main([str(in_dir), str(out)] + common_args(lm_path))          # one process, no communicator
+        return open(out / "reads-0.fasta").read()
+
+    lm_path = None
+    if model != "none":
+        lm_path = str(tmp_path / "lm.json")
+        (tmp_path / "lm.json").write_text(json.dumps(dense))
+    a = single(lm_path, "dense")
+    if model == "sparse":
+        # remove a context no read's search reaches (the mask must travel with the broadcast; a read that reached it would raise on every
+        # route alike): candidates are the 3-mers that occur in no emitted sequence in either direction
+        seqs = [ln for ln in a.splitlines() if not ln.startswith(">")]
+        free = [c for c in keys if not any(c in sq or c[::-1] in sq for sq in seqs)]
+        assert free, "every 3-mer occurs in the output: pick other weights for this test"
+        for tries, c in enumerate(free[:6]):
+            sparse = dict(dense)
+            del sparse[c]
+            (tmp_path / "lm.json").write_text(json.dumps(sparse))
+            try:
+                a = single(lm_path, f"sparse{tries}")
+                break
+            except KeyError:
+                continue
+        else:
+            pytest.fail("every candidate context was reached by some read's search")
+    common = common_args(lm_path)
+    out3 = tmp_path / "out3"
+    out3.mkdir()
+    argv3 = [str(in_dir), str(out3)] + common + ["--gpus", "3"]
+    args3 = basecall.build_parser().parse_args(argv3)
+    monkeypatch.setenv("LD_LIBRARY_PATH", standin_env["LD_LIBRARY_PATH"])     # the ranks are children of this process
+    monkeypatch.delenv("RD_CLI_DEVICE", raising=False)
+    report = launch.run_multi_gpu(args3, argv3)
+    assert [r["transport"] for r in report["ranks"]] == ["rccl"] * 3, report
+    assert [r["device"] for r in report["ranks"]] == [0, 0, 0] or len({r["device"] for r in report["ranks"]}) == 3, report
+    b = open(out3 / "reads-0.fasta").read()
+    assert a == b and a.count(">") == 120 and report["records"] == 120
