@@ -115,3 +115,22 @@ def test_cli_three_ranks_receive_the_artefacts_by_broadcast(tmp_path, standin_en
     assert [r["device"] for r in report["ranks"]] == [0, 0, 0] or len({r["device"] for r in report["ranks"]}) == 3, report
     b = open(out3 / "reads-0.fasta").read()
     assert a == b and a.count(">") == 120 and report["records"] == 120
+
+
+def test_bench_under_the_drivers_own_launcher(standin_env):
+    """the round-end driver's command, rank for rank: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` (a foreign launcher: RANK / LOCAL_RANK / WORLD_SIZE come from it, the rendezvous
+    directory is named after its pid) -- two ranks, the collectives through the stand-in library: ONE JSON line on the job's stdout."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--preheat-ms", "0"]
+    r = subprocess.run(cmd, env=standin_env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-4000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["startup_comm"] == "rccl" and d["rccl_nranks"] == 2 and len(d["ms_per_step_per_rank"]) == 2
+    assert d["config"]["launcher"].startswith("foreign") and d["value"] > 0 and d["steps"] == 4 and d["warmup"] == 1
