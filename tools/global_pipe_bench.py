@@ -33,7 +33,9 @@ def main():
         d = be.dev_alloc(norm.nbytes); be.h2d(d, norm); bufs.append(d)
     off = np.arange(n + 1, dtype=np.int64) * L
     lab_off = np.ascontiguousarray(off[:-1])
-    ring = [(np.zeros(n * L + 1, np.uint8), np.zeros(n, np.int32)) for _ in range(40)]
+    lag = int(os.environ.get("LAG", "32"))          # submits the caller lets the pipeline run ahead before it waits for results
+    steps = int(os.environ.get("STEPS", "64"))
+    ring = [(np.zeros(n * L + 1, np.uint8), np.zeros(n, np.int32)) for _ in range(lag + 8)]
     groups = [int(a[1:]) for a in sys.argv[1:] if a.startswith('g') and a[1:].isdigit()] or [1, 2, 3, 4, 6, 8, 16]
     for group in groups:
         be.pipe_flush(); be.pipe_config(group)
@@ -41,12 +43,12 @@ def main():
             for i in range(k):
                 lab, ln = ring[i % len(ring)]
                 be.pipe_submit_reads_global(bufs[i % 4], off, n, 1024, 512, W, True, 0.5, 0.5, lab, lab_off, ln)
-                if i >= 32:
-                    be.pipe_progress(be.pipe_submitted() - 32)
+                if i >= lag:
+                    be.pipe_progress(be.pipe_submitted() - lag)
             be.pipe_flush(); be.sync()
         run(8)
-        t0 = time.perf_counter(); run(64); dt = time.perf_counter() - t0
-        print(f"group {group:2d}: {64 * n * L / dt / 1e6:6.2f} M samples/s  ({dt / 64 * 1e3:.2f} ms per {n}-read step, {dt / 64 / (n * L) * 1e9:.2f} ns per row)"
+        t0 = time.perf_counter(); run(steps); dt = time.perf_counter() - t0
+        print(f"group {group:2d}: {steps * n * L / dt / 1e6:6.2f} M samples/s  ({dt / steps * 1e3:.2f} ms per {n}-read step, {dt / steps / (n * L) * 1e9:.2f} ns per row)"
               f"   policy: {[(m, round(q['ns_per_row'], 1), round(q['us_per_step'], 2), q['rows_per_step']) for m in (1, 2, 3, 0) for q in [be.pipe_policy(W, m, True)]]}", flush=True)
     be.close()
 main()
