@@ -115,7 +115,10 @@ def load_json(path, native=True):
     """basecall.py:48-57.  Returns (table, k).  native: try the library's one-pass reader first (the 4^11-key model: ~2 s instead of
     ~25 s, no 2-GB object tree); any text it does not recognise goes through json.load + table_from_dict."""
     if native:
-        got = _load_json_native(path)
+        try:
+            got = _load_json_native(path)
+        except (OSError, ValueError, BufferError, MemoryError):     # (a file that cannot be mapped, a table that does not fit: the standard route reports)
+            got = None
         if got is not None:
             return got
     with open(path, "r") as f:
