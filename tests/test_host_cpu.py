@@ -624,3 +624,41 @@ def test_lm_json_native_reader_equals_the_standard_parser(tmp_path):
     p.write_text('{"ACGU":[0.1,0.2,0.3,0.4]}')
     with pytest.raises(ValueError, match="is not in list"):
         lm.load_json(str(p))
+
+
+def test_lm_json_reader_under_address_sanitizer(tmp_path):
+    """csrc/lmjson.hip is host code that walks untrusted text: compiled for the CPU with -fsanitize=address,undefined and fed 60 000
+    valid, mutated, truncated and random texts in exact-size heap buffers (no terminator), it must never read past an end."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    exe = tmp_path / "asan_lmjson"
+    r = subprocess.run(["g++", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-g", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__",
+                        "-I/opt/rocm/include", "-x", "c++", os.path.join(ROOT, "radian_amd", "csrc", "lmjson.hip"),
+                        os.path.join(ROOT, "tests", "asan_lmjson.cpp"), "-o", str(exe)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    if r.returncode != 0 and b"sanitize" in r.stderr and b"cannot find" in r.stderr:
+        pytest.skip("the sanitizer runtimes are not installed")
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    r = subprocess.run([str(exe), "60000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0 and b"no sanitizer report" in r.stdout, (r.stdout.decode()[-500:], r.stderr.decode()[-3000:])
+    accepted = int(r.stdout.split()[0])
+    assert 5000 < accepted < 40000          # the harness feeds both kinds
+
+
+def test_native_stitch_under_address_sanitizer(tmp_path):
+    """csrc/stitch.hip (simple_assembly + difflib restated, host threads) compiled for the CPU with -fsanitize=address,undefined: 20 000
+    random batches -- empty / repeated / shifted fragments, fragments of 200+ labels (autojunk), exact-size buffers, 1-3 threads."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    exe = tmp_path / "asan_stitch"
+    r = subprocess.run(["g++", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-g", "-O1", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__",
+                        "-I/opt/rocm/include", "-x", "c++", os.path.join(ROOT, "radian_amd", "csrc", "stitch.hip"),
+                        os.path.join(ROOT, "tests", "asan_stitch.cpp"), "-o", str(exe)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    if r.returncode != 0 and b"sanitize" in r.stderr and b"cannot find" in r.stderr:
+        pytest.skip("the sanitizer runtimes are not installed")
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    r = subprocess.run([str(exe), "20000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0 and b"no sanitizer report" in r.stdout, (r.stdout.decode()[-500:], r.stderr.decode()[-3000:])
