@@ -662,3 +662,23 @@ def test_native_stitch_under_address_sanitizer(tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     r = subprocess.run([str(exe), "20000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0 and b"no sanitizer report" in r.stdout, (r.stdout.decode()[-500:], r.stderr.decode()[-3000:])
+
+
+def test_tile_planner_properties_under_address_sanitizer(tmp_path):
+    """csrc/plan.hip -- the host code whose tile descriptors every forward kernel indexes HBM with -- compiled for the CPU with
+    -fsanitize=address,undefined and checked on 2500 random (model, read set, chunk, step) geometries: every sub-tile inside its segment,
+    every write inside the activation tensor and no row written twice within a layer, every sample / stream row a sub-tile reads existing,
+    every decoded sequence's rows inside the tensor (tests/asan_plan.cpp).  A violated property would be an out-of-bounds access on the GPU."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    exe = tmp_path / "asan_plan"
+    r = subprocess.run(["g++", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-g", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__",
+                        "-I/opt/rocm/include", "-x", "c++", os.path.join(ROOT, "radian_amd", "csrc", "plan.hip"),
+                        os.path.join(ROOT, "tests", "asan_plan.cpp"), "-o", str(exe)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    if r.returncode != 0 and b"sanitize" in r.stderr and b"cannot find" in r.stderr:
+        pytest.skip("the sanitizer runtimes are not installed")
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    r = subprocess.run([str(exe), "2500"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0 and b"every property holds" in r.stdout, (r.stdout.decode()[-800:], r.stderr.decode()[-3000:])
