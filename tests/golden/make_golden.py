@@ -547,6 +547,176 @@ def gen_pipeline():
     print("pipeline:", len(cases), "cases")
 
 
+# ----------------------------------------------------------------------------------------------
+# 8. beam_search at the geometries BASELINE.json names (round 5; VERDICT r4 "Missing 3"):
+#    (a) the reference's default context 11 (basecall.py:35) with a 4^11-entry model served lazily, on [4096,5] float64 matrices that the
+#        reference's own assemble_matrices built at chunk 1024 / step 512 and step 128, W in {6, 10, 25}; dense and sparse (KeyError)
+#    (b) no LM at W in {26, 40, 51, 64, 100} (the wide launch forms) at T in {8, 64, 1024}, and a 3-mer LM at those widths
+#    (c) float32 single-window reads with an LM, chosen so that numpy 1.19 and 2.x agree (see `entropy_margin`)
+# ----------------------------------------------------------------------------------------------
+class LazyLM(dict):
+    """An RNA model `{context tuple: [pA, pC, pG, pT]}` whose entries are materialised from a dense table when decode.py:83 first asks
+    for them (`model[context]` on a dict subclass calls __missing__), so that k = 11 needs no 4^11-entry dict.  A context listed in
+    `missing` raises the KeyError a plain dict without that key raises.  `if lm and ...` (decode.py:154,174) tests truthiness, and an
+    empty dict is falsy: one present context is stored up front, as any loaded model is non-empty."""
+
+    def __init__(self, table, k, missing=()):
+        super().__init__()
+        self._table, self._k, self._missing = table, k, frozenset(int(i) for i in missing)
+        first = next(i for i in range(table.shape[0]) if i not in self._missing)
+        ctx = tuple((first >> (2 * (k - 1 - j))) & 3 for j in range(k))
+        self[ctx] = [float(x) for x in table[first]]
+
+    def __missing__(self, ctx):
+        idx = 0
+        for c in ctx:
+            idx = idx * 4 + int(c)
+        if idx in self._missing:
+            raise KeyError(ctx)
+        v = [float(x) for x in self._table[idx]]
+        self[ctx] = v
+        return v
+
+
+def _final_json(final):
+    return [{"labeling": f_["labeling"], "pr_total": fenc(f_["pr_total"]), "pr_blank": fenc(f_["pr_blank"]),
+             "pr_non_blank": fenc(f_["pr_non_blank"])} for f_ in final]
+
+
+def _entropy_legacy(row32):
+    """decode.py:66-76 on a float32 row under the PINNED numpy 1.19 (requirements.txt:5): builtin sum() of np.float32 scalars starts from
+    int 0, and value-based casting makes 0 + float32 a float64, so the sum accumulates in float64; `dist / sum(dist)` stays float32 (the
+    float64 scalar is cast down); `p * math.log(p)` is float32 * Python float = float64.  Used only to measure how far each row's entropy
+    is from the threshold (the margin the case records); the expected strings come from the reference itself."""
+    s = 0.0
+    for p in row32[:-1]:
+        s += float(p)
+    if s == 0:
+        d = row32[:-1]
+    else:
+        d = (row32[:-1] / np.float32(s)).astype(np.float32)
+    e = 0.0
+    for p in d:
+        if p > 0:
+            e += float(p) * math.log(float(p))
+    return -e
+
+
+def gen_beam_baseline():
+    import time
+    sys.path.insert(0, os.path.dirname(HERE))
+    import _golden_lm
+    t_start = time.time()
+    rng = np.random.default_rng(20261006)
+    arrays, cases = {}, []
+    table = _golden_lm.k11_table()
+    k = _golden_lm.K11
+    meta = {"k11_seed": _golden_lm.K11_SEED, "k11_table_sha256": _golden_lm.table_sha256(table), "numpy": np.__version__}
+
+    # ---- (a) [4096,5] float64 from the reference's assemble_matrices, k = 11
+    mats = {}
+    for (step, kind) in ((512, "peaky"), (512, "flat"), (128, "peaky")):
+        windows, pad = ref_pre.get_windows(np.zeros(4096), 1024, step)
+        nW = windows.shape[0]
+        probs = np.stack([make_matrix(rng, 1024, kind, np.float32) for _ in range(nW)])
+        parts = [probs[i] for i in range(nW)]
+        parts[-1] = parts[-1][:-pad]                       # basecall.py:96
+        mat = ref_asm.assemble_matrices(parts, step)       # basecall.py:101
+        assert mat.shape == (4096, 5) and mat.dtype == np.float64
+        name = f"g{step}_{kind}"
+        arrays["probs_" + name] = probs
+        mats[name] = (mat, step, int(pad), kind)
+    for name, (mat, step, pad, kind) in mats.items():
+        for W in (6, 10, 25):
+            for (s_thr, r_thr) in ((0.5, 0.5), (0.0, math.inf)):
+                if kind == "flat" and W == 25 and s_thr == 0.0:
+                    continue
+                t0 = time.time()
+                seq, final = run_beam(mat, W, LazyLM(table, k), s_thr, r_thr, k, capture=True)
+                cases.append({"group": "global_k11", "probs": "probs_" + name, "chunk": 1024, "step": step, "pad": pad, "kind": kind, "T": 4096,
+                              "mat_sha256": _golden_lm.table_sha256(mat), "k": k, "W": W, "s_thr": fenc(s_thr), "r_thr": fenc(r_thr),
+                              "seq": seq, "final": _final_json(final[:8])})
+                print(f"  global_k11 {name} W={W} thr=({s_thr},{r_thr}) len={len(seq)} {time.time() - t0:.1f}s", flush=True)
+    # ---- sparse k = 11: the same matrices, models that lack a few contexts (listed by row index)
+    mrng = np.random.default_rng(20261007)
+    for name in ("g512_peaky", "g128_peaky"):
+        mat, step, pad, kind = mats[name]
+        for W in (6, 10):
+            for frac in (2e-6, 2e-5, 2e-4, 2e-3):
+                missing = sorted(int(x) for x in np.flatnonzero(mrng.random(4 ** k) < frac))
+                try:
+                    seq, _ = run_beam(mat, W, LazyLM(table, k, missing), 0.5, 0.5, k)
+                    outcome = {"seq": seq}
+                except KeyError as e:
+                    outcome = {"key_error": [int(x) for x in e.args[0]]}
+                cases.append({"group": "global_k11_sparse", "probs": "probs_" + name, "chunk": 1024, "step": step, "pad": pad, "kind": kind, "T": 4096,
+                              "k": k, "W": W, "s_thr": fenc(0.5), "r_thr": fenc(0.5), "missing": missing, **outcome})
+                print(f"  sparse {name} W={W} frac={frac} missing={len(missing)} -> {'KeyError' if 'key_error' in outcome else 'decodes'}", flush=True)
+
+    # ---- (b) wide beams without an LM, float32 (chunk-mode semantics), and with a 3-mer LM on float64
+    lm3, table3 = make_lm(rng, 3)
+    arrays["lm_k3"] = table3
+    cid = 0
+    for T in (8, 64, 1024):
+        for kind in ("flat", "peaky", "hard"):
+            if T == 1024 and kind == "hard":
+                continue
+            mat = make_matrix(rng, T, kind, np.float32)
+            name = f"w{cid}"
+            cid += 1
+            arrays[name] = mat
+            for W in ((26, 40, 51, 64, 100) if T <= 64 else (26, 40, 51, 64)):
+                seq, final = run_beam(mat, W, capture=T <= 64)
+                c = {"group": "wide_nolm", "mat": name, "T": T, "kind": kind, "W": W, "seq": seq}
+                if final is not None:
+                    c["final"] = _final_json(final)
+                cases.append(c)
+    for T, kind in ((64, "flat"), (64, "peaky"), (300, "peaky")):
+        mat = make_matrix(rng, T, kind, np.float64)
+        name = f"w{cid}"
+        cid += 1
+        arrays[name] = mat
+        for W in (26, 51, 64, 100):
+            for (s_thr, r_thr) in ((0.5, 0.5), (0.0, math.inf)):
+                seq, final = run_beam(mat, W, lm3, s_thr, r_thr, 3, capture=T <= 64)
+                c = {"group": "wide_lm", "mat": name, "lm": "lm_k3", "k": 3, "T": T, "kind": kind, "W": W, "s_thr": fenc(s_thr), "r_thr": fenc(r_thr),
+                     "seq": seq}
+                if final is not None:
+                    c["final"] = _final_json(final)
+                cases.append(c)
+
+    # ---- (c) float32 single-window reads (N < chunk_len: the matrix basecall.py:99-109 decodes stays float32) with an LM
+    for T, kind in ((300, "peaky"), (1000, "peaky"), (700, "flat")):
+        mat = make_matrix(rng, T, kind, np.float32)
+        name = f"s{cid}"
+        cid += 1
+        arrays[name] = mat
+        ent = np.array([_entropy_legacy(mat[t]) for t in range(T)])
+        ent_here = np.array([float(ref_decode.entropy(ref_decode.normalise(mat[t][:-1]))) for t in range(T)])
+        for (kk, lm_obj, lm_name) in ((3, lm3, "lm_k3"), (k, None, "k11")):
+            for W in (6, 10):
+                for (s_thr, r_thr) in ((0.5, 0.5), (0.5, 0.9), (1.0, math.inf)):
+                    margin = float(np.abs(ent - s_thr).min())
+                    assert margin > 1e-5 and np.array_equal(ent > s_thr, ent_here > s_thr), "pick another seed: a row's entropy sits on the threshold"
+                    model = lm_obj if lm_obj is not None else LazyLM(table, k)
+                    seq, final = run_beam(mat, W, model, s_thr, r_thr, kk, capture=True)
+                    cases.append({"group": "single_window_f32_lm", "mat": name, "lm": lm_name, "k": kk, "T": T, "kind": kind, "W": W,
+                                  "s_thr": fenc(s_thr), "r_thr": fenc(r_thr), "entropy_margin": margin, "seq": seq,
+                                  "winner_pr_total": fenc(final[0]["pr_total"])})
+    np.savez_compressed(os.path.join(HERE, "beam_baseline_mats.npz"), **arrays)
+    meta["source"] = ("radian/decode.py:79-96,100-212 + matrix_assembly.py:6-53 + basecall.py:35,96-109 at BASELINE.json's geometries; k = 11 model = "
+                      "tests/_golden_lm.k11_table() served through a dict subclass with __missing__; group single_window_f32_lm holds only cases whose "
+                      "per-row entropies stay `entropy_margin` away from s_thr, so numpy 1.19 (float64 entropies, the pinned version) and numpy 2.x "
+                      "(float32) take the same gate decisions; their winner_pr_total is the reference's under the numpy named in `numpy`")
+    meta["cases"] = cases
+    with open(os.path.join(HERE, "beam_baseline_cases.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+    by = {}
+    for c in cases:
+        by[c["group"]] = by.get(c["group"], 0) + 1
+    print("beam_baseline:", by, f"{time.time() - t_start:.0f}s")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:       # regenerate single fixture sets: make_golden.py gen_seq_assembly_random ...
         for name in sys.argv[1:]:
@@ -561,5 +731,6 @@ if __name__ == "__main__":
     gen_seq_assembly_random()
     gen_fast5_signals()
     gen_pipeline()
+    gen_beam_baseline()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE))
     print("total bytes in tests/golden:", tot)

@@ -361,3 +361,114 @@ def test_sparse_lm_reports_exactly_the_reads_the_reference_fails_on(be, golden_d
         be.load_lm(None, 0)
         be.set_decode_math("glibc")
         be.set_decode_form("auto")
+
+
+# ------------------------------------------------------------------------------ BASELINE.json's own geometries (round 5)
+def _baseline(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "beam_baseline_cases.json")))
+    return g, np.load(os.path.join(golden_dir, "beam_baseline_mats.npz"))
+
+
+def test_baseline_global_k11_assembled_4096_vs_reference(be, golden_dir):
+    """configs[3]'s decode against the imported reference directly (not through the oracle): the reference's window probabilities ->
+    rd_assemble -> [4096,5] float64 (bytes == matrix_assembly.assemble_matrices') -> beam search with the reference's default
+    context 11 (4^11-row table), W in {6, 10, 25}: labelings equal, the winner's pr_total bit-equal in glibc arithmetic."""
+    from _golden_lm import checked_k11_table, table_sha256
+    g, arr = _baseline(golden_dir)
+    table = checked_k11_table(g["k11_table_sha256"])
+    be.set_decode_math("glibc")
+    be.load_lm(table, g["cases"][0]["k"])
+    try:
+        mats, n = {}, 0
+        for c in g["cases"]:
+            if c["group"] != "global_k11":
+                continue
+            if c["probs"] not in mats:
+                m = be.assemble(arr[c["probs"]], c["pad"], c["step"])
+                assert m.dtype == np.float64 and table_sha256(m) == c["mat_sha256"]
+                mats[c["probs"]] = m
+            m = mats[c["probs"]]
+            (lab,), sc = be.decode_batch(m, [0], [m.shape[0]], c["W"], use_lm=True, s_threshold=fdec(c["s_thr"]), r_threshold=fdec(c["r_thr"]),
+                                         with_scores=True)
+            assert s_of(lab) == c["seq"], (c["probs"], c["W"], c["s_thr"])
+            assert sc[0] == fdec(c["final"][0]["pr_total"]), (c["probs"], c["W"], float(sc[0]).hex(), c["final"][0]["pr_total"])
+            n += 1
+        assert n == 17
+    finally:
+        be.load_lm(None, 0)
+
+
+def test_baseline_global_k11_sparse_vs_reference(be, golden_dir):
+    """12-mer models lacking 7 ... 8 572 contexts: RD_LEN_MISSING_CONTEXT exactly for the reads on which decode.py:83 raises KeyError."""
+    from _golden_lm import checked_k11_table, sparse_table
+    g, arr = _baseline(golden_dir)
+    table = checked_k11_table(g["k11_table_sha256"])
+    try:
+        n_err = 0
+        for c in g["cases"]:
+            if c["group"] != "global_k11_sparse":
+                continue
+            be.load_lm(sparse_table(table, c["missing"]), c["k"])
+            m = be.assemble(arr[c["probs"]], c["pad"], c["step"])
+            lab = be.decode(m, c["W"], use_lm=True, s_threshold=fdec(c["s_thr"]), r_threshold=fdec(c["r_thr"]))
+            if "key_error" in c:
+                assert lab is None, (c["probs"], c["W"], len(c["missing"]))
+                n_err += 1
+            else:
+                assert lab is not None and s_of(lab) == c["seq"], (c["probs"], c["W"], len(c["missing"]))
+        assert n_err == 8
+    finally:
+        be.load_lm(None, 0)
+
+
+def test_baseline_wide_beams_vs_reference(be, golden_dir):
+    """Beam widths 26 ... 100 against the imported reference: the four-wave launch form (26 ... 51) and the widths beyond it."""
+    g, arr = _baseline(golden_dir)
+    be.set_decode_math("glibc")
+    try:
+        n = 0
+        for c in g["cases"]:
+            if c["group"] not in ("wide_nolm", "wide_lm"):
+                continue
+            m = arr[c["mat"]]
+            if "lm" in c:
+                be.load_lm(arr[c["lm"]], c["k"])
+                (lab,), sc = be.decode_batch(m, [0], [m.shape[0]], c["W"], use_lm=True, s_threshold=fdec(c["s_thr"]), r_threshold=fdec(c["r_thr"]),
+                                             with_scores=True)
+            else:
+                be.load_lm(None, 0)
+                (lab,), sc = be.decode_batch(m, [0], [m.shape[0]], c["W"], with_scores=True)
+            assert s_of(lab) == c["seq"], (c["group"], c["mat"], c["W"])
+            if "final" in c:
+                exp = fdec(c["final"][0]["pr_total"])
+                assert sc[0] == exp or (np.isnan(exp) and np.isnan(sc[0])), (c["group"], c["mat"], c["W"], float(sc[0]).hex(), c["final"][0]["pr_total"])
+            n += 1
+        assert n == 62
+    finally:
+        be.load_lm(None, 0)
+
+
+def test_baseline_single_window_float32_lm_vs_reference(be, golden_dir):
+    """Reads shorter than one chunk in global mode (float32 matrix + LM), k = 3 and k = 11; cases are numpy-version-independent
+    (tests/golden/make_golden.py gen_beam_baseline, group single_window_f32_lm)."""
+    from _golden_lm import checked_k11_table
+    g, arr = _baseline(golden_dir)
+    table = checked_k11_table(g["k11_table_sha256"])
+    be.set_decode_math("glibc")
+    try:
+        cur, n = None, 0
+        for c in g["cases"]:
+            if c["group"] != "single_window_f32_lm":
+                continue
+            if cur != c["lm"]:
+                be.load_lm(table if c["lm"] == "k11" else arr[c["lm"]], c["k"])
+                cur = c["lm"]
+            m = arr[c["mat"]]
+            (lab,), sc = be.decode_batch(m, [0], [m.shape[0]], c["W"], use_lm=True, s_threshold=fdec(c["s_thr"]), r_threshold=fdec(c["r_thr"]),
+                                         with_scores=True)
+            assert s_of(lab) == c["seq"], (c["mat"], c["lm"], c["W"])
+            assert sc[0] == fdec(c["winner_pr_total"])
+            n += 1
+        assert n == 36
+    finally:
+        be.load_lm(None, 0)

@@ -216,3 +216,90 @@ def test_sparse_lm_matches_reference_key_errors(golden_dir, oracle):
                     assert g is None
                 else:
                     assert "".join("ACGT"[x] for x in g) == c["seq"]
+
+
+# ------------------------------------------------------------------------------ BASELINE.json's own geometries (round 5)
+def _baseline(golden_dir):
+    g = _load(golden_dir, "beam_baseline_cases.json")
+    return g, np.load(os.path.join(golden_dir, "beam_baseline_mats.npz"))
+
+
+def _check_final(final, exp_final, tag):
+    assert len(final) == len(exp_final), tag
+    for gf, exp in zip(final, exp_final):
+        assert gf[0] == exp["labeling"], tag
+        assert same_float(gf[1], fdec(exp["pr_total"])), tag
+        assert same_float(gf[2], fdec(exp["pr_blank"])), tag
+        assert same_float(gf[3], fdec(exp["pr_non_blank"])), tag
+
+
+def test_baseline_global_k11_assembled_4096(oracle, golden_dir):
+    """configs[3]'s decode as the reference runs it: windows -> pad trim -> assemble_matrices -> [4096,5] float64 -> beam search with the
+    default context 11 (4^11-entry model), W in {6, 10, 25}, thresholds 0.5/0.5 and gate-always-open.  Labelings and the 8 best final
+    entries' three scores bit-exact against the imported reference (VERDICT r4 Missing 3a)."""
+    from _golden_lm import checked_k11_table, table_sha256
+    g, arr = _baseline(golden_dir)
+    table = checked_k11_table(g["k11_table_sha256"])
+    cases = [c for c in g["cases"] if c["group"] == "global_k11"]
+    assert len(cases) == 17 and {c["W"] for c in cases} == {6, 10, 25} and {c["step"] for c in cases} == {512, 128}
+    mats = {}
+    for c in cases:
+        if c["probs"] not in mats:
+            mat = oracle.assemble_matrices(arr[c["probs"]], c["pad"], c["step"])
+            assert mat.dtype == np.float64 and mat.shape == (4096, 5)
+            assert table_sha256(mat) == c["mat_sha256"], "assembled matrix differs from the reference's assemble_matrices"
+            mats[c["probs"]] = mat
+        labels, final = oracle.beam_search_labels(mats[c["probs"]], c["W"], table, fdec(c["s_thr"]), fdec(c["r_thr"]), c["k"], max_final=len(c["final"]))
+        tag = (c["probs"], c["W"], c["s_thr"], c["r_thr"])
+        assert "".join(BASES[x] for x in labels) == c["seq"], tag
+        _check_final(final, c["final"], tag)
+
+
+def test_baseline_global_k11_sparse_models(oracle, golden_dir):
+    """The same matrices with 12-mer models that lack 7 ... 8 572 of the 4^11 contexts: KeyError exactly where decode.py:83 raises."""
+    from _golden_lm import checked_k11_table, sparse_table
+    g, arr = _baseline(golden_dir)
+    table = checked_k11_table(g["k11_table_sha256"])
+    cases = [c for c in g["cases"] if c["group"] == "global_k11_sparse"]
+    assert len(cases) == 16 and sum("key_error" in c for c in cases) == 8
+    for c in cases:
+        mat = oracle.assemble_matrices(arr[c["probs"]], c["pad"], c["step"])
+        args = (mat, BASES, c["W"], sparse_table(table, c["missing"]), fdec(c["s_thr"]), fdec(c["r_thr"]), c["k"])
+        if "key_error" in c:
+            with pytest.raises(KeyError):
+                oracle.beam_search(*args)
+        else:
+            assert oracle.beam_search(*args) == c["seq"], (c["probs"], c["W"], len(c["missing"]))
+
+
+def test_baseline_wide_beams(oracle, golden_dir):
+    """Beam widths 26 ... 100 (the reference takes any width, decode.py:145), without an LM on float32 and with a 3-mer LM on float64."""
+    g, arr = _baseline(golden_dir)
+    cases = [c for c in g["cases"] if c["group"] in ("wide_nolm", "wide_lm")]
+    assert {c["W"] for c in cases} == {26, 40, 51, 64, 100}
+    for c in cases:
+        lm = arr[c["lm"]] if "lm" in c else None
+        labels, final = oracle.beam_search_labels(arr[c["mat"]], c["W"], lm, fdec(c["s_thr"]) if lm is not None else 0.0,
+                                                  fdec(c["r_thr"]) if lm is not None else 0.0, c.get("k", 0), max_final=30)
+        tag = (c["group"], c["mat"], c["W"])
+        assert "".join(BASES[x] for x in labels) == c["seq"], tag
+        if "final" in c:
+            _check_final(final, c["final"], tag)
+
+
+def test_baseline_single_window_float32_with_lm(oracle, golden_dir):
+    """A read shorter than one chunk in global mode: the decoded matrix stays float32.  The cases keep every row's entropy at least
+    `entropy_margin` from s_thr, so the pinned numpy 1.19 (float64 entropies; what the oracle follows) and numpy 2.x (float32) decide the
+    gate alike and the labeling is version-independent; the winner's score is bit-exact as well (entropies only gate)."""
+    from _golden_lm import checked_k11_table
+    g, arr = _baseline(golden_dir)
+    table = checked_k11_table(g["k11_table_sha256"])
+    cases = [c for c in g["cases"] if c["group"] == "single_window_f32_lm"]
+    assert len(cases) == 36
+    for c in cases:
+        mat = arr[c["mat"]]
+        assert mat.dtype == np.float32 and c["entropy_margin"] > 1e-5
+        lm = table if c["lm"] == "k11" else arr[c["lm"]]
+        labels, final = oracle.beam_search_labels(mat, c["W"], lm, fdec(c["s_thr"]), fdec(c["r_thr"]), c["k"], max_final=1)
+        assert "".join(BASES[x] for x in labels) == c["seq"], (c["mat"], c["lm"], c["W"])
+        assert same_float(final[0][1], fdec(c["winner_pr_total"]))
