@@ -45,7 +45,8 @@ typedef struct rd_ctx rd_ctx;
 const char* rd_last_error(void);
 int rd_version(void);                 /* ABI version, currently 1 */
 int rd_device_count(int* n);          /* number of visible HIP devices */
-int rd_decode_max_width(void);        /* largest supported --beam-width (51) */
+int rd_decode_max_width(void);        /* largest supported --beam-width (1024; radian/decode.py:145 slices with any width) */
+int rd_decode_lane_width(void);       /* widths up to this (51) run on the wave-per-sequence kernels, wider ones on the general kernel */
 
 /* ---- context ------------------------------------------------------------------------------- */
 int rd_create(int device_id, rd_ctx** out);

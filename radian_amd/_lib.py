@@ -22,6 +22,7 @@ SIGNATURES = {
     "rd_version": (c_i, []),
     "rd_device_count": (c_i, [ctypes.POINTER(c_i)]),
     "rd_decode_max_width": (c_i, []),
+    "rd_decode_lane_width": (c_i, []),
     "rd_create": (c_i, [c_i, ctypes.POINTER(c_vp)]),
     "rd_destroy": (c_i, [c_vp]),
     "rd_sync": (c_i, [c_vp]),

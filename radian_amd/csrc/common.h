@@ -165,6 +165,7 @@ struct rd_ctx {
     int part_mode = -1;   // rd_set_decode_partition: -1 = chosen by beam width, 0 = off, k = k CUs per XCD
     int part_cus = 0;     // CUs per XCD the existing masked streams were created for (0: none exist)
     DevBuf ws_in, ws_probs, ws_mat, ws_seq, ws_nodes_child, ws_nodes_back, ws_labels, ws_misc;
+    DevBuf ws_wide, ws_wide_slot;   // beam widths above 51 (decode_wide.hip): per-sequence scratch block, per-trie-node slot map
     // pinned host staging
     void* h_stage = nullptr;
     size_t h_stage_cap = 0;
@@ -229,5 +230,8 @@ void rd_rpipe_destroy(rd_ctx* ctx);
 inline bool rd_decode_len_ok(int W, int64_t rows) { return 1 + (int64_t)W * rows < ((int64_t)1 << 29); }
 
 extern "C" int rd_decode_max_width(void);
+// decode_wide.hip: beam widths above the wave-per-sequence kernels' 51, up to RD_WIDE_MAX_W (40 W bytes of LDS for the ranking keys)
+constexpr int RD_WIDE_MAX_W = 1024;
+int rd_decode_wide_launch(rd_ctx* ctx, hipStream_t st, const void* decode_args, int ptype, int n_seq, int64_t total_nodes, bool lm);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

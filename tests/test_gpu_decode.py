@@ -472,3 +472,47 @@ def test_baseline_single_window_float32_lm_vs_reference(be, golden_dir):
         assert n == 36
     finally:
         be.load_lm(None, 0)
+
+
+def test_wide_beams_vs_oracle(be, oracle):
+    """Widths above the wave-per-sequence kernels' 51 (decode_wide.hip; the reference slices with any --beam-width, decode.py:145):
+    batches with empty / one-row / ragged sequences, float32 and float64 rows, exact-0 probabilities (ties), with a 3-mer LM (dense
+    and sparse), both arithmetics, against the oracle; the width where the two kernels meet (51 | 52) included."""
+    assert be._L.rd_decode_lane_width() == 51 and be.max_beam_width >= 1024
+    rng = np.random.default_rng(2026)
+    lens = [300, 0, 1, 64, 65, 129, 512, 7]
+    rows = []
+    for i, n in enumerate(lens):
+        z = rng.normal(size=(n, 5)) * (1.0 if i % 2 == 0 else 3.5)
+        m = softmax_rows(z)
+        if i % 3 == 2 and n:
+            m[rng.integers(0, n, size=max(1, n // 5)), rng.integers(0, 5)] = 0.0     # exact zeros: -inf scores and ties
+        rows.append(m)
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    table = rng.dirichlet([0.3] * 4, size=4 ** 3)
+    sparse = table.copy()
+    sparse[[5, 17, 40]] = np.nan
+    for math in ("glibc", "fast"):
+        be.set_decode_math(math)
+        for dtype in (np.float32, np.float64):
+            mats = np.concatenate(rows, axis=0).astype(dtype)
+            for W in (51, 52, 64, 100, 257, 1024):
+                if math == "fast" and W not in (52, 100):
+                    continue
+                be.load_lm(None, 0)
+                got = be.decode_batch(mats, off, lens, W)
+                exp = oracle.beam_search_batch(mats, off, lens, W)
+                for i in range(len(lens)):
+                    assert np.array_equal(got[i], exp[i]), (math, dtype, W, i, "no LM")
+                if W in (52, 100):
+                    for tb in (table, sparse):
+                        be.load_lm(tb, 3)
+                        got = be.decode_batch(mats, off, lens, W, use_lm=True, s_threshold=0.5, r_threshold=0.9)
+                        exp = oracle.beam_search_batch(mats, off, lens, W, tb, 0.5, 0.9, 3)
+                        for i in range(len(lens)):
+                            if exp[i] is None:
+                                assert got[i] is None, (math, dtype, W, i, "sparse")
+                            else:
+                                assert got[i] is not None and np.array_equal(got[i], exp[i]), (math, dtype, W, i, "LM")
+    be.load_lm(None, 0)
+    be.set_decode_math("glibc")
