@@ -104,6 +104,11 @@ int rd_load_weights(rd_ctx* ctx, const void* blob, size_t nbytes);
  * back as RD_LEN_MISSING_CONTEXT and every other read is unaffected.
  * Passing table == NULL unloads the LM. */
 int rd_load_lm(rd_ctx* ctx, const double* table, int k);
+/* --context-len k (1..13) with an RNA model whose keys have another length: the reference's `model[context]` (decode.py:83) then
+ * raises KeyError for EVERY context, i.e. on the first read whose search keeps a labeling of >= k labels before its last time step,
+ * after having basecalled the shorter reads before it (basecall.py:70-141).  Loads that model: every read that reaches such a
+ * labeling comes back as RD_LEN_MISSING_CONTEXT, every other read decodes as without an LM (no lookup ever succeeds). */
+int rd_load_lm_absent(rd_ctx* ctx, int k);
 /* Long contexts (--context-len up to 256; BASELINE configs[4]).  NO reference behaviour: the reference needs one dict
  * entry per context (decode.py:83), impossible beyond a dozen labels.  A synthetic LM for such contexts is a dense
  * table[4^table_order][4] addressed by a hash of the context: row = H(l_0..l_{k-1}) & (4^table_order - 1),
@@ -117,9 +122,10 @@ int rd_load_lm_hashed(rd_ctx* ctx, const double* table, int table_order, int con
 int rd_set_logits(rd_ctx* ctx, int mode);
 /* Launch shape of the beam search (no effect on results; no reference counterpart): 0 = chosen per launch (default).  Widths
  * above 12: several waves per sequence while the launch leaves SIMDs idle, else two candidates per lane; 1 / 2 pin either.
- * Widths up to 12: two sequences per wave -- always for widths up to 6 (the reference's default, basecall.py:32: one
- * candidate per lane of a half-wave), and for 7..12 (two candidates per lane) when the launch puts several waves on
- * every SIMD; 3 = two per wave whenever the width allows, 4 = one per wave.  For tests and measurements. */
+ * Widths up to 6 (the reference's default, basecall.py:32) run two sequences per wave (one candidate per lane of a half-wave);
+ * widths 7..12 run ONE sequence per wave under form 0 -- two per wave (two candidates per lane) exists and measured slower, so
+ * only form 3 selects it; 3 = two per wave whenever the width allows (up to 12), 4 = always one per wave.  Widths above
+ * rd_decode_lane_width() run on the general kernel whatever the form.  For tests and measurements. */
 int rd_set_decode_form(rd_ctx* ctx, int form);
 /* Decode partition of the global-mode reads pipeline (rd_pipe_submit_reads_global / rd_pipe_submit_raw_global; no effect on
  * results, no reference counterpart): cus_per_xcd CUs of each of the 8 XCDs are kept free of forward workgroups (the

@@ -32,6 +32,7 @@ SIGNATURES = {
     "rd_split3": (c_i, [c_vp, c_vp, c_sz, c_vp]),
     "rd_load_weights": (c_i, [c_vp, c_vp, c_sz]),
     "rd_load_lm": (c_i, [c_vp, c_vp, c_i]),
+    "rd_load_lm_absent": (c_i, [c_vp, c_i]),
     "rd_load_lm_hashed": (c_i, [c_vp, c_vp, c_i, c_i]),
     "rd_set_logits": (c_i, [c_vp, c_i]),
     "rd_set_decode_form": (c_i, [c_vp, c_i]),

@@ -172,6 +172,11 @@ class Backend:
         self._check(self._L.rd_load_lm(self._h, _p(table), int(k)))
         self.lm_k = k
 
+    def load_lm_absent(self, k):
+        """--context-len k with an RNA model whose keys have another length (rd_load_lm_absent): every lookup is the reference's KeyError."""
+        self._check(self._L.rd_load_lm_absent(self._h, int(k)))
+        self.lm_k = k
+
     def load_lm_hashed(self, table, table_order, context_len):
         """Synthetic LM for contexts longer than a dense table can index (rd_load_lm_hashed): table [4^table_order, 4],
         row = hash of the last `context_len` labels (<= 256)."""

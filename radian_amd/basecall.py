@@ -10,9 +10,16 @@ What differs (results do not): reads are batched ACROSS reads for the GPU (the f
 SURVEY F10), so `--batch-size` no longer sizes anything (`--gpu-batch-windows` bounds a device batch); windows are formed on the
 device and every time step is evaluated once (bit-identical to evaluating all windows, DESIGN.md section 4.6);
 `--rna-model None` disables the LM in global mode instead of crashing at decode.py:83; an RNA model that lacks some contexts
-loads, and a read whose beam search reaches an absent one raises the reference's KeyError when the driver gets to it; `--sig-model` also
+loads, and a read whose beam search reaches an absent one raises the reference's KeyError when the driver gets to it -- which is
+also what a --context-len that differs from the model's key length does (every context is absent; lazy like decode.py:83, for
+--context-len up to 13; longer ones raise at load); `--sig-config none` stands for sig2seq.yaml's dilations without a file (any other
+path must exist, as in utilities.get_config; so must --rna-model in both decode types, basecall.py:48-50); `--sig-model` also
 accepts `synthetic[:seed]` (seeded He-normal weights: the reference's sig2seq.h5 is not distributed with
 the source tree) and packed `.rdnw` blobs; extra flags `--device`, `--gpus`.
+One deliberate difference on failure with `--gpus N`: a single-GPU run (like the reference) leaves the reads before a failing one in
+reads-*.fasta; the multi-GPU merger (launch.StreamMerger) writes under a hidden directory and removes it when any rank fails -- the
+sparse-model KeyError included -- because ranks run ahead of each other and "the reads before the failing one" would be a set with
+holes.  A failed multi-GPU job therefore leaves NO reads-*.fasta rather than a valid-looking partial one.
 """
 import argparse
 import os
@@ -85,8 +92,10 @@ def build_parser():
 
 
 def load_dilations(sig_config):
-    """models/sig2seq.yaml `model.tcn` -> per-block dilations; checks the fixed geometry (sig2seq.yaml:34-49)."""
-    if not sig_config or not os.path.exists(sig_config):
+    """models/sig2seq.yaml `model.tcn` -> per-block dilations; checks the fixed geometry (sig2seq.yaml:34-49).  A path that does not
+    exist raises FileNotFoundError like utilities.get_config's open() (utilities.py:16-18, basecall.py:60); `--sig-config none` is this
+    CLI's explicit way of asking for sig2seq.yaml's dilations without a file."""
+    if not sig_config or sig_config.lower() == "none":
         return weights_mod.DEFAULT_DILATIONS
     import yaml
     with open(sig_config) as f:
@@ -230,7 +239,7 @@ def _read_ahead(pairs, max_reads=8192, max_samples=48 << 20, block=128):
     libhdf5: tools/host_feed_bench.py) overlaps the loop's batching and the finishing of earlier batches; every libhdf5 call of
     the process stays on this one thread.  Reads change hands in blocks of `block`: handing over every read makes the two
     threads fight for the interpreter lock at every ctypes call (measured: half the rate of no thread at all).  Order is
-    preserved; an exception of the producer is re-raised by the consumer."""
+    preserved; an exception of the producer is re-raised by the consumer at the position where it happened (every read before it is delivered first)."""
     import queue as queue_mod
     import threading
     q = queue_mod.Queue()
@@ -238,8 +247,8 @@ def _read_ahead(pairs, max_reads=8192, max_samples=48 << 20, block=128):
     state = {"reads": 0, "samples": 0, "stop": False}
 
     def produce():
+        blk, n_s = [], 0
         try:
-            blk, n_s = [], 0
             for key, read in pairs:
                 raw = np.asarray(read.get_raw_data())
                 blk.append((key, read.read_id, raw))
@@ -257,7 +266,9 @@ def _read_ahead(pairs, max_reads=8192, max_samples=48 << 20, block=128):
             if blk:
                 q.put((blk, n_s))
             q.put(None)
-        except BaseException as e:      # (handed to the consumer)
+        except BaseException as e:      # (handed to the consumer -- behind the reads that were read before it: the reference has
+            if blk:                     # basecalled and written every read ahead of the failing one, basecall.py:70-141)
+                q.put((blk, n_s))
             q.put(e)
         finally:
             close = getattr(pairs, "close", None)
@@ -474,13 +485,17 @@ def save_artifacts(art, directory):
     feeds the broadcast reads the arrays back instead of parsing again"""
     np.savez(os.path.join(directory, ARTIFACT_CACHE), dilations=np.asarray(art["dilations"], dtype=np.int64), weights=art["weights"],
              lm_table=art["lm_table"] if art["lm_table"] is not None else np.zeros((0, 4)), lm_k=art["lm_k"],
-             lm_hashed_order=art.get("lm_hashed_order", 0))
+             lm_hashed_order=art.get("lm_hashed_order", 0), lm_absent=art.get("lm_absent", 0))
 
 
 def load_artifacts(args, cache_dir=None):
     """Host-only half of basecall.py:47-62: parse / validate the signal model and (global mode) the RNA model.
-    Returns {"dilations", "weights", "lm_table", "lm_k"}; raises what the reference would (KeyError for a context
-    length that does not match the RNA model, FileNotFoundError for a missing file) before any GPU is touched.
+    Returns {"dilations", "weights", "lm_table", "lm_k"}; raises what the reference would before any GPU is touched: FileNotFoundError
+    for a --rna-model (in EITHER decode type: basecall.py:48-50 opens it unconditionally) or --sig-config file that does not exist.
+    A --context-len that differs from the model's key length is NOT an error here: the reference fails lazily, with KeyError at
+    decode.py:83 on the first read whose beam search keeps a labeling of context-len labels, after basecalling the shorter reads before
+    it -- art["lm_absent"] asks for exactly that model (Backend.load_lm_absent); beyond 13 labels, where no dense image exists, the
+    KeyError comes at load instead.
     cache_dir: where the launcher left its parse of the same arguments (save_artifacts)."""
     if cache_dir is not None and os.path.exists(os.path.join(cache_dir, ARTIFACT_CACHE)):
         with np.load(os.path.join(cache_dir, ARTIFACT_CACHE)) as z:
@@ -488,24 +503,28 @@ def load_artifacts(args, cache_dir=None):
                    "lm_table": z["lm_table"] if z["lm_table"].shape[0] else None, "lm_k": int(z["lm_k"])}
             if int(z["lm_hashed_order"]):
                 art["lm_hashed_order"] = int(z["lm_hashed_order"])
+            if "lm_absent" in z.files and int(z["lm_absent"]):
+                art["lm_absent"] = int(z["lm_absent"])
         return art
     dil = load_dilations(args.sig_config)
     art = {"dilations": dil, "weights": load_sig_model(args.sig_model, dil), "lm_table": None, "lm_k": 0}
     if args.rna_model != "None":
-        if os.path.exists(args.rna_model):
-            table, k = lm_mod.load_json(args.rna_model)
-            if args.decode_type == "global":
-                if k != args.context_len and getattr(args, "lm_hashed_context", False):
-                    if not (k < args.context_len <= 256):   # (a shorter context has a dense table of its own: not what the flag is for)
-                        raise ValueError(f"--lm-hashed-context: --context-len must be longer than the RNA model's {k}-label contexts, at most 256")
-                    art["lm_table"], art["lm_k"], art["lm_hashed_order"] = table, args.context_len, k
-                    return art
-                if k != args.context_len:
+        if not os.path.exists(args.rna_model):
+            raise FileNotFoundError(2, "No such file or directory", args.rna_model)   # basecall.py:49, whatever --decode-type says
+        table, k = lm_mod.load_json(args.rna_model)
+        if args.decode_type == "global":
+            if k != args.context_len and getattr(args, "lm_hashed_context", False):
+                if not (k < args.context_len <= 256):   # (a shorter context has a dense table of its own: not what the flag is for)
+                    raise ValueError(f"--lm-hashed-context: --context-len must be longer than the RNA model's {k}-label contexts, at most 256")
+                art["lm_table"], art["lm_k"], art["lm_hashed_order"] = table, args.context_len, k
+                return art
+            if k != args.context_len:
+                if not 1 <= args.context_len <= 13:
                     raise KeyError(f"--context-len {args.context_len} does not match the RNA model's context length {k} "
                                    "(the reference fails with KeyError at decode.py:83)")
-                art["lm_table"], art["lm_k"] = table, k
-        elif args.decode_type == "global":
-            raise FileNotFoundError(args.rna_model)
+                art["lm_absent"], art["lm_k"] = args.context_len, args.context_len
+                return art
+            art["lm_table"], art["lm_k"] = table, k
     return art
 
 
@@ -522,7 +541,10 @@ def apply_artifacts(args, be, art, clone_from=None):
         return
     be.load_weights(art["weights"], art["dilations"])
     args._lm_loaded = False
-    if art["lm_table"] is not None:
+    if art.get("lm_absent"):
+        be.load_lm_absent(art["lm_absent"])
+        args._lm_loaded = True
+    elif art["lm_table"] is not None:
         if art.get("lm_hashed_order"):
             be.load_lm_hashed(art["lm_table"], art["lm_hashed_order"], art["lm_k"])
         else:

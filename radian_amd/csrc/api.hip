@@ -556,6 +556,31 @@ extern "C" int rd_load_lm(rd_ctx* ctx, const double* table, int k)
     return load_lm_table(ctx, table, k, k, 0);
 }
 
+// An RNA model none of whose keys has k characters: `model[context]` (decode.py:83) raises KeyError for every context of k labels.  The
+// image is an ordinary sparse one -- every row absent, every gate bit closed (entropy NaN compares false) -- filled on the device.
+extern "C" int rd_load_lm_absent(rd_ctx* ctx, int k)
+{
+    RD_REQUIRE(ctx, "rd_load_lm_absent: null context");
+    RD_REQUIRE(k >= 1 && k <= 13, "rd_load_lm_absent: context length %d out of range [1,13]", k);
+    LM& lm = ctx->lm;
+    lm.loaded = false;
+    lm.gate_valid = false;
+    RD_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << (2 * k);
+    lm.k = k;
+    lm.table_order = k;
+    lm.hashed = 0;
+    lm.sparse = 1;
+    if (lm.storage.reserve(lm_image_doubles(k) * sizeof(double))) return RD_ERR_NOMEM;
+    lm_bind(lm);
+    RD_HIP(hipMemset(lm.table, 0, n * 4 * sizeof(double)));
+    RD_HIP(hipMemset(lm.d_entropy, 0xff, n * sizeof(double)));                  // NaN: `entropy < r_threshold` is false
+    RD_HIP(hipMemset(lm.d_missing, 0xff, ((n + 63) / 64) * sizeof(double)));
+    RD_HIP(hipDeviceSynchronize());
+    lm.loaded = true;
+    return RD_OK;
+}
+
 extern "C" int rd_load_lm_hashed(rd_ctx* ctx, const double* table, int table_order, int context_len)
 {
     RD_REQUIRE(ctx && table, "rd_load_lm_hashed: null argument");

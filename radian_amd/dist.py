@@ -146,8 +146,8 @@ def _allgather_by_max(comm, value):
 class RcclComm:
     """RCCL communicator owned by the Backend's rd_ctx (created by connect(): every rank has one, or none has)."""
 
-    def __init__(self, be, rank, world):
-        self.be, self.rank, self.world = be, rank, world
+    def __init__(self, be, rank, world, rdv=None):
+        self.be, self.rank, self.world, self.rdv = be, rank, world, rdv
 
     def barrier(self):
         self.be.rccl_barrier()
@@ -155,12 +155,33 @@ class RcclComm:
     def allreduce_max(self, values):
         return self.be.rccl_allreduce_max(values)
 
-    def bcast_artifacts(self, be, load_fn, timeout=600.0):
-        """rank 0 loads + repacks weights / LM, then one broadcast puts the device images on every rank.  The broadcast runs on a
-        helper thread under a deadline: a rank that a peer left alone inside the collective (its load failed, it ran out of memory)
-        raises StartupFailed(stuck=True) instead of waiting for ever; an error of this rank's own call is re-raised as it is."""
+    def bcast_artifacts(self, be, load_fn, timeout=600.0, load_timeout=3600.0):
+        """rank 0 loads + repacks weights / LM, then one broadcast puts the device images on every rank.  Two watched phases:
+        (1) the load: rank 0 publishes "loaded" (ok / fail) through the rendezvous when load_fn has returned; the others wait for that
+        mark under `load_timeout` WITHOUT entering the collective -- a slow parse on rank 0 (the 420 MB JSON through the fallback parser
+        on a cold filesystem) does not eat the broadcast's deadline, and a load that fails leaves nobody inside a collective;
+        (2) the broadcast, on a helper thread under `timeout` counted from the mark: a rank that a peer left alone inside the
+        collective raises StartupFailed(stuck=True) instead of waiting for ever; an error of this rank's own call is re-raised as it is."""
         if self.rank == 0:
-            load_fn(be)
+            try:
+                load_fn(be)
+            except BaseException as e:
+                if self.rdv is not None:
+                    self.rdv.publish("loaded", f"fail: {type(e).__name__}: {e}")
+                raise
+            if self.rdv is not None:
+                self.rdv.publish("loaded", "ok")
+        elif self.rdv is not None:
+            t0 = time.time()
+            while True:
+                mark = self.rdv.peek("loaded").get(0)
+                if mark is not None:
+                    break
+                if time.time() - t0 > load_timeout:
+                    raise StartupFailed(f"rank {self.rank}: rank 0 did not finish loading the artefacts within {load_timeout:.0f} s")
+                time.sleep(0.01)
+            if mark.startswith("fail"):
+                raise StartupFailed(f"rank {self.rank}: rank 0 failed to load the artefacts ({mark[5:].strip()}); nothing to receive")
         box = {}
 
         def run():
@@ -323,7 +344,7 @@ def connect(be, rank, world, uid_file, allow_file_fallback=True, timeout=120.0, 
                         pass
                 break
         if not errors:
-            return RcclComm(be, rank, world), "rccl"
+            return RcclComm(be, rank, world, rdv), "rccl"
     msg = "RCCL start-up failed on " + "; ".join(errors)
     if not allow_file_fallback:
         raise RuntimeError(msg)

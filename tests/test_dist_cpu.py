@@ -457,3 +457,53 @@ def test_host_feed_dry_run_rate_floor(tmp_path):
             ids += [ln[1:].strip() for ln in f if ln.startswith(">")]
     exp = [f"{fi:03d}-{i:07d}" for fi in range(3) for i in range(2667 if fi < 2 else 2666)]
     assert ids == exp
+
+
+def test_rccl_bcast_waits_for_rank0_load_outside_the_collective(tmp_path):
+    """RcclComm.bcast_artifacts: the receivers wait for rank 0's "loaded" mark WITHOUT entering the broadcast and start the
+    broadcast's deadline there -- a load slower than that deadline is fine; a load that fails leaves no rank inside a collective (the
+    receivers raise StartupFailed(stuck=False), rank 0 re-raises its own error); a rank 0 that never finishes runs into load_timeout."""
+    import threading
+    import time
+    from radian_amd import dist
+
+    class FakeBackend:
+        def __init__(self):
+            self.bcasts = 0
+
+        def rccl_bcast_model(self, root):
+            self.bcasts += 1
+
+    def run(load, **kw):
+        d = tmp_path / f"rdv{len(os.listdir(tmp_path))}"
+        bes = [FakeBackend(), FakeBackend()]
+        out = [None, None]
+
+        def rank(r):
+            comm = dist.RcclComm(bes[r], r, 2, dist.Rendezvous(str(d), r, 2))
+            try:
+                comm.bcast_artifacts(bes[r], load, **kw)
+                out[r] = "ok"
+            except BaseException as e:
+                out[r] = e
+
+        ths = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(30)
+        return out, bes
+
+    # a load that takes longer than the broadcast's own deadline
+    out, bes = run(lambda b: time.sleep(0.6), timeout=0.3, load_timeout=10.0)
+    assert out == ["ok", "ok"] and [b.bcasts for b in bes] == [1, 1]
+
+    def boom(b):
+        raise FileNotFoundError("models/rnamodel_12mer_pc.json")
+    out, bes = run(boom, timeout=5.0, load_timeout=10.0)
+    assert isinstance(out[0], FileNotFoundError)
+    assert isinstance(out[1], dist.StartupFailed) and not out[1].stuck and "rnamodel_12mer_pc.json" in str(out[1])
+    assert [b.bcasts for b in bes] == [0, 0]
+    # rank 0 stalls inside its load: the receiver gives up on the load's own deadline, still outside the collective
+    out, bes = run(lambda b: time.sleep(1.5), timeout=5.0, load_timeout=0.3)
+    assert isinstance(out[1], dist.StartupFailed) and not out[1].stuck and "did not finish loading" in str(out[1]) and bes[1].bcasts == 0

@@ -326,3 +326,43 @@ def test_cli_sparse_rna_model_fails_like_the_reference(tmp_path, golden_dir, ora
                            "--step-size", "512", "--sig-threshold", "0.0", "--rna-threshold", "9.0"] + extra)
         got = _read_fasta(str(out))
         assert got == [(ids[i], "".join("ACGT"[x] for x in full[i])[::-1]) for i in range(bad[0])]
+
+
+def test_cli_context_len_mismatch_fails_lazily_like_the_reference(tmp_path, golden_dir, oracle):
+    """--context-len 5 with a model of 3-character keys: the reference loads it (basecall.py:48-57), basecalls every read whose beam
+    search never keeps a labeling of 5 labels -- no lookup is ever made, so as without an LM -- and dies with KeyError at decode.py:83 on the
+    first read that does (a tuple of 5 labels is no key of the dict).  Here: the same reads in the FASTA, then the KeyError; the expectation
+    is the oracle's with a 5-label model that holds no context at all, on the GPU's own probabilities."""
+    from radian_amd import Backend, basecall, fast5, weights
+    ids, sig, _, lm_path = _make_inputs(tmp_path, golden_dir, k=3)
+    rng = np.random.default_rng(5)
+    reads = {"00000000-short-a": np.round(rng.normal(500, 80, size=6)).astype(np.int16),
+             "00000000-short-b": np.round(rng.normal(500, 80, size=9)).astype(np.int16)}
+    reads.update({r: sig[r] for r in ids[:2]})
+    order = sorted(reads)       # (a multi-read fast5 iterates its groups in name order)
+    in_dir = tmp_path / "mixed"
+    in_dir.mkdir()
+    fast5.write_multi_fast5(str(in_dir / "reads.fast5"), reads)
+    flat = weights.synthetic_weights(seed=1234).copy()
+    flat[-645:-5] *= np.float32(0.05)          # soft head: labelings of hundreds of bases on the long reads
+    wpath = str(tmp_path / "soft.rdnw")
+    open(wpath, "wb").write(weights.pack_blob(flat))
+    be = Backend(0)
+    be.load_weights(flat)
+    absent = np.full((4 ** 5, 4), np.nan)
+    exp = []
+    for r in order:
+        win, pad = oracle.get_windows(oracle.mad_normalise(reads[r], 4), 1024, 512)
+        mat = oracle.assemble_matrices(be.forward(np.asarray(win, dtype=np.float32)), pad, 512)
+        lab = oracle.beam_search_batch(mat, [0], [mat.shape[0]], 6, absent, 0.5, 0.5, 5)[0]
+        exp.append(None if lab is None else (r, "".join("ACGT"[c] for c in lab)[::-1]))
+    be.close()
+    first_bad = next(i for i, e in enumerate(exp) if e is None)
+    assert first_bad == 2, "the two short reads decode, the first long one reaches a 5-label labeling"
+    for extra in ([], ["--no-pipeline"]):
+        out = tmp_path / ("c" + str(len(extra)))
+        out.mkdir()
+        with pytest.raises(KeyError, match="decode.py:83"):
+            basecall.main([str(in_dir), str(out), "--sig-model", wpath, "--sig-config", "none", "--rna-model", lm_path, "--context-len", "5",
+                           "--step-size", "512"] + extra)
+        assert _read_fasta(str(out)) == exp[:first_bad]

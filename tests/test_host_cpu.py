@@ -470,10 +470,28 @@ def test_default_artifact_route_host_half(tmp_path, monkeypatch):
     write_cfg(dilations=[1, 2, 4, 8])
     with pytest.raises(ValueError, match="weight tensors"):
         basecall.load_artifacts(args)
-    # the reference's default --context-len (11) against this 2-label model: decode.py:83's KeyError, raised at load
+    # the reference's default --context-len (11) against this 2-label model: decode.py:83 raises KeyError lazily, on the first read
+    # whose search keeps a labeling of 11 labels -- the artefacts ask for the model in which every 11-label context is absent
     write_cfg(nb_stacks=2, dilations=[1, 2, 4])
-    with pytest.raises(KeyError):
-        basecall.load_artifacts(basecall.build_parser().parse_args(["in", "out"]))
+    art = basecall.load_artifacts(basecall.build_parser().parse_args(["in", "out"]))
+    assert art["lm_absent"] == 11 and art["lm_k"] == 11 and art["lm_table"] is None
+    basecall.save_artifacts(art, str(tmp_path))
+    back = basecall.load_artifacts(None, cache_dir=str(tmp_path))
+    assert back["lm_absent"] == 11 and back["lm_table"] is None and np.array_equal(back["weights"], w)
+    with pytest.raises(KeyError):      # no dense image beyond 13 labels: there the KeyError comes at load
+        basecall.load_artifacts(basecall.build_parser().parse_args(["in", "out", "--context-len", "14"]))
+    # start-up failures like the reference's: a --sig-config that does not exist (utilities.py:16-18 opens it), an --rna-model that
+    # does not exist in EITHER decode type (basecall.py:48-50 opens it before the decode type matters)
+    with pytest.raises(FileNotFoundError):
+        basecall.load_artifacts(basecall.build_parser().parse_args(["in", "out", "--context-len", "2", "--sig-config", "models/nope.yaml"]))
+    for mode in ("global", "chunk"):
+        with pytest.raises(FileNotFoundError) as ei:
+            basecall.load_artifacts(basecall.build_parser().parse_args(["in", "out", "--decode-type", mode, "--rna-model", "models/nope.json"]))
+        assert ei.value.filename == "models/nope.json"
+    # ... and the explicit ways of running without either file stay: --sig-config none, --rna-model None
+    art = basecall.load_artifacts(basecall.build_parser().parse_args(["in", "out", "--decode-type", "chunk", "--rna-model", "None", "--sig-config", "none",
+                                                                       "--sig-model", "synthetic:3"]))
+    assert art["lm_table"] is None and art["dilations"] == weights.DEFAULT_DILATIONS
 
 
 def test_driver_raises_reference_keyerror_at_the_read_that_reaches_a_missing_context(oracle, capsys):
@@ -563,7 +581,7 @@ def test_read_ahead_preserves_order_bounds_memory_and_propagates_errors():
     with pytest.raises(OSError, match="disk on fire"):
         for k, _, _ in basecall._read_ahead(source(300, boom_at=137), block=16):
             seen.append(k)
-    assert seen == list(range(137 - 137 % 16))   # (whole blocks before the failing one; the failing block is not delivered)
+    assert seen == list(range(137))   # (every read before the failing one, the partly filled block included: basecall.py:70-141)
 
 
 def test_artifact_cache_roundtrip_for_multi_gpu_ranks(tmp_path):
