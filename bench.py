@@ -346,6 +346,9 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))   # this process is the launcher; it never touches a GPU
     args.gpus = world
+    # host budget before the first GPU call (radian_amd/hostbudget.py): each rank on its own slice of the usable cores, NUMA-local to its GPU
+    from radian_amd import hostbudget
+    host_budget = hostbudget.apply(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
 
     from radian_amd import Backend, weights, synthetic
     from radian_amd.backend import RD_TIMER_CONV, RD_TIMER_DECODE, RD_TIMER_HEAD
@@ -732,6 +735,7 @@ def main():
             # multi-GPU evidence: the transport every rank agreed on, the communicator size as RCCL reports it
             # (ncclCommCount; on the file transport: ranks that answered an exchange), every rank's own ms per step
             "startup_comm": comm_kind, "rccl_nranks": rccl_nranks, "ms_per_step_per_rank": per_rank_ms,
+            "host_budget_rank0": {"cores": len(host_budget["cpus"]), "split": host_budget["how"], "bound": host_budget["bound"], "numa_node": host_budget["numa_node"]},
         }
         out.update(sec)
         if cpu is not None:

@@ -81,6 +81,10 @@ def build_parser():
     parser.add_argument("--stitch-workers", default=None, type=int,
                         help="chunk mode: host threads of the native fragment stitch (default: the usable cores - 2, at most 16); with "
                              "--no-pipeline: worker processes of the pure-Python stitch (default min(4, cores / 4); 0: on the driver's thread)")
+    parser.add_argument("--cpu-affinity", default="auto", choices=["auto", "none"],
+                        help="--gpus N: auto = every rank binds itself, before its first GPU call, to an even share of the usable cores -- NUMA-local "
+                             "to its GPU when /sys tells -- and sizes its threads from that share (radian_amd/hostbudget.py); none = stay where the "
+                             "launcher put the process")
     parser.add_argument("--queue-block", default=256, type=int,
                         help="--gpus N: reads per claim of the per-node work queue (0: static round-robin by read index)")
     parser.add_argument("--gpu-batch-windows", default=None, type=int,
@@ -135,7 +139,11 @@ class FastaWriter:
         self.f = open(f"{fasta_dir}/reads-{self.n}.fasta", "w")
 
     def write(self, read_id, sequence):
-        self.f.write(f">{read_id}\n{sequence[::-1]}\n")  # reversed to be 5' to 3' (basecall.py:129)
+        self.write_final(read_id, sequence[::-1])  # reversed to be 5' to 3' (basecall.py:129)
+
+    def write_final(self, read_id, sequence):
+        """a record whose sequence is already 5' to 3' (the multi-GPU ranks reverse before they hand over)"""
+        self.f.write(f">{read_id}\n{sequence}\n")
         self.i += 1
         if self.i == 1000:
             self.f.close()

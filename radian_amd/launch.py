@@ -20,8 +20,8 @@ class StreamMerger:
     merged afterwards would add seconds behind ~20 s of 8-GPU compute).
 
     A rank's file is a sequence of lines in the order things happen on that rank: {"claim": [file, lo, hi]} when it takes a
-    block from the work queue, [key, read_id, sequence] per finished read (increasing key: results leave the driver in
-    input order), {"end": true} last.  A record with key m can be written as soon as no rank can still produce a smaller
+    block from the work queue, one line per finished read -- "R<key>\\t<read_id>\\t<sequence>", or the JSON list [key, read_id,
+    sequence] for a read id that does not fit that form -- (increasing key: results leave the driver in input order), {"end": true} last.  A record with key m can be written as soon as no rank can still produce a smaller
     key: a rank with parsed-but-unwritten records is represented by the first of them; one without is bounded from below
     by the first key it may still produce -- the next expected read of its oldest unfinished claim (a claim is finished
     when a record of a later claim, or the end mark, shows up: skipped reads leave no record), else its latest key.
@@ -62,7 +62,12 @@ class StreamMerger:
         for ln in lines:
             if not ln:
                 continue
-            o = json.loads(ln)
+            if ln[:1] == b"R":     # a result in the compact form _RankFile writes: R <file>,<read> \t read_id \t sequence as the FASTA holds it
+                kf, rid, seq = ln[1:].decode("ascii").split("\t")
+                a, _, b = kf.partition(",")
+                o = [(int(a), int(b)) if b else (int(a),), rid, seq, True]
+            else:
+                o = json.loads(ln)
             if isinstance(o, dict):
                 if "claim" in o:
                     fi, lo, hi = o["claim"]
@@ -78,7 +83,7 @@ class StreamMerger:
             if cl:
                 cl[0][1] = key[1] + 1
             self.last[r] = key
-            self.recs[r].append((key, o[1], o[2]))
+            self.recs[r].append((key, o[1], o[2], len(o) > 3))
 
     def _bound(self, r):
         """no record that rank r has not handed over yet can have a key below this"""
@@ -103,11 +108,21 @@ class StreamMerger:
             for r in range(self.world):
                 if self.recs[r] and (best is None or bounds[r] < bounds[best]):
                     best = r
-            if best is None or any(bounds[r] < bounds[best] for r in range(self.world) if r != best):
+            if best is None:
                 return
-            _, rid, seq = self.recs[best].popleft()
-            self.writer.write(rid, seq)
-            self.n += 1
+            limit = min((bounds[r] for r in range(self.world) if r != best), default=self.INF)
+            if limit < bounds[best]:
+                return
+            # nothing the other ranks can still produce sorts before `limit`, and their state does not change while this rank's
+            # records are written: hand over the whole run up to it (one bounds computation per run of a rank, not per record)
+            q = self.recs[best]
+            while q and not (limit < q[0][0]):
+                _, rid, seq, final = q.popleft()
+                if final:
+                    self.writer.write_final(rid, seq)      # (the rank has reversed it already)
+                else:
+                    self.writer.write(rid, seq)
+                self.n += 1
 
     def finish(self):
         """every worker has exited: read what is left, write it, close the FASTA.  -> number of records written"""
@@ -180,8 +195,12 @@ def run_ranks(world, cmd, env_extra=None, capture_rank0=False, on_poll=None):
     import threading
     procs, chunks = [], []
     for rank in range(world):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **(env_extra or {}))
+        # numpy's BLAS starts a pool of one idle thread per core of the NODE at import, before the rank can bind itself to its slice
+        # (hostbudget.py); nothing in a rank calls BLAS
+        env.setdefault("OPENBLAS_NUM_THREADS", "1")
+        env.setdefault("MKL_NUM_THREADS", "1")
         out = None
         if capture_rank0:
             out = subprocess.PIPE if rank == 0 else sys.stderr
@@ -245,7 +264,11 @@ class _RankFile:
 
     def emit(self, key, rid, seq):
         with self.lock:
-            self.f.write(json.dumps([list(key) if isinstance(key, tuple) else key, rid, seq]) + "\n")
+            if "\t" in rid or "\n" in rid or not rid.isascii():     # (not a fast5 read id; the JSON form carries anything)
+                self.f.write(json.dumps([list(key) if isinstance(key, tuple) else key, rid, seq]) + "\n")
+            else:   # compact form: 8 ranks x 27 M samples/s are ~53 k records/s for the merging parent to parse
+                kf = ",".join(str(int(x)) for x in key) if isinstance(key, tuple) else str(int(key))
+                self.f.write(f"R{kf}\t{rid}\t{seq[::-1]}\n")    # (reversed here, on the rank: 5' to 3' as basecall.py:129 writes it)
             now = time.time()
             if now - self.t > 0.1:
                 self.f.flush()
@@ -274,6 +297,20 @@ def run_rank(args, be, comm, scratch, sources, rank, world, stitch_pool=None, ba
     return queue
 
 
+def rank_budget(args, local_rank, local_world):
+    """Host budget of one rank, BEFORE any GPU call or thread (hostbudget.py holds the placement rule): bind to this rank's slice of the
+    usable cores -- NUMA-local to its GPU when the topology is readable -- and size the threads that scale (the chunk-mode stitch) from
+    the slice, never from the node: eight ranks on 64 cores run 8 x 6 stitch threads, not 8 x 16.  Fills args.stitch_workers when the
+    user left it open.  -> the plan (cpus, how, bound, numa_node, cores_for_threads)."""
+    from . import hostbudget
+    budget = hostbudget.apply(local_rank, local_world, getattr(args, "cpu_affinity", "auto"))
+    n_mine = len(budget["cpus"]) if (budget["bound"] or budget["how"] != "all") else max(1, len(budget["cpus"]) // max(1, local_world))
+    budget["cores_for_threads"] = n_mine
+    if args.stitch_workers is None and args.decode_type == "chunk":
+        args.stitch_workers = (min(4, max(1, n_mine // 4)) if args.no_pipeline else hostbudget.threads_for(n_mine, "chunk")["stitch_threads"])
+    return budget
+
+
 def worker(scratch, argv):
     from . import fast5
     from .backend import Backend
@@ -281,6 +318,7 @@ def worker(scratch, argv):
     from .dist import StartupFailed, connect, env_rank_world, uid_path
     args = build_parser().parse_args(argv)
     rank, local_rank, world = env_rank_world()
+    budget = rank_budget(args, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     pool = make_stitch_pool(args.stitch_workers) if args.decode_type == "chunk" and args.no_pipeline else None   # before the GPU is touched
     from .backend import device_for_rank
     device = int(os.environ["RD_CLI_DEVICE"]) if "RD_CLI_DEVICE" in os.environ else device_for_rank(local_rank)   # (override: rehearsals on a 1-GPU box)
@@ -309,7 +347,8 @@ def worker(scratch, argv):
     with open(os.path.join(scratch, "files.json")) as f:
         sources = [fast5.Fast5Source(p) for p in json.load(f)]
     with open(os.path.join(scratch, f"contexts{rank}.json"), "w") as f:
-        json.dump({"device": device, "contexts": len(backends), "transport": kind}, f)   # (what the worker-route test reads)
+        json.dump({"device": device, "contexts": len(backends), "transport": kind, "cpus": budget["cpus"], "cpu_split": budget["how"],
+                   "cpu_bound": budget["bound"], "numa_node": budget["numa_node"], "stitch_workers": args.stitch_workers}, f)   # (what the worker-route tests read)
     run_rank(args, be, comm, scratch, sources, rank, world, stitch_pool=pool, backends=backends)
     comm.close()
     for b in reversed(backends):

@@ -111,7 +111,8 @@ def test_cli_worker_path_with_rccl_single_rank(tmp_path, golden_dir):
     assert len(_read_fasta(str(b_dir))) == 5
     # the worker honours --device-contexts like the single-GPU CLI: the further contexts are filled by rd_clone_artifacts
     # from the one that received the broadcast; the one-rank communicator is RCCL's
-    assert report["ranks"] == [{"device": 0, "contexts": 2, "transport": "rccl"}], report
+    assert [{k: r[k] for k in ("device", "contexts", "transport")} for r in report["ranks"]] == [{"device": 0, "contexts": 2, "transport": "rccl"}], report
+    assert report["ranks"][0]["cpu_split"] == "all" and not report["ranks"][0]["cpu_bound"]      # one rank: the whole node is its budget
     assert report["records"] == 5
 
 

@@ -7,8 +7,8 @@ product's side of the seam then runs as it will on the 8-GPU node: rd_rccl_uniqu
 (load, ncclCommInitRank, the watched first collective), rd_rccl_bcast_model with rank 0 as the sender and the OTHER ranks executing the
 receiver's half (header -> storage reserved and bound -> weight images -> LM table, entropies, sparse mask), the barriers and the
 max-reductions of the timed region, ncclCommCount -- and the receivers then basecall with what they received:
-  * `python bench.py --gpus 3`: one JSON line, startup_comm == "rccl", rccl_nranks == 3, every rank's step time;
-  * `python -m radian_amd.basecall ... --gpus 3`, chunk mode and global mode with an RNA model (dense, and sparse: the "absent" mask is
+  * `python bench.py --gpus 5`: one JSON line, startup_comm == "rccl", rccl_nranks == 5, every rank's step time;
+  * `python -m radian_amd.basecall ... --gpus 5`, chunk mode and global mode with an RNA model (dense, and sparse: the "absent" mask is
     part of the broadcast image): FASTA identical to the single-process run, every worker reporting the rccl transport.
 What this does NOT show is RCCL itself (its transports over xGMI): that needs the 8-GPU node.
 """
@@ -41,20 +41,30 @@ def standin_env(tmp_path_factory):
     return env
 
 
-def test_bench_three_ranks_broadcast_through_the_collective_seam(standin_env):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "4", "--warmup", "1", "--preheat-ms", "0", "--check"],
+# Ranks per rehearsal.  The 8-GPU node runs eight; a GPU box of this pool allows SIX processes on its card at once (gpurun's process guard,
+# which ends the run beyond that) and the pytest process itself holds a context, so FIVE ranks is the largest job a test may start here.
+# Nothing in the product's start-up depends on the count beyond what 5 > 2 exercises (rank 0 sends, four ranks execute the receiver's half,
+# the work queue deals blocks to five claimants, the merger interleaves five streams); eight ranks run on the CPU (tests/test_dist_cpu.py).
+WORLD = 5
+
+
+def test_bench_five_ranks_broadcast_through_the_collective_seam(standin_env):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(WORLD), "--steps", "4", "--warmup", "1", "--preheat-ms", "0", "--check"],
                        env=standin_env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-4000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 3 and d["startup_comm"] == "rccl" and d["rccl_nranks"] == 3, {k: d[k] for k in ("n_gpus", "startup_comm", "rccl_nranks")}
-    assert len(d["ms_per_step_per_rank"]) == 3 and all(x > 0 for x in d["ms_per_step_per_rank"])
+    assert d["n_gpus"] == WORLD and d["startup_comm"] == "rccl" and d["rccl_nranks"] == WORLD, {k: d[k] for k in ("n_gpus", "startup_comm", "rccl_nranks")}
+    assert len(d["ms_per_step_per_rank"]) == WORLD and all(x > 0 for x in d["ms_per_step_per_rank"])
+    hb = d["host_budget_rank0"]      # every rank bound itself to its share of the cores before its first GPU call (radian_amd/hostbudget.py)
+    usable = len(os.sched_getaffinity(0))
+    assert hb["split"] in ("numa", "even") and (not hb["bound"] or hb["cores"] <= max(1, usable // WORLD + 1)), (hb, usable)
     assert abs(d["ms_per_step"] - max(d["ms_per_step_per_rank"])) < 1e-6 and d["value"] > 0 and d["scaling"] == "weak"
 
 
 @pytest.mark.parametrize("mode,model", [("chunk", "none"), ("global", "dense"), ("global", "sparse")])
-def test_cli_three_ranks_receive_the_artefacts_by_broadcast(tmp_path, standin_env, monkeypatch, mode, model):
+def test_cli_five_ranks_receive_the_artefacts_by_broadcast(tmp_path, standin_env, monkeypatch, mode, model):
     from radian_amd import fast5, synthetic
     reads = synthetic.synthetic_reads(120, 3000, seed=5)
     rng = np.random.default_rng(2)
@@ -106,13 +116,20 @@ def test_cli_three_ranks_receive_the_artefacts_by_broadcast(tmp_path, standin_en
     common = common_args(lm_path)
     out3 = tmp_path / "out3"
     out3.mkdir()
-    argv3 = [str(in_dir), str(out3)] + common + ["--gpus", "3"]
+    argv3 = [str(in_dir), str(out3)] + common + ["--gpus", str(WORLD)]
     args3 = basecall.build_parser().parse_args(argv3)
     monkeypatch.setenv("LD_LIBRARY_PATH", standin_env["LD_LIBRARY_PATH"])     # the ranks are children of this process
     monkeypatch.delenv("RD_CLI_DEVICE", raising=False)
     report = launch.run_multi_gpu(args3, argv3)
-    assert [r["transport"] for r in report["ranks"]] == ["rccl"] * 3, report
-    assert [r["device"] for r in report["ranks"]] == [0, 0, 0] or len({r["device"] for r in report["ranks"]}) == 3, report
+    assert [r["transport"] for r in report["ranks"]] == ["rccl"] * WORLD, report
+    assert [r["device"] for r in report["ranks"]] == [0] * WORLD or len({r["device"] for r in report["ranks"]}) == WORLD, report
+    # the host budget every rank took before its first GPU call: disjoint core slices; chunk mode's stitch threads sized from the slice
+    cpus = [r["cpus"] for r in report["ranks"]]
+    usable = len(os.sched_getaffinity(0))
+    if usable >= WORLD:
+        assert all(r["cpu_bound"] for r in report["ranks"]) and len({c for cs in cpus for c in cs}) == sum(len(cs) for cs in cpus) <= usable, report
+    if mode == "chunk":
+        assert sum(r["stitch_workers"] for r in report["ranks"]) <= max(WORLD, usable), report
     b = open(out3 / "reads-0.fasta").read()
     assert a == b and a.count(">") == 120 and report["records"] == 120
 

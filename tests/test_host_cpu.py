@@ -700,3 +700,79 @@ def test_tile_planner_properties_under_address_sanitizer(tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     r = subprocess.run([str(exe), "2500"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0 and b"every property holds" in r.stdout, (r.stdout.decode()[-800:], r.stderr.decode()[-3000:])
+
+
+def test_host_budget_placement_rule(tmp_path):
+    """radian_amd/hostbudget.py: every local rank gets a disjoint, contiguous share of the usable cores -- the cores of
+    its GPU's NUMA node when the (fake) sysfs tells -- and sizes its threads from the share: eight chunk-mode ranks on 64 cores start 8 x 6
+    stitch threads, not 8 x 16."""
+    from radian_amd import hostbudget as hb
+    assert hb.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and hb.parse_cpulist("") == []
+    # a fake two-socket node: 64 cores (0-31 | 32-63), eight GPUs, four per socket; one CPU-only KFD node in front
+    sysfs = tmp_path / "sys"
+    for n, cl in ((0, "0-31"), (1, "32-63")):
+        d = sysfs / "devices" / "system" / "node" / f"node{n}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cl + "\n")
+    top = sysfs / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    (top / "0").mkdir(parents=True)
+    (top / "0" / "properties").write_text("cpu_cores_count 64\nsimd_count 0\n")
+    for g in range(8):
+        (top / str(g + 1)).mkdir()
+        bus = 0x10 + g * 0x10
+        (top / str(g + 1) / "properties").write_text(f"simd_count 1024\nlocation_id {bus << 8}\ndomain 0\n")
+        pd = sysfs / "bus" / "pci" / "devices" / f"0000:{bus:02x}:00.0"
+        pd.mkdir(parents=True)
+        (pd / "numa_node").write_text(f"{0 if g < 4 else 1}\n")
+    assert hb.gpu_numa_nodes(str(sysfs)) == [0, 0, 0, 0, 1, 1, 1, 1]
+    plans = [hb.plan(r, 8, usable=range(64), gpu_nodes=hb.gpu_numa_nodes(str(sysfs)), sysfs=str(sysfs)) for r in range(8)]
+    assert all(p["how"] == "numa" and len(p["cpus"]) == 8 for p in plans)
+    assert [p["cpus"][0] for p in plans] == [0, 8, 16, 24, 32, 40, 48, 56] and [p["numa_node"] for p in plans] == [0] * 4 + [1] * 4
+    assert sorted(c for p in plans for c in p["cpus"]) == list(range(64))                      # disjoint, nothing left over
+    assert hb.threads_for(8, "chunk")["stitch_threads"] == 6 and hb.threads_for(8, "global")["stitch_threads"] == 0
+    assert sum(hb.threads_for(len(p["cpus"]), "chunk")["total"] for p in plans) <= 2 * 64      # <= 10 threads per rank, most of them waiting
+    # a cgroup that only allows 20 cores of socket 0 and 4 of socket 1: still NUMA-local where every rank gets a core
+    usable = list(range(4, 24)) + [40, 41, 42, 43]
+    plans = [hb.plan(r, 8, usable=usable, gpu_nodes=[0, 0, 0, 0, 1, 1, 1, 1], sysfs=str(sysfs)) for r in range(8)]
+    assert all(p["how"] == "numa" for p in plans) and [len(p["cpus"]) for p in plans] == [5, 5, 5, 5, 1, 1, 1, 1]
+    assert sorted(c for p in plans for c in p["cpus"]) == usable
+    # fewer usable cores on a node than ranks on it: the even split for EVERY rank (mixed rules could overlap)
+    plans = [hb.plan(r, 8, usable=list(range(0, 32)) + [40, 41], gpu_nodes=[0, 0, 0, 0, 1, 1, 1, 1], sysfs=str(sysfs)) for r in range(8)]
+    assert all(p["how"] == "even" for p in plans) and sorted(c for p in plans for c in p["cpus"]) == list(range(32)) + [40, 41]
+    # no topology: even split; one rank: everything; the container this test runs in, whatever it is
+    plans = [hb.plan(r, 3, usable=range(8), gpu_nodes=None) for r in range(3)]
+    assert [p["cpus"] for p in plans] == [[0, 1], [2, 3, 4], [5, 6, 7]] and plans[0]["how"] == "even"
+    assert hb.plan(0, 1, usable=range(8))["how"] == "all"
+    here = [hb.plan(r, 2) for r in range(2)]
+    assert not set(here[0]["cpus"]) & set(here[1]["cpus"]) and here[0]["cpus"] and here[1]["cpus"]
+    # HIP_VISIBLE_DEVICES re-orders the devices a rank sees
+    import os
+    old = os.environ.get("HIP_VISIBLE_DEVICES")
+    os.environ["HIP_VISIBLE_DEVICES"] = "4,5"
+    try:
+        assert hb._visible_order(8) == [4, 5]
+    finally:
+        if old is None:
+            del os.environ["HIP_VISIBLE_DEVICES"]
+        else:
+            os.environ["HIP_VISIBLE_DEVICES"] = old
+
+
+def test_apply_binds_a_child_rank_to_its_slice():
+    """hostbudget.apply in a fresh process (the worker's first act): rank 1 of 2 ends up bound to the upper half of what it could use, and a
+    thread-count default that reads sched_getaffinity (sequence_assembly.consensus_batch) follows the slice."""
+    import subprocess
+    import sys
+    code = ("import os, json; from radian_amd import hostbudget as hb; before = sorted(os.sched_getaffinity(0)); p = hb.apply(1, 2); "
+            "print(json.dumps({'before': before, 'after': sorted(os.sched_getaffinity(0)), 'plan': p['cpus'], 'bound': p['bound']}))")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr
+    import json
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    if len(d["before"]) < 2:
+        pytest.skip("one usable core")
+    assert d["bound"] and d["after"] == d["plan"] == d["before"][len(d["before"]) // 2:]
+    code = code.replace("hb.apply(1, 2)", "hb.apply(1, 2, 'none')")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert not d["bound"] and d["after"] == d["before"]

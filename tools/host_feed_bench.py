@@ -6,8 +6,12 @@
            launch.run_ranks -> per-node FileReadQueue claims -> Fast5Source parsing -> basecall.run's batching / pipeline tickets ->
            rank result streams -> launch.StreamMerger -> FASTA rotation.  What it reports is the rate at which the HOST side of
            the node could feed and drain its GPUs: reads/s, samples/s, and per worker process.
+  merger   launch.StreamMerger alone: N rank result files with 2-kb sequences written beforehand, merged into the FASTA layout
 usage: host_feed_bench.py read [n_reads=16384] [len=4096]
-       host_feed_bench.py ranks [world=8] [n_reads=100000] [len=4096] [files=8] [mode=global|chunk]"""
+       host_feed_bench.py ranks [world=8] [n_reads=100000] [len=4096] [files=8] [mode=global|chunk]
+       host_feed_bench.py merger [world=8] [n_records=200000] [seq_len=2048]
+Every worker of `ranks` takes its host budget exactly as launch.worker does (launch.rank_budget: core slice + thread counts) and reports
+the threads it had alive at its busiest."""
 import json, os, shutil, sys, tempfile, time
 import numpy as np
 R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -92,12 +96,31 @@ def worker(scratch, argv):
     from radian_amd.basecall import build_parser
     from radian_amd.dist import env_rank_world
     args = build_parser().parse_args(argv)
-    rank, _, world = env_rank_world()
+    rank, local_rank, world = env_rank_world()
+    budget = launch.rank_budget(args, local_rank, world)        # the first act of a rank, as in launch.worker
     args._lm_loaded = False
+    import threading
+    peak = {"threads": 0}
+    stop = threading.Event()
+
+    def census():
+        while not stop.wait(0.05):
+            try:
+                tids = os.listdir("/proc/self/task")
+                if len(tids) - 1 > peak["threads"]:
+                    peak["threads"] = len(tids) - 1   # (minus this census thread)
+                    peak["names"] = sorted(n_.name for n_ in threading.enumerate()) + sorted(open(f"/proc/self/task/{t}/comm").read().strip() for t in tids if os.path.exists(f"/proc/self/task/{t}/comm"))
+            except OSError:
+                pass
+    threading.Thread(target=census, daemon=True).start()
     with open(os.path.join(scratch, "files.json")) as f:
         sources = [fast5.Fast5Source(p) for p in json.load(f)]
     sys.stdout = open(os.devnull, "w")      # (the per-read "Basecalled read ..." lines: the CLI prints them; a job redirects them)
     launch.run_rank(args, NullBackend(), NullComm(), scratch, sources, rank, world)
+    stop.set()
+    with open(os.path.join(scratch, f"budget{rank}.json"), "w") as f:
+        json.dump({"cpus": budget["cpus"], "split": budget["how"], "bound": budget["bound"], "stitch_workers": args.stitch_workers,
+                   "peak_threads": peak["threads"], "names": peak.get("names")}, f)
 
 
 def bench_ranks(world, n_reads, length, n_files, mode, keep=None):
@@ -120,7 +143,15 @@ def bench_ranks(world, n_reads, length, n_files, mode, keep=None):
         assert not any(rcs), rcs
         written = merger.finish()
         dt = time.perf_counter() - t0
-        res = {"world": world, "mode": mode, "reads": n, "samples_per_read": length, "cores": os.cpu_count(), "seconds": round(dt, 2),
+        budgets = [json.load(open(os.path.join(scratch, f"budget{r}.json"))) for r in range(world)]
+        if os.environ.get("RD_FEED_VERBOSE"):
+            print(budgets[0]["names"], file=sys.stderr)
+        usable = len(os.sched_getaffinity(0))
+        res = {"world": world, "mode": mode, "reads": n, "samples_per_read": length, "cores": os.cpu_count(), "usable_cores": usable,
+               "cores_per_rank": [len(b["cpus"]) for b in budgets], "cpu_split": budgets[0]["split"], "bound": all(b["bound"] for b in budgets),
+               "slices_disjoint": len({c for b in budgets for c in b["cpus"]}) == sum(len(b["cpus"]) for b in budgets),
+               "stitch_threads_per_rank": [b["stitch_workers"] for b in budgets], "stitch_threads_total": sum((b["stitch_workers"] or 0) for b in budgets),
+               "peak_threads_per_rank": [b["peak_threads"] for b in budgets], "seconds": round(dt, 2),
                "merge_after_last_rank_s": round(dt - t_ranks, 2), "records": written, "reads_per_s": round(n / dt),
                "M_samples_per_s": round(n * length / dt / 1e6, 1), "M_samples_per_s_per_rank": round(n * length / dt / 1e6 / world, 1),
                "fasta_files": len([x for x in os.listdir(out_dir) if x.startswith("reads-")])}
@@ -131,10 +162,44 @@ def bench_ranks(world, n_reads, length, n_files, mode, keep=None):
             shutil.rmtree(d, ignore_errors=True)
 
 
+def bench_merger(world, n_records, seq_len):
+    """StreamMerger alone: the eight ranks' result streams exist already (round-robin blocks of 256 reads over the ranks, as the work
+    queue deals them), sequences of seq_len bases; time poll-until-done + finish.  Target (VERDICT r4 #2c): >= 60 k records/s with 2-kb
+    sequences = 8 x 27 M samples/s / 4096 samples per read."""
+    from radian_amd import launch
+    d = tempfile.mkdtemp(prefix="rd_merge_", dir="/dev/shm" if os.path.isdir("/dev/shm") and os.environ.get("RD_MERGE_ON_DISK") is None else None)
+    try:   # (memory-backed by default: the container's overlay disk adds 2-3x run-to-run noise that is not the merger's)
+        scratch, out_dir = os.path.join(d, "scratch"), os.path.join(d, "out")
+        os.makedirs(scratch)
+        os.makedirs(out_dir)
+        rng = np.random.default_rng(0)
+        seq = "".join("ACGT"[i] for i in rng.integers(0, 4, size=seq_len))
+        files = [launch._RankFile(os.path.join(scratch, f"rank{r}.jsonl")) for r in range(world)]
+        block = 256
+        for b0 in range(0, n_records, block):
+            r = (b0 // block) % world
+            files[r].claim(0, b0, min(n_records, b0 + block))
+            for i in range(b0, min(n_records, b0 + block)):
+                files[r].emit((0, i), f"read-{i:08d}", seq)
+        for f in files:
+            f.end()
+        t0, c0 = time.perf_counter(), time.process_time()
+        m = launch.StreamMerger(scratch, world, out_dir)
+        n = m.finish()
+        dt, dc = time.perf_counter() - t0, time.process_time() - c0
+        assert n == n_records
+        print(json.dumps({"merger_alone": {"world": world, "records": n, "seq_len": seq_len, "seconds": round(dt, 2), "cpu_seconds": round(dc, 2), "records_per_s": round(n / dt),
+                                           "MB_per_s": round(n * (seq_len + 16) / dt / 1e6), "fasta_files": len(os.listdir(out_dir))}}))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 if __name__ == "__main__":
     a = sys.argv[1:]
     if a and a[0] == "--worker":
         worker(a[1], a[3:])
+    elif a and a[0] == "merger":
+        bench_merger(int(a[1]) if len(a) > 1 else 8, int(a[2]) if len(a) > 2 else 200000, int(a[3]) if len(a) > 3 else 2048)
     elif a and a[0] == "read":
         bench_read(int(a[1]) if len(a) > 1 else 16384, int(a[2]) if len(a) > 2 else 4096)
     else:
