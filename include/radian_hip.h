@@ -33,7 +33,8 @@ extern "C" {
 #define RD_ERR_STATE (-3) /* call order (e.g. forward before weights) */
 #define RD_ERR_NOMEM (-4) /* device allocation failed */
 #define RD_ERR_RCCL (-5)  /* RCCL error / librccl not loadable */
-#define RD_ERR_FORMAT (-6) /* rd_lm_json_*: the text is not of the one shape the fast reader handles (no verdict: use a full JSON parser) */
+#define RD_ERR_FORMAT (-6) /* rd_lm_json_* / rd_fast5_*: the input is not of the one shape the fast reader handles (no verdict: use the full parser / libhdf5) */
+#define RD_ERR_IO (-7)     /* rd_fast5_open: the file cannot be opened or mapped */
 /* Not an error code: the value of label_len[i] for a sequence whose beam search looked up a context that a SPARSE RNA model
  * does not hold (rd_load_lm, rows of NaN).  The reference raises KeyError at radian/decode.py:83 on such a read; the caller
  * does the same when it reaches that read (radian_amd/basecall.py).  The sequence's labels are not written. */
@@ -323,6 +324,29 @@ int rd_pipe_submitted(rd_ctx* ctx, int64_t* submitted);
  * converted correctly rounded and locale-independently (the double Python's float() gives).  No GPU is touched, no context is needed. */
 int rd_lm_json_probe(const char* buf, size_t n, int* k_out);
 int rd_lm_json_fill(const char* buf, size_t n, int k, double* table, int64_t* n_entries, int64_t* n_contexts);
+
+/* ---- the step before the hot path, on the HOST's cores: raw signals out of fast5 files, in batches --
+ * radian/basecall.py:7,70-76: `get_fast5_file(path).get_reads()`, `read.read_id`, `read.get_raw_data()` (int16 DAQ values, unscaled).
+ * A handle indexes one file's reads in ont_fast5_api's order -- multi-read: the root's `read_<id>` groups by name, signal at Raw/Signal;
+ * single-read: the groups of /Raw/Reads, id = the group's `read_id` attribute (else its name) -- over a read-only mapping of the file, walking
+ * the CLASSIC HDF5 layout (superblock 0/1, version-1 object headers, symbol-table or compact-link groups, contiguous / compact / chunked
+ * int16 datasets without filters: what libhdf5's defaults write, and what radian/data/reads.fast5 is) with every access bounds-checked.
+ *   rd_fast5_open / rd_fast5_open_mem (the caller keeps buf alive and unchanged) / rd_fast5_close
+ *   rd_fast5_count       reads of the file
+ *   rd_fast5_lengths     samples of reads [lo, hi): sizes the block for ...
+ *   rd_fast5_read_batch  reads [lo, hi) copied back to back into samples (capacity cap), offsets[hi - lo + 1] = where each starts (the
+ *                        last entry = the total); ids (nullable): the read ids, NUL-terminated, id_stride bytes apart.
+ * Anything else in the file (newer superblock / object headers, fractal-heap groups, compressed signals such as VBZ or gzip, another sample
+ * type, variable-length string ids, an address outside the file) returns RD_ERR_FORMAT and decides nothing: the caller reads the file
+ * through libhdf5, whose errors are then the verdict.  ~2 us per 4096-sample read on one core (libhdf5: ~63); no GPU is touched, no
+ * context is needed, a handle is used by one thread at a time. */
+typedef struct rd_fast5 rd_fast5;
+int rd_fast5_open(const char* path, rd_fast5** out);
+int rd_fast5_open_mem(const void* buf, size_t n, rd_fast5** out);
+void rd_fast5_close(rd_fast5* f);
+int rd_fast5_count(const rd_fast5* f, int64_t* n_reads);
+int rd_fast5_lengths(rd_fast5* f, int64_t lo, int64_t hi, int64_t* n_samples);
+int rd_fast5_read_batch(rd_fast5* f, int64_t lo, int64_t hi, int16_t* samples, int64_t cap, int64_t* offsets, char* ids, int id_stride);
 
 /* ---- the step after the hot path in chunk mode, on the HOST's cores: simple_assembly + argmax --
  * radian/sequence_assembly.py:19-48, radian/basecall.py:122-123.  labels / label_len as the chunk-mode entry points return

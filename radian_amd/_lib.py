@@ -59,6 +59,12 @@ SIGNATURES = {
     "rd_basecall_raw_chunk": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
     "rd_basecall_raw_global": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp, c_vp]),
     "rd_stitch_chunk": (c_i, [c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_i]),
+    "rd_fast5_open": (c_i, [ctypes.c_char_p, ctypes.POINTER(c_vp)]),
+    "rd_fast5_open_mem": (c_i, [c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "rd_fast5_close": (None, [c_vp]),
+    "rd_fast5_count": (c_i, [c_vp, c_i64p]),
+    "rd_fast5_lengths": (c_i, [c_vp, c_i64, c_i64, c_vp]),
+    "rd_fast5_read_batch": (c_i, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i]),
     "rd_lm_json_probe": (c_i, [c_vp, ctypes.c_size_t, ctypes.POINTER(c_i)]),
     "rd_lm_json_fill": (c_i, [c_vp, ctypes.c_size_t, c_i, c_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "rd_dev_alloc": (c_i, [c_vp, c_sz, ctypes.POINTER(c_vp)]),

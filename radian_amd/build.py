@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libradian_hip.so")
-SOURCES = ["api.hip", "plan.hip", "pipe_reads.hip", "forward.hip", "decode.hip", "decode_wide.hip", "assemble.hip", "preprocess.hip", "stitch.hip", "lmjson.hip"]
+SOURCES = ["api.hip", "plan.hip", "pipe_reads.hip", "forward.hip", "decode.hip", "decode_wide.hip", "assemble.hip", "preprocess.hip", "stitch.hip", "lmjson.hip", "fast5.hip"]
 
 
 def _stale():

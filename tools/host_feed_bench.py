@@ -118,8 +118,10 @@ def worker(scratch, argv):
     sys.stdout = open(os.devnull, "w")      # (the per-read "Basecalled read ..." lines: the CLI prints them; a job redirects them)
     launch.run_rank(args, NullBackend(), NullComm(), scratch, sources, rank, world)
     stop.set()
+    import resource
+    ru = resource.getrusage(resource.RUSAGE_SELF)
     with open(os.path.join(scratch, f"budget{rank}.json"), "w") as f:
-        json.dump({"cpus": budget["cpus"], "split": budget["how"], "bound": budget["bound"], "stitch_workers": args.stitch_workers,
+        json.dump({"cpu_s": round(ru.ru_utime + ru.ru_stime, 2), "cpus": budget["cpus"], "split": budget["how"], "bound": budget["bound"], "stitch_workers": args.stitch_workers,
                    "peak_threads": peak["threads"], "names": peak.get("names")}, f)
 
 
@@ -152,6 +154,8 @@ def bench_ranks(world, n_reads, length, n_files, mode, keep=None):
                "slices_disjoint": len({c for b in budgets for c in b["cpus"]}) == sum(len(b["cpus"]) for b in budgets),
                "stitch_threads_per_rank": [b["stitch_workers"] for b in budgets], "stitch_threads_total": sum((b["stitch_workers"] or 0) for b in budgets),
                "peak_threads_per_rank": [b["peak_threads"] for b in budgets], "seconds": round(dt, 2),
+               "rank_cpu_seconds": [b["cpu_s"] for b in budgets], "cores_busy_ranks": round(sum(b["cpu_s"] for b in budgets) / dt, 2),
+               "fast5_reader": "libhdf5" if os.environ.get("RADIAN_FAST5_NATIVE") == "0" else "native",
                "merge_after_last_rank_s": round(dt - t_ranks, 2), "records": written, "reads_per_s": round(n / dt),
                "M_samples_per_s": round(n * length / dt / 1e6, 1), "M_samples_per_s_per_rank": round(n * length / dt / 1e6 / world, 1),
                "fasta_files": len([x for x in os.listdir(out_dir) if x.startswith("reads-")])}
