@@ -168,7 +168,7 @@ extern "C" int rd_destroy(rd_ctx* ctx)
         for (DevBuf& b : L.act) b.release();
     }
     DevBuf* bufs[] = {&ctx->ws_tiles, &ctx->ws_raw, &ctx->ws_in, &ctx->ws_probs, &ctx->ws_mat, &ctx->ws_seq,
-                      &ctx->ws_nodes_child, &ctx->ws_nodes_back, &ctx->ws_wide, &ctx->ws_wide_slot, &ctx->ws_labels, &ctx->ws_misc, &ctx->model.storage,
+                      &ctx->ws_nodes_child, &ctx->ws_nodes_back, &ctx->ws_wide, &ctx->ws_wide_slot, &ctx->ws_queue, &ctx->ws_labels, &ctx->ws_misc, &ctx->model.storage,
                       &ctx->lm.storage, &ctx->lm.gate_storage};
     for (DevBuf* b : bufs) b->release();
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);   // (ctx->stream was synchronised at the top)

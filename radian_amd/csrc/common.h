@@ -165,6 +165,7 @@ struct rd_ctx {
     int part_mode = -1;   // rd_set_decode_partition: -1 = chosen by beam width, 0 = off, k = k CUs per XCD
     int part_cus = 0;     // CUs per XCD the existing masked streams were created for (0: none exist)
     DevBuf ws_in, ws_probs, ws_mat, ws_seq, ws_nodes_child, ws_nodes_back, ws_labels, ws_misc;
+    DevBuf ws_queue;                // the work-queue counter of beam_search_queue_kernel (decode.hip)
     DevBuf ws_wide, ws_wide_slot;   // beam widths above 51 (decode_wide.hip): per-sequence scratch block, per-trie-node slot map
     // pinned host staging
     void* h_stage = nullptr;
@@ -197,7 +198,8 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype /* 0 f32, 1 f64, 2
                   const int64_t* d_node_off, const int64_t* d_label_off, int n_seq, int64_t total_nodes, int W, int use_lm,
                   double s_thr, double r_thr, uint8_t* d_labels, int32_t* d_label_len, double* d_best_score,
                   hipStream_t stream = nullptr /* default: ctx->stream */, const int64_t* d_seq_off2 = nullptr,
-                  const int32_t* d_seq_split = nullptr, int n_cu_avail = 0 /* CUs the stream may use (0: all) */);
+                  const int32_t* d_seq_split = nullptr, int n_cu_avail = 0 /* CUs the stream may use (0: all) */,
+                  int queue_wave_slots = 0 /* > 0: n_seq exceeds what those CUs keep resident: that many waves' worth of workgroups take the sequences from a queue */);
 // preprocess.hip
 int rd_normalise_dev(rd_ctx* ctx, const int16_t* d_raw, const int64_t* d_read_off, int n_reads, int clip, float* d_out,
                      int32_t* d_status, hipStream_t stream = nullptr /* default: ctx->stream */);

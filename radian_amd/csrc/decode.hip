@@ -81,7 +81,7 @@ __device__ __forceinline__ void seq_sync()
 // share a sequence (W <= 12: one wave; W <= 25: two; W <= 51: four), each with R slots per lane (R = 1 in the product;
 // R > 1 is the single-wave form of round 2's first half, kept for A/B builds).
 template <typename PT, int R, int NW, bool LM, bool HC, bool GX>
-__global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
+__device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int seq)
 {
     static_assert(LM || !HC, "hashed contexts only exist with an LM");
     constexpr int WM = Cfg<R, NW>::WM;
@@ -98,7 +98,6 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int seq = blockIdx.x;
     const int T = a.seq_len[seq];
     const PT* __restrict__ probs = (const PT*)a.probs;
     const int64_t row_a = a.seq_off[seq];
@@ -615,6 +614,33 @@ __global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
 }
 
 
+template <typename PT, int R, int NW, bool LM, bool HC, bool GX>
+__global__ __launch_bounds__(64 * NW) void beam_search_kernel(DecodeArgs a)
+{
+    beam_search_body<PT, R, NW, LM, HC, GX>(a, (int)blockIdx.x);
+}
+
+// The same search behind a work queue: `gridDim.x` workgroups -- as many as the CUs they may run on keep RESIDENT -- take the sequences in
+// index order (the caller sorts longest first) from a counter in HBM until it runs past n_seq, which every workgroup reaches.  For a group
+// of the reads pipeline with more sequences than its decode partition holds (pipe_reads.hip): launched as one workgroup per sequence, the
+// surplus workgroups wait in the dispatcher, and a dispatch that cannot place its workgroups blocks the other queues of its pipe -- the
+// forward lanes stood still for the length of the longest chain (200-ms stalls in tools/policy_probe.py's trace; DESIGN_LOG.md round 5).
+template <typename PT, int R, int NW, bool LM, bool HC, bool GX>
+__global__ __launch_bounds__(64 * NW) void beam_search_queue_kernel(DecodeArgs a, int n_seq, int* counter)
+{
+    __shared__ int s_next;
+    for (;;) {
+        if (threadIdx.x == 0) s_next = atomicAdd(counter, 1);
+        __syncthreads();
+        const int seq = __builtin_amdgcn_readfirstlane(s_next);
+        __syncthreads();                       // (everyone has read it before thread 0 draws again)
+        if (seq >= n_seq) return;
+        beam_search_body<PT, R, NW, LM, HC, GX>(a, seq);
+        __syncthreads();                       // (the sequence's LDS state is dead before the next one initialises it)
+    }
+}
+
+
 // ---- two sequences per wave (W <= 12) -----------------------------------------------------------------------------------
 // At the reference's default width (basecall.py:32: beam 6) a step has at most 30 candidates: half of a wave.  Here a wave
 // carries TWO sequences, lanes 0-31 and lanes 32-63 ("halves"), through the same step as beam_search_kernel<PT, R, 1, ...>:
@@ -1102,6 +1128,27 @@ int launch_r(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
     return a.glibc_math ? launch_g<PT, R, NW, true>(st, a, n_seq, lm) : launch_g<PT, R, NW, false>(st, a, n_seq, lm);
 }
 
+// work-queue form (beam_search_queue_kernel): `slots` workgroups take n_seq sequences; no hashed contexts (the pipeline's groups have none
+// beyond the partition's capacity: configs[4]'s leg closes at the limit, as before)
+template <typename PT, int R, int NW, bool GX>
+int launch_qg(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm, int slots, int* counter)
+{
+    if (lm) hipLaunchKernelGGL((beam_search_queue_kernel<PT, R, NW, true, false, GX>), dim3(slots), dim3(64 * NW), 0, st, a, n_seq, counter);
+    else hipLaunchKernelGGL((beam_search_queue_kernel<PT, R, NW, false, false, GX>), dim3(slots), dim3(64 * NW), 0, st, a, n_seq, counter);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+template <typename PT>
+int launch_queue_pt(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm, int wave_slots, int* counter)
+{
+    // one workgroup = 1 / 2 / 4 waves for W <= 12 / 25 / 51 (the shapes part_seq_limit counts with)
+    const int nw = a.W <= Cfg<1, 1>::WM ? 1 : a.W <= Cfg<1, 2>::WM ? 2 : 4;
+    const int slots = std::max(1, std::min(n_seq, wave_slots / nw));
+    if (nw == 1) return a.glibc_math ? launch_qg<PT, 1, 1, true>(st, a, n_seq, lm, slots, counter) : launch_qg<PT, 1, 1, false>(st, a, n_seq, lm, slots, counter);
+    if (nw == 2) return a.glibc_math ? launch_qg<PT, 1, 2, true>(st, a, n_seq, lm, slots, counter) : launch_qg<PT, 1, 2, false>(st, a, n_seq, lm, slots, counter);
+    return a.glibc_math ? launch_qg<PT, 1, 4, true>(st, a, n_seq, lm, slots, counter) : launch_qg<PT, 1, 4, false>(st, a, n_seq, lm, slots, counter);
+}
+
 template <typename PT, int R>
 int launch_two(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
 {
@@ -1180,7 +1227,7 @@ static int ensure_lm_gate(rd_ctx* ctx, double r_thr, hipStream_t st)
 int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_seq_off, const int32_t* d_seq_len,
                   const int64_t* d_node_off, const int64_t* d_label_off, int n_seq, int64_t total_nodes, int W, int use_lm,
                   double s_thr, double r_thr, uint8_t* d_labels, int32_t* d_label_len, double* d_best_score, hipStream_t stream,
-                  const int64_t* d_seq_off2, const int32_t* d_seq_split, int n_cu_avail)
+                  const int64_t* d_seq_off2, const int32_t* d_seq_split, int n_cu_avail, int queue_wave_slots)
 {
     const int n_simd = 4 * (n_cu_avail > 0 ? n_cu_avail : ctx->n_cu);
     hipStream_t st = stream ? stream : ctx->stream;
@@ -1229,7 +1276,17 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_
 #endif
     KernelTimer& tm = ctx->timer_decode;
     if (tm.enabled && tm.used < tm.starts.size()) RD_HIP(hipEventRecord(tm.starts[tm.used], st));
-    int rc = W > kMaxW ? rd_decode_wide_launch(ctx, st, &a, ptype, n_seq, total_nodes, use_lm != 0)   // (decode_wide.hip: any wider beam)
+    int rc;
+    if (queue_wave_slots > 0 && W <= kMaxW && !(use_lm && a.hashed)) {
+        // more sequences than the CUs of this stream keep resident: resident workgroups + a work queue (beam_search_queue_kernel)
+        if (ctx->ws_queue.reserve(256)) return RD_ERR_NOMEM;
+        RD_HIP(hipMemsetAsync(ctx->ws_queue.p, 0, 4, st));
+        int* counter = ctx->ws_queue.as<int>();
+        rc = ptype == 1 ? launch_queue_pt<double>(st, a, n_seq, use_lm != 0, queue_wave_slots, counter)
+             : ptype == 2 ? launch_queue_pt<_Float16>(st, a, n_seq, use_lm != 0, queue_wave_slots, counter)
+                          : launch_queue_pt<float>(st, a, n_seq, use_lm != 0, queue_wave_slots, counter);
+    } else
+    rc = W > kMaxW ? rd_decode_wide_launch(ctx, st, &a, ptype, n_seq, total_nodes, use_lm != 0)   // (decode_wide.hip: any wider beam)
              : ptype == 1 ? launch_pt<double>(st, a, n_seq, use_lm != 0, n_simd, ctx->decode_form)
              : ptype == 2 ? launch_pt<_Float16>(st, a, n_seq, use_lm != 0, n_simd, ctx->decode_form) : launch_pt<float>(st, a, n_seq, use_lm != 0, n_simd, ctx->decode_form);
     if (rc) return rc;

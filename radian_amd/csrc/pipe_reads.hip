@@ -73,7 +73,10 @@ struct Calib {
     } f[NF];
     int64_t f_next = 0;        // submits recorded so far (sample i lives in f[i % NF])
     int64_t f_seen = 0;        // samples before this index have been used or dropped
-    double ns_row[3] = {0.0, 0.0, 0.0};   // per matrix-product mode, all lanes together; 0: not measured yet
+    double ns_row[3] = {0.0, 0.0, 0.0};   // per matrix-product mode, all lanes together; 0: not measured yet: the smallest of the last NH windows
+    static constexpr int NH = 5;
+    double ns_hist[3][NH] = {{0.0}};      // the last NH windows' figures per mode (a ring)
+    int ns_n[3] = {0, 0, 0};              // windows seen per mode
     struct Dec {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         int64_t longest = 0;
@@ -159,9 +162,21 @@ void calib_harvest(Calib& c)
             }
             busy += hi - lo;
             if (rows > 0 && busy > 0.0) {
+                // The SMALLEST of the last five windows, not a running mean: a lane's interval now and then holds a stall that is not the
+                // forward's -- 80-200 ms inside one submit's lane work, while a long beam search runs or a second process uses the GPU
+                // (tools/policy_probe.py; one window in ten read 220 ns per row against 36-50).  A mean follows such windows, the rule
+                // hits its lower clamp, groups close uncovered, the host waits for their beam searches -- which is what makes stalls.
+                // Stalls only ever lengthen an interval, so the smallest recent figure is the forward's own pace; a real slowdown
+                // (another matrix-product mode has its own ring; a shared GPU) moves all five within five windows, and until then
+                // the rule errs towards LARGER groups: more coverage, not less.
                 const double ns = busy * 1e6 / (double)rows;
-                double& e = c.ns_row[ref.prec];
-                e = e == 0.0 ? ns : 0.6 * e + 0.4 * ns;
+                const int pr = ref.prec;
+                c.ns_hist[pr][c.ns_n[pr] % Calib::NH] = ns;
+                c.ns_n[pr]++;
+                double v[Calib::NH];
+                const int n = c.ns_n[pr] < Calib::NH ? c.ns_n[pr] : Calib::NH;
+                for (int i = 0; i < n; i++) v[i] = c.ns_hist[pr][i];
+                c.ns_row[pr] = *std::min_element(v, v + n);
             }
         } else {
             (void)hipGetLastError();
@@ -266,6 +281,8 @@ struct RSlot {                // a group
     int mode = -1, W = 0, f16 = 0, use_lm = 0;
     double s_thr = 0.0, r_thr = 0.0;
     int64_t rows = 0, rows64 = 0, cap_rows = 0, labels_total = 0, longest = 0;
+    int64_t steps_total = 0;  // time steps of all the group's sequences (global mode): the partition's total work
+    bool oversub = false;     // global mode: more sequences than the partition keeps resident, by decision (see submit): stays on the partition
     int n_reads = 0;
     size_t status_off = 0;    // inside h_out, valid while busy
     std::vector<int> order;   // decode order of the sequences (global: float64 ones first), valid while busy
@@ -315,6 +332,8 @@ void slot_reset(RSlot& s)
     s.seqs.clear();
     s.order.clear();
     s.rows = s.rows64 = s.labels_total = s.longest = 0;
+    s.steps_total = 0;
+    s.oversub = false;
     s.n_reads = 0;
     s.lane_mask = 0;
     s.mode = -1;
@@ -429,7 +448,7 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
     // the group's beam search runs on the decode partition when its forwards kept one clear and its sequences are few
     // enough to run there at chain pace, else on the whole chip; the two streams share the trie workspace, so a launch on
     // one waits for the other's latest
-    const bool on_part = s.part && (int)n <= part_seq_limit(s.part, s.W);
+    const bool on_part = s.part && ((int)n <= part_seq_limit(s.part, s.W) || s.oversub);
     hipStream_t ds = on_part ? p->s_part : p->s_dec;
     if (p->last_dec && p->last_dec != ds) {
         RD_HIP(hipEventRecord(p->ev_switch, p->last_dec));
@@ -443,7 +462,10 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
     char* dm = (char*)s.meta.p;
     // global mode: the group's beam search is timed for the group policy (Calib)
     Calib::Dec* cd = nullptr;
-    if (s.mode == 1 && s.longest > 0) {
+    // (an oversubscribed partition -- work queue, every slot taken from the start -- gives the pace at three waves per SIMD as long as its longest
+    // chain, not its total work, decides when it ends: steps_total / slots well below the longest chain)
+    const bool q_launch = on_part && (int)n > part_seq_limit(s.part, s.W);
+    if (s.mode == 1 && s.longest > 0 && (!q_launch || s.steps_total / part_seq_limit(s.part, s.W) <= s.longest * 4 / 5)) {
         calib_harvest(p->calib);
         Calib::Dec& d = p->calib.d[p->calib.d_next % Calib::ND];
         if (!d.pending) {
@@ -463,7 +485,9 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
         rc = rd_decode_dev(ctx, src, ptype, (const int64_t*)dm + k0, (const int32_t*)(dm + o_len) + k0, (const int64_t*)(dm + o_node) + k0,
                            (const int64_t*)(dm + o_lab) + k0, k1 - k0, nodes[pass], s.W, s.use_lm, s.s_thr, s.r_thr, s.labels.as<uint8_t>(),
                            (int32_t*)(dm + o_llen) + k0, nullptr, ds, chunk ? (const int64_t*)(dm + o_off2) + k0 : nullptr,
-                           chunk ? (const int32_t*)(dm + o_split) + k0 : nullptr, on_part ? RD_XCDS * s.part : 0);
+                           chunk ? (const int32_t*)(dm + o_split) + k0 : nullptr, on_part ? RD_XCDS * s.part : 0,
+                           // an oversubscribed partition (s.oversub): resident workgroups + a work queue, three waves per SIMD
+                           on_part && (int)n > part_seq_limit(s.part, s.W) ? RD_XCDS * s.part * 4 * 3 : 0);
         if (rc) return rc;
     }
     if (cd) {
@@ -494,6 +518,10 @@ int open_slot(rd_ctx* ctx, ReadsPipe* p, int mode, int W, int f16, int use_lm, d
 {
     int rc;
     RSlot* s = &p->slot[p->cur];
+    // The current slot may still hold the group BEFORE the last one (launched, not yet handed to its callers): that group goes out first.
+    // (Round 5: judged by the tests below while still busy -- its rows plus this batch "did not fit" -- it was "closed" again, which only
+    // flipped the slots, and the host then waited for the group it had just launched: no forward under that group's beam search.)
+    if (s->busy && (rc = slot_collect(p, *s))) return rc;
     const bool same = s->mode == mode && s->W == W && s->f16 == f16 && s->use_lm == use_lm && s->s_thr == s_thr && s->r_thr == r_thr && s->part == part;
     if (!s->seqs.empty() && (!same || s->rows + rows > s->cap_rows)) {
         if (same) s->grow_hint = 2 * (s->rows + rows);   // closed for lack of room: the slot grows when it is empty again
@@ -688,6 +716,32 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
         calib_harvest(p->calib);
         expect_rows = std::min<int64_t>(kGroupRowsCap, chain_rows(ctx, p->calib, W, part ? 2 : 0, use_lm) * longest_b + 2 * P.total_rows);
     }
+    if (mode == 1 && part) {
+        // A partition-lane group that THIS batch would take past what the partition keeps resident (part_seq_limit), before its forward
+        // rows cover its longest chain.  Flipping it onto the whole chip (beside the next group's conv waves) is a regime that needs 5-6x
+        // the rows (configs[4] leg: 26.3 M samples/s closing here, 20.6 M flipping), so round 4 closed the group at this point, covered or
+        // not -- which starves a stream whose batches mix a few long reads with many short ones: the short reads use up the sequence
+        // budget after a few batches and the group closes with 40 ms of forward under a 150-ms chain (tools/policy_probe.py, batches
+        // alternating between 64 x 4096 and 6 x 40960 samples at W = 25: 6.5 M samples/s against 32 / 22 M for either kind alone).  Now the
+        // group may keep growing ON the partition -- its workgroups queue longest-first: the long chains start at once, the short ones
+        // fill the slots behind them -- as long as the partition's total work keeps up with the forward:
+        //     steps_total x pace(three waves per SIMD) / resident sequences  <=  forward time of the group's rows
+        // and closes here, as before, where it does not (many short reads at a wide beam).  Decided when the crossing batch ARRIVES, with
+        // that batch counted in: a rule that predicts "another batch like the last one" flips a coin on a stream of alternating batches.
+        RSlot& g = p->slot[p->cur];
+        const int limit = part_seq_limit(part, W);
+        if (!g.busy && !g.seqs.empty() && g.mode == 1 && g.part == part && g.W == W && !g.oversub && (int)g.seqs.size() <= limit &&
+            (int)g.seqs.size() + n_reads > limit) {
+            const double ns = p->calib.ns_row[ctx->precision] > 0.0 ? p->calib.ns_row[ctx->precision] : kDefaultNsPerRow;
+            const double* us3 = p->calib.find(Calib::key_of(W, 3, ctx->decode_math, ctx->precision, use_lm));
+            const double pace3 = us3 ? *us3 : (double)chain_rows_default(W, true) * kDefaultNsPerRow * 1e-3;
+            const double work_ms = (double)(g.steps_total + (int64_t)n_samples) * pace3 * 1e-3 / (double)limit;
+            const double fwd_ms = (double)(g.rows + P.total_rows) * ns * 1e-6;
+            // (a quarter over is tolerated: a partition 25 % behind the forward costs that much at worst; closing here costs the uncovered chain)
+            if (work_ms <= 1.25 * fwd_ms && W <= rd_decode_lane_width() && !(use_lm && ctx->lm.hashed)) g.oversub = true;
+            else if ((rc = close_group(ctx, p))) return rc;
+        }
+    }
     if ((rc = open_slot(ctx, p, mode, W, f16, use_lm, s_thr, r_thr, part, P.total_rows, expect_rows, &s))) return rc;
 
     // ---- its sequences (and, in global mode, the per-read assembly records), not yet part of the group
@@ -816,19 +870,21 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
     s->n_reads += n_reads;
     s->rows += P.total_rows;
     if (longest > s->longest) s->longest = longest;
+    if (mode == 1) s->steps_total += (int64_t)n_samples;     // (a read's search takes one time step per sample)
     s->subs.push_back(std::move(sb));
     p->next_lane = (lane + 1) % n_lanes;
     p->submitted++;
     bool close;
     if (mode == 1) {
         // global mode: by coverage of the longest read's chain (see chain_rows), not by a batch count
-        const bool few = part && (int)s->seqs.size() <= part_seq_limit(part, W);
-        const int m = few ? part_waves_per_simd(part, W, (int64_t)s->seqs.size()) : 0;
-        close = s->rows >= chain_rows(ctx, p->calib, W, m, use_lm) * s->longest || s->rows >= kGroupRowsCap;
-        // A group of partition-lane batches closes when another batch of this size would take it past what the partition decodes
-        // at chain pace, covered or not: past that point the group would decode on the whole chip beside the next group's conv
-        // waves -- a different regime that needs 5-6x the rows (configs[4] leg: 26.3 M samples/s closing here, 20.6 M flipping).
-        if (few && (int)s->seqs.size() + n_reads > part_seq_limit(part, W)) close = true;
+        const int limit = part ? part_seq_limit(part, W) : 0;
+        const bool few = part && ((int)s->seqs.size() <= limit || s->oversub);
+        const int m = few ? std::min(3, part_waves_per_simd(part, W, (int64_t)s->seqs.size())) : 0;
+        int64_t need = chain_rows(ctx, p->calib, W, m, use_lm) * s->longest;
+        // An oversubscribed partition (decided when the crossing batch arrived, above) finishes no sooner than its total work allows: every resident slot steps at the saturated
+        // pace, so the group's forward rows must also cover  steps_total x pace(3) / slots  (chain_rows(3) = that pace in forward rows + 20 %)
+        if (s->oversub) need = std::max(need, chain_rows(ctx, p->calib, W, 3, use_lm) * s->steps_total / limit);
+        close = s->rows >= need || s->rows >= kGroupRowsCap;
         // (the very first group of a context closes with its first batch: nothing is decoding yet, and its chains start one
         // group's forward time earlier -- a quarter of a second on a job of long reads)
         close = close || p->launches == 0;
