@@ -18,7 +18,8 @@ def _stale():
 
 
 def build(force=False, verbose=False, defines=(), out=None):
-    """defines/out: build an experiment variant (-D...) into another file (tools/variants.sh); the product build uses neither."""
+    """defines/out: compile with extra -D options into another file (one-off measurements: the sources hold no conditional on an RD_ macro,
+    tests/test_abi_cpu.py); the product build uses neither."""
     if not force and not _stale() and out is None:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -133,9 +133,6 @@ struct FwdLane {
     hipStream_t st = nullptr;
     DevBuf act[3];
     hipEvent_t done = nullptr;   // recorded after the lane's latest forward
-    // experiment (RD_X_ALT_STREAMS, tools only): odd layers on a second stream, no ordering between neighbouring layers
-    hipStream_t st2 = nullptr;
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;
 };
 
 struct rd_ctx {

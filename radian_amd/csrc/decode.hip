@@ -1267,13 +1267,6 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_
     a.labels = d_labels;
     a.label_len = d_label_len;
     a.best_score = d_best_score;
-#ifdef RD_EXPERIMENTS   // timing only (labels are garbage): the pipeline with everything but the beam-search kernel itself
-    static const bool x_no_decode = getenv("RD_X_NO_DECODE") != nullptr;
-    if (x_no_decode) {
-        RD_HIP(hipMemsetAsync(d_label_len, 0, (size_t)n_seq * 4, st));
-        return RD_OK;
-    }
-#endif
     KernelTimer& tm = ctx->timer_decode;
     if (tm.enabled && tm.used < tm.starts.size()) RD_HIP(hipEventRecord(tm.starts[tm.used], st));
     int rc;

@@ -135,39 +135,6 @@ __device__ __forceinline__ void wait_dma_and_barrier()
     else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LEAVE) : "memory");
 }
 
-// Diagnostic build only (-DRD_CLOCK_STAMPS, tools/conv_clock.py): every conv workgroup stamps the shader clock and the 100-MHz
-// wall clock at its start and end; rd_debug_conv_clock() reports the clock the chip actually held inside the kernel
-// (MI355X_MICROARCH.md, "DVFS give-back" (6): sysfs / rocm-smi read up to 10 % above it).  The stamps go to a buffer of their
-// own; no output depends on them.
-#ifdef RD_CLOCK_STAMPS
-// a ring of the last 131 072 conv workgroups x {wall start, wall end, shader-clock ticks, xcc << 32 | HW_ID}
-__device__ unsigned long long g_clock_stamps[32 * 4096 * 4];
-__device__ unsigned g_launch_seq;
-#define RD_STAMP_BEGIN()                                                                                              \
-    unsigned long long ck0_ = 0, rt0_ = 0;                                                                            \
-    unsigned seq_ = 0;                                                                                                \
-    if (threadIdx.x == 0 && EPI != EPI_HEAD) {                                                                        \
-        seq_ = atomicAdd(&g_launch_seq, 1u);   /* (a ring position per workgroup) */                                  \
-        ck0_ = __builtin_amdgcn_s_memtime();                                                                          \
-        rt0_ = __builtin_amdgcn_s_memrealtime();                                                                      \
-    }
-#define RD_STAMP_END()                                                                                                \
-    if (threadIdx.x == 0 && EPI != EPI_HEAD) {                                                                        \
-        unsigned xcc_, hw_;                                                                                           \
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                           \
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                             \
-        unsigned long long* o_ = g_clock_stamps + (size_t)(seq_ & (32 * 4096 - 1)) * 4;                               \
-        o_[0] = rt0_;                                                                                                 \
-        o_[1] = __builtin_amdgcn_s_memrealtime();                                                                     \
-        o_[2] = __builtin_amdgcn_s_memtime() - ck0_;                                                                  \
-        o_[3] = ((unsigned long long)(uintptr_t)a.out >> 12 & 0xffff) << 48 | (unsigned long long)(a.dil & 0xff) << 40 | \
-                (unsigned long long)EPI << 36 | (unsigned long long)(xcc_ & 0xf) << 32 | hw_;   /* (out, dil, EPI: which launch) */ \
-    }
-#else
-#define RD_STAMP_BEGIN()
-#define RD_STAMP_END()
-#endif
-
 // ReLU of an accumulator.  Written as `v > 0 ? v : 0` hipcc emits v_max v, v, v (quieting a possible signalling NaN) in front
 // of the v_max with 0: 128 extra vector instructions per wave in the epilogue.
 __device__ __forceinline__ float relu_raw(float v)
@@ -286,7 +253,6 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
 
     __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];  // 3 x 24 KiB (conv, WM = 2) / 3 x 32 KiB (WM = 4) / 67 KiB (head) / 70 KiB (FIN)
 
-    RD_STAMP_BEGIN()
     if constexpr (FIN) clear_zero_rows(a.zr);   // (this kernel is then the forward's first)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -654,7 +620,6 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void tcn_gemm_kernel(Con
         static_assert(64 * NWAVE == 2 * BM, "head epilogue: two threads per row");
         head_dense5_softmax<BM>(hs, w2s, w2s + RD_H * 5 + 8, tds, a, tid);
     }
-    RD_STAMP_END()
 }
 
 // Block 0, first conv: C_in = 1 (VALU; memory-bound 1 KiB write per time step), fused bias + ReLU.
@@ -1030,13 +995,6 @@ __global__ __launch_bounds__(256) void tcn_in_split_kernel(const float* __restri
 // =====================================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-// The RD_BF3_* switches below build ABLATION variants of the bf16x3 kernel (operands from registers instead of LDS, DMA or MFMA
-// or epilogue skipped: wrong results by design).  They exist for tools/variants.sh only: a product build that
-// defines one by accident stops here.
-#if (defined(RD_BF3_NOLDS) || defined(RD_BF3_NOMFMA) || defined(RD_BF3_SKIPALL) || defined(RD_BF3_SKIPA) || defined(RD_BF3_SKIPB) || \
-     defined(RD_BF3_NODMA) || defined(RD_BF3_NOA) || defined(RD_BF3_NOB) || defined(RD_BF3_NOEPI)) && !defined(RD_EXPERIMENTS)
-#error "RD_BF3_* ablation switches change results: build them with -DRD_EXPERIMENTS (tools/variants.sh), never into the product"
-#endif
 
 constexpr int ROW3 = 3 * RD_C;   // bf16 elements per activation row (768 = 1536 B)
 
@@ -1183,16 +1141,6 @@ __global__ __launch_bounds__(512, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
         const char* Bb = st + b_off;
         bf16x8 af[2][3], bf[2][3];
         const bool st_ok = next < NCHUNK;
-#ifdef RD_BF3_NOLDS
-        if (work) {   // experiment: operands from registers (no fragment reads)
-#pragma unroll
-            for (int m = 0; m < 2; m++)
-#pragma unroll
-                for (int t = 0; t < 3; t++) af[m][t] = (bf16x8)(__bf16)(float)(toff[t] + m);
-#pragma unroll
-            for (int t = 0; t < 3; t++) bf[0][t] = bf[1][t] = (bf16x8)(__bf16)(float)(toff[t] + 7);
-        }
-#else
         if (work) {
 #pragma unroll
             for (int m = 0; m < 2; m++)
@@ -1201,23 +1149,16 @@ __global__ __launch_bounds__(512, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
 #pragma unroll
             for (int t = 0; t < 3; t++) bf[0][t] = *(const bf16x8*)(Bb + toff[t]);
         }
-#endif
         constexpr int PPS = (NPIECE + NT - 1) / NT;   // DMA pieces issued after each N step
 #pragma unroll
         for (int n = 0; n < NT; n++) {
             if (work) {
-#ifndef RD_BF3_NOLDS
                 if (n + 1 < NT) {
 #pragma unroll
                     for (int t = 0; t < 3; t++) bf[(n + 1) & 1][t] = *(const bf16x8*)(Bb + (n + 1) * 32 * RB + toff[t]);
                 }
-#endif
 #pragma unroll
                 for (int m = 0; m < 2; m++) {
-#ifdef RD_BF3_NOMFMA
-                    asm volatile("" ::"v"(af[m][0]), "v"(af[m][1]), "v"(af[m][2]), "v"(bf[n & 1][0]), "v"(bf[n & 1][1]), "v"(bf[n & 1][2]));
-                    continue;
-#endif
                     // smallest terms first: 2^-16 order, 2^-8 order, then hi*hi
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][2], bf[n & 1][0], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[n & 1][2], acc[m][n], 0, 0, 0);
@@ -1226,30 +1167,14 @@ __global__ __launch_bounds__(512, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[n & 1][1], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[n & 1][0], acc[m][n], 0, 0, 0);
                 }
-#ifndef RD_BF3_NOLDS
                 __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < PPS; q++)
                 if (st_ok && n * PPS + q < NPIECE) {
-#if defined(RD_BF3_SKIPALL)
-                    (void)0;
-#elif defined(RD_BF3_SKIPA)
-                    if (n * PPS + q >= 3) stage_piece(next, next_tap, nst, n * PPS + q);     // experiment: B pieces only
-#elif defined(RD_BF3_SKIPB)
-                    if (n * PPS + q < 3) stage_piece(next, next_tap, nst, n * PPS + q);      // experiment: A pieces only
-#elif defined(RD_BF3_NODMA)
-                    stage_piece(0, 0, nst, n * PPS + q);     // experiment: always the first chunk (cache-resident): no HBM / L2 misses
-#elif defined(RD_BF3_NOA)
-                    if (n * PPS + q >= 3) stage_piece(next, next_tap, nst, n * PPS + q); else stage_piece(0, 0, nst, n * PPS + q);
-#elif defined(RD_BF3_NOB)
-                    if (n * PPS + q < 3) stage_piece(next, next_tap, nst, n * PPS + q); else stage_piece(0, 0, nst, n * PPS + q);
-#else
                     stage_piece(next, next_tap, nst, n * PPS + q);
-#endif
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1268,15 +1193,7 @@ __global__ __launch_bounds__(512, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
     constexpr bool T3 = TAPS == 3;
     stage(0, 0, st0);
     stage(1, T3 ? 1 : 0, st1);
-#if defined(RD_BF3_SKIPALL)
-    constexpr int NWAIT = 0;
-#elif defined(RD_BF3_SKIPA)
-    constexpr int NWAIT = NPIECE - 3;
-#elif defined(RD_BF3_SKIPB)
-    constexpr int NWAIT = 3;
-#else
     constexpr int NWAIT = NPIECE;
-#endif
     auto step = [&](int c, const char* st, int tap2, char* nst) {
         if (c + 1 < NCHUNK && c >= 2) wait_dma_and_barrier<NWAIT>(); else if (c + 1 < NCHUNK) wait_dma_and_barrier<(NWAIT < NPIECE ? 0 : NPIECE)>(); else wait_dma_and_barrier<0>();
         chunk_step(st, c + 2, tap2, nst);
@@ -1287,12 +1204,6 @@ __global__ __launch_bounds__(512, 2) void tcn_gemm_bf3_kernel(Bf3Args a)
         if (chunk + 2 < NCHUNK) step(chunk + 2, st2, T3 ? 1 : 0, st1);
     }
     __syncthreads();
-#ifdef RD_BF3_NOEPI
-    if (a.dil >= 0) {   // experiment: no epilogue (keeps the accumulators alive)
-        asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[0][NT - 1]), "v"(acc[1][NT - 1]));
-        return;
-    }
-#endif
 
     if constexpr (EPI != EPI_HEAD) {
         constexpr int TSTR = 64;   // see the fp32 kernel
@@ -1726,13 +1637,6 @@ int rd_lane_get(rd_ctx* ctx, int lane, FwdLane** out)
     if (!L.st) {
         if (lane == 0) L.st = ctx->stream;
         else if (lane < RD_MAX_LANES) {
-#ifdef RD_EXPERIMENTS
-            if (getenv("RD_X_LANE_PRIO")) {     // lanes >= 1 at the lowest queue priority: they fill what lane 0 leaves (measurement)
-                int lo = 0, hi = 0;
-                RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-                RD_HIP(hipStreamCreateWithPriority(&L.st, hipStreamNonBlocking, lo));
-            } else
-#endif
             RD_HIP(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
         }
         else {
@@ -1796,39 +1700,15 @@ int rd_forward_tiles_dev(rd_ctx* ctx, const float* d_signal, const TileLists& tl
     const int zero_row = (int)total_rows;
     // (the three tensors' zero rows are cleared by the forward's first kernel: clear_zero_rows)
     const int nl = 2 * m.nblocks + 1;
-    // EXPERIMENT (wrong results, timing only; tools/alt_streams.sh): neighbouring layers on two streams with NO ordering between
-    // them -- an upper bound on what overlapping a layer's last round with the next layer's first could win
-#ifdef RD_EXPERIMENTS   // (python -m radian_amd.build -DRD_EXPERIMENTS -o...: not in the product library)
-    static const bool x_alt = getenv("RD_X_ALT_STREAMS") != nullptr;
-#else
-    constexpr bool x_alt = false;
-#endif
-    if (x_alt) {
-        if (!L->st2) {
-            RD_HIP(hipStreamCreateWithFlags(&L->st2, hipStreamNonBlocking));
-            RD_HIP(hipEventCreateWithFlags(&L->ev_a, hipEventDisableTiming));
-            RD_HIP(hipEventCreateWithFlags(&L->ev_b, hipEventDisableTiming));
-        }
-        RD_HIP(hipEventRecord(L->ev_a, L->st));
-        RD_HIP(hipStreamWaitEvent(L->st2, L->ev_a, 0));
-    }
     for (int li = 0; li < nl; li++) {
         const int b = li == nl - 1 ? m.nblocks : li / 2;
         const int kind = li == nl - 1 ? 3 : (li == 0 ? 0 : (li & 1 ? 2 : 1));
-#ifdef RD_EXPERIMENTS   // timing only (wrong results): what would a forward without its first-conv / head launch cost?
-        static const bool x_skip_in = getenv("RD_X_SKIP_IN") != nullptr, x_skip_head = getenv("RD_X_SKIP_HEAD") != nullptr;
-        if ((kind == 0 && x_skip_in) || (kind == 3 && x_skip_head)) continue;
-#endif
-        if ((rc = launch_layer(ctx, x_alt && (li & 1) ? L->st2 : L->st, b, kind, tl.d[li], tl.n[li], (double)tl.rows[li], zero_row, d_signal, Xin, Xout, MID, (float*)d_probs, probs_f16))) return rc;
+        if ((rc = launch_layer(ctx, L->st, b, kind, tl.d[li], tl.n[li], (double)tl.rows[li], zero_row, d_signal, Xin, Xout, MID, (float*)d_probs, probs_f16))) return rc;
         if (kind == 2) {   // block finished: its output becomes the next block's input
             float* t = Xin;
             Xin = Xout;
             Xout = t;
         }
-    }
-    if (x_alt) {
-        RD_HIP(hipEventRecord(L->ev_b, L->st2));
-        RD_HIP(hipStreamWaitEvent(L->st, L->ev_b, 0));
     }
     RD_HIP(hipEventRecord(L->done, L->st));
     return RD_OK;
@@ -1887,11 +1767,3 @@ int rd_forward_dev(rd_ctx* ctx, const float* d_windows, int nW, int T, float* d_
     return rd_forward_tiles_dev(ctx, d_windows, tl, (int64_t)nW * T, d_probs, lane);
 }
 
-#ifdef RD_CLOCK_STAMPS
-// copies the stamp ring (32 launches x 4096 workgroups x 4 values) to the host: tools/conv_clock.py does the arithmetic
-extern "C" int rd_debug_conv_stamps(unsigned long long* out /* [32 * 4096 * 4] */)
-{
-    RD_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_stamps), sizeof(unsigned long long) * 32 * 4096 * 4));
-    return RD_OK;
-}
-#endif

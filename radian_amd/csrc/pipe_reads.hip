@@ -47,10 +47,6 @@ namespace {
 constexpr double kDefaultNsPerRow = 34.0;
 inline int64_t chain_rows_default(int W, bool on_partition)
 {
-#ifdef RD_EXPERIMENTS   // (python -m radian_amd.build -DRD_EXPERIMENTS -o...: measurements only, not in the product library)
-    static const long env = getenv("RD_CHAIN_ROWS") ? atol(getenv("RD_CHAIN_ROWS")) : 0;
-    if (env > 0) return env;
-#endif
     // (W <= 6: two sequences share a wave's instructions -- beam_search2_kernel -- so beside conv waves a sequence advances
     // twice as fast per issued instruction)
     if (!on_partition) return W <= 6 ? 300 : W <= 12 ? 560 : W <= 25 ? 900 : 1500;
@@ -216,10 +212,6 @@ int64_t chain_rows(const rd_ctx* ctx, Calib& c, int W, int m, int use_lm)
 {
     const bool on_partition = m > 0;
     const int64_t def = chain_rows_default(W, on_partition);
-#ifdef RD_EXPERIMENTS
-    static const bool no_calib = getenv("RD_NO_CALIB") != nullptr;   // A/B against the constants (tools only)
-    if (no_calib) return def;
-#endif
     const double ns = c.ns_row[ctx->precision];
     if (ns <= 0.0) return def;
     double rows = (double)def * kDefaultNsPerRow / ns;   // the constant, for the forward this context really runs

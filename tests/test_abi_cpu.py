@@ -67,3 +67,23 @@ def test_weight_blob_roundtrip():
     back, dil = weights.unpack_blob(blob)
     assert dil == weights.DEFAULT_DILATIONS
     assert np.array_equal(back, flat)
+
+
+def test_no_experiment_branches_in_the_product_sources():
+    """the ablation / measurement hooks (RD_BF3_*, RD_CLOCK_STAMPS, RD_EXPERIMENTS, RD_X_* environment switches) left the
+    product sources in round 5 -- no conditional compilation on an RD_ macro and no environment switch inside the library: a wrong -D or
+    a stray variable cannot change what the shipped kernels compute.  (Their measurements: profiles/, DESIGN_LOG.md.)"""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "radian_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")))
+    assert len(files) >= 15
+    for f in files:
+        text = open(f).read()
+        for ln in text.split("\n"):
+            s = ln.strip()
+            if s.startswith("#") and re.match(r"#\s*(if|ifdef|ifndef|elif)\b", s):
+                assert not re.search(r"\bRD_[A-Z0-9_]+", s), (os.path.basename(f), s)
+        assert "getenv(\"RD_" not in text and "getenv(\"RADIAN_" not in text, os.path.basename(f)
+    build_py = open(os.path.join(ROOT, "radian_amd", "build.py")).read()
+    assert "RD_EXPERIMENTS" not in build_py

@@ -1,3 +1,6 @@
+"""From a rocprofv3 --kernel-trace directory of a pipelined global-mode run: how much of the long beam searches' time the forward's conv
+kernels were running (1.0 = the next group's forward fully covers the search), conv durations inside / outside those windows, queues.
+usage: decode_overlap_trace.py <dir>   (round 5: found the busy-slot stall of open_slot; profiles/r05_policy_probe.txt)"""
 import csv, glob, sys
 d=sys.argv[1]
 p=glob.glob(d+"/*/*_kernel_trace.csv")[0]

@@ -1,5 +1,5 @@
 """One-context pipelined global decode (rd_pipe_submit_reads_global) at the bench's 64-read steps: samples/s against the
-group size.  usage: python tools/global_pipe_bench.py [soft] [fast] [hashed] [f16] [partK] [nREADS] [gN ...] [W] (RD_CHAIN_ROWS=<rows per chain step> overrides the early-close rule)"""
+group size.  usage: python tools/global_pipe_bench.py [soft] [fast] [hashed] [f16] [partK] [nREADS] [gN ...] [W] """
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

@@ -1,3 +1,6 @@
+"""From a rocprofv3 --kernel-trace directory: per hardware queue, the kernels longer than 30 ms and the pauses longer than 60 ms between
+consecutive kernels -- a forward lane that stands still while a beam search runs shows as a pause as long as that search.
+usage: lane_gap_trace.py <dir>"""
 import csv, glob, sys
 d=sys.argv[1]
 p=glob.glob(d+"/*/*_kernel_trace.csv")[0]
