@@ -126,7 +126,9 @@ int rd_set_logits(rd_ctx* ctx, int mode);
  * Widths up to 6 (the reference's default, basecall.py:32) run two sequences per wave (one candidate per lane of a half-wave);
  * widths 7..12 run ONE sequence per wave under form 0 -- two per wave (two candidates per lane) exists and measured slower, so
  * only form 3 selects it; 3 = two per wave whenever the width allows (up to 12), 4 = always one per wave.  Widths above
- * rd_decode_lane_width() run on the general kernel whatever the form.  For tests and measurements. */
+ * rd_decode_lane_width() run on the general kernel whatever the form.  5 = every launch (widths up to rd_decode_lane_width(), no hashed
+ * contexts) through the work-queue kernel with 16 waves' worth of workgroups: the form the reads pipeline uses, with the partition's
+ * resident count, for a group that holds more sequences than its decode partition.  For tests and measurements. */
 int rd_set_decode_form(rd_ctx* ctx, int form);
 /* Decode partition of the global-mode reads pipeline (rd_pipe_submit_reads_global / rd_pipe_submit_raw_global; no effect on
  * results, no reference counterpart): cus_per_xcd CUs of each of the 8 XCDs are kept free of forward workgroups (the

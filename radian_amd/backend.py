@@ -196,8 +196,8 @@ class Backend:
 
     def set_decode_form(self, form):
         """'auto' (default); 'waves' / 'lanes': launch shape for widths above 12; 'two' / 'one': widths up to 12 always / never as
-        two sequences per wave (rd_set_decode_form)."""
-        self._check(self._L.rd_set_decode_form(self._h, {"auto": 0, "waves": 1, "lanes": 2, "two": 3, "one": 4}[form] if isinstance(form, str) else int(form)))
+        two sequences per wave; 'queue': every launch through the work-queue kernel with few resident workgroups (rd_set_decode_form)."""
+        self._check(self._L.rd_set_decode_form(self._h, {"auto": 0, "waves": 1, "lanes": 2, "two": 3, "one": 4, "queue": 5}[form] if isinstance(form, str) else int(form)))
 
     def set_decode_partition(self, cus_per_xcd):
         """CUs per XCD reserved for the beam search of the global-mode reads pipeline (rd_set_decode_partition): -1 = by beam

@@ -600,8 +600,8 @@ extern "C" int rd_set_logits(rd_ctx* ctx, int mode)
 extern "C" int rd_set_decode_form(rd_ctx* ctx, int form)
 {
     RD_REQUIRE(ctx, "rd_set_decode_form: null context");
-    RD_REQUIRE(form >= 0 && form <= 4, "rd_set_decode_form: form %d (0 = per launch, 1 = waves per sequence, 2 = candidates per lane, 3 = W <= 12: two sequences per "
-               "wave, 4 = one)", form);
+    RD_REQUIRE(form >= 0 && form <= 5, "rd_set_decode_form: form %d (0 = per launch, 1 = waves per sequence, 2 = candidates per lane, 3 = W <= 12: two sequences per "
+               "wave, 4 = one, 5 = work queue)", form);
     ctx->decode_form = form;
     return RD_OK;
 }

@@ -1270,6 +1270,7 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_
     KernelTimer& tm = ctx->timer_decode;
     if (tm.enabled && tm.used < tm.starts.size()) RD_HIP(hipEventRecord(tm.starts[tm.used], st));
     int rc;
+    if (ctx->decode_form == 5 && queue_wave_slots == 0) queue_wave_slots = 16;   // rd_set_decode_form 5 (tests): every launch through the work queue, few slots
     if (queue_wave_slots > 0 && W <= kMaxW && !(use_lm && a.hashed)) {
         // more sequences than the CUs of this stream keep resident: resident workgroups + a work queue (beam_search_queue_kernel)
         if (ctx->ws_queue.reserve(256)) return RD_ERR_NOMEM;

@@ -516,3 +516,53 @@ def test_wide_beams_vs_oracle(be, oracle):
                                 assert got[i] is not None and np.array_equal(got[i], exp[i]), (math, dtype, W, i, "LM")
     be.load_lm(None, 0)
     be.set_decode_math("glibc")
+
+
+def test_work_queue_form_matches_the_reference(be, golden_dir, oracle):
+    """beam_search_queue_kernel (rd_set_decode_form 5: 16 waves' worth of resident workgroups take the sequences of a launch from a counter,
+    one after the other -- what the reads pipeline launches for a group larger than its decode partition): every golden case of the
+    wave-per-sequence widths, with and without an LM, bit-equal winner scores; then batches of hundreds of ragged sequences (each workgroup
+    runs dozens of sequences back to back: the per-sequence LDS state must start clean every time) against the oracle, dense and sparse LM."""
+    be.set_decode_form("queue")
+    be.set_decode_math("glibc")
+    try:
+        g = json.load(open(os.path.join(golden_dir, "beam_nolm_cases.json")))
+        mats = np.load(os.path.join(golden_dir, "beam_nolm_mats.npz"))
+        for c in g["cases"]:
+            m = mats[c["mat"]]
+            (lab,), sc = be.decode_batch(m.reshape(-1, 5), [0], [m.shape[0]], c["W"], with_scores=True)
+            assert s_of(lab) == c["seq"], (c["mat"], c["W"])
+            if "final" in c:
+                exp = fdec(c["final"][0]["pr_total"])
+                assert sc[0] == exp or (np.isnan(exp) and np.isnan(sc[0]))
+        gb, arr = _baseline(golden_dir)
+        for c in gb["cases"]:
+            if c["group"] == "wide_nolm" and c["W"] <= 51:
+                (lab,), _ = be.decode_batch(arr[c["mat"]], [0], [arr[c["mat"]].shape[0]], c["W"], with_scores=True)
+                assert s_of(lab) == c["seq"], (c["mat"], c["W"])
+        rng = np.random.default_rng(77)
+        n = 700
+        lens = rng.integers(0, 90, size=n)
+        lens[::50] = 400
+        rows = [softmax_rows(rng.normal(size=(int(k), 5)) * (1.0 if i % 2 else 3.0)) for i, k in enumerate(lens)]
+        mat64 = np.concatenate(rows, axis=0)
+        off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        table = rng.dirichlet([0.3] * 4, size=4 ** 3)
+        sparse = table.copy()
+        sparse[[3, 30]] = np.nan
+        for W in (1, 6, 10, 25, 40):
+            for dtype in (np.float32, np.float64):
+                mats_b = mat64.astype(dtype)
+                be.load_lm(None, 0)
+                got = be.decode_batch(mats_b, off, lens, W)
+                exp = oracle.beam_search_batch(mats_b, off, lens, W)
+                assert all(np.array_equal(a, b) for a, b in zip(got, exp)), (W, dtype)
+            for tb in (table, sparse):
+                be.load_lm(tb, 3)
+                got = be.decode_batch(mat64, off, lens, W, use_lm=True, s_threshold=0.4, r_threshold=0.9)
+                exp = oracle.beam_search_batch(mat64, off, lens, W, tb, 0.4, 0.9, 3)
+                for a, b in zip(got, exp):
+                    assert (a is None) == (b is None) and (a is None or np.array_equal(a, b)), W
+    finally:
+        be.load_lm(None, 0)
+        be.set_decode_form("auto")
