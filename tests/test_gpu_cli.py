@@ -367,3 +367,23 @@ def test_cli_context_len_mismatch_fails_lazily_like_the_reference(tmp_path, gold
             basecall.main([str(in_dir), str(out), "--sig-model", wpath, "--sig-config", "none", "--rna-model", lm_path, "--context-len", "5",
                            "--step-size", "512"] + extra)
         assert _read_fasta(str(out)) == exp[:first_bad]
+
+
+def test_cli_beam_width_above_the_lane_kernels(tmp_path, golden_dir, oracle):
+    """--beam-width 64 (the reference slices `sort_labelings()[:beam_width]` with any width, decode.py:145): the five reads of data/reads.fast5
+    through the CLI in both decode types -- the pipeline's groups launch csrc/decode_wide.hip -- equal to the oracle's decode of the GPU's
+    own probabilities."""
+    from radian_amd import Backend, basecall, weights, lm
+    ids, sig, in_dir, lm_path = _make_inputs(tmp_path, golden_dir, k=3)
+    table, k = lm.load_json(lm_path)
+    be = Backend(0)
+    be.load_weights(weights.synthetic_weights(seed=1234))
+    exp_chunk = _expected(be, oracle, ids, sig, 1024, 512, 64, "chunk")
+    exp_global = _expected(be, oracle, ids, sig, 1024, 512, 64, "global", table, k)
+    be.close()
+    for mode, exp, extra in (("chunk", exp_chunk, ["--rna-model", "None"]), ("global", exp_global, ["--rna-model", lm_path, "--context-len", "3"])):
+        out = tmp_path / f"w64_{mode}"
+        out.mkdir()
+        basecall.main([in_dir, str(out), "--decode-type", mode, "--beam-width", "64", "--step-size", "512", "--sig-model", "synthetic:1234",
+                       "--sig-config", "none"] + extra)
+        assert _read_fasta(str(out)) == exp, mode

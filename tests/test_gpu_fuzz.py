@@ -11,8 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_fuzz_decode_bounded():
-    """beam search vs the oracle: 60 rounds of random width (1..51, incl. the two-sequences-per-wave widths), launch form,
-    arithmetic, row type and LM order; every labeling identical"""
+    """beam search vs the oracle: 60 rounds of random width (1..160: the two-sequences-per-wave widths, the wave-per-sequence kernels, the
+    general kernel above 51), launch form (incl. the work queue), arithmetic, row type and LM order; every labeling identical"""
     import fuzz_decode
     total, bad = fuzz_decode.run(rounds=60, seed=404, tmax=300, nseq=400)
     assert total == 60 * 400 and bad == 0
