@@ -312,6 +312,10 @@ int rd_pipe_policy_read(rd_ctx* ctx, int beam_width, int on_partition, int use_l
 /* Batches submitted to the reads-level pipeline so far: right after a submit, the number rd_pipe_progress must reach for
  * that batch to have been delivered. */
 int rd_pipe_submitted(rd_ctx* ctx, int64_t* submitted);
+/* Counters of the reads-level pipeline over the context's life (no reference counterpart; for tools and tests): out[0..n) of
+ * { batches submitted, batches delivered, groups whose beam search was launched, of those: global-mode groups that held more sequences than
+ * their decode partition keeps resident and were searched through the work queue, groups closed at that limit instead }. */
+int rd_pipe_stats(rd_ctx* ctx, int64_t* out, int n);
 
 /* RNA model file -> dense table, without a JSON object tree.  radian/basecall.py:48-57 (json.load, then every "ACGT..." key re-keyed as a
  * tuple of label indices).  The reference's default model has 4^11 keys in ~420 MB of text; these two calls scan the one shape such a

@@ -55,6 +55,7 @@ SIGNATURES = {
     "rd_pipe_progress": (c_i, [c_vp, c_i64, c_i64p]),
     "rd_pipe_policy_read": (c_i, [c_vp, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
     "rd_pipe_submitted": (c_i, [c_vp, c_i64p]),
+    "rd_pipe_stats": (c_i, [c_vp, c_i64p, c_i]),
     "rd_normalise_reads": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_vp, c_vp]),
     "rd_basecall_raw_chunk": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
     "rd_basecall_raw_global": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp, c_vp]),

@@ -508,6 +508,12 @@ class Backend:
         self._check(self._L.rd_pipe_submitted(self._h, ctypes.byref(n)))
         return n.value
 
+    def pipe_stats(self):
+        """counters of the reads-level pipeline (rd_pipe_stats)"""
+        v = (ctypes.c_int64 * 5)()
+        self._check(self._L.rd_pipe_stats(self._h, v, 5))
+        return dict(zip(("submitted", "delivered", "launches", "queue_launches", "limit_closes"), (int(x) for x in v)))
+
     def pipe_policy(self, beam_width, on_partition, use_lm=False):
         """what the context has measured for its global-mode group policy (rd_pipe_policy_read): ns per forward row, us per time
         step of a group's longest chain (0.0: not measured yet) and the rule in force, forward rows per chain step.  on_partition:

@@ -313,6 +313,7 @@ struct ReadsPipe {
     int cur = 0;
     int next_lane = 0;
     int64_t submitted = 0, delivered = 0, launches = 0;
+    int64_t queue_launches = 0, limit_closes = 0;   // groups searched through the work queue (oversubscribed partition); groups closed at the partition's limit instead
     hipStream_t last_dec = nullptr;   // stream of the latest beam-search launch
     hipEvent_t ev_switch = nullptr;
     Calib calib;
@@ -493,6 +494,7 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
     RD_HIP(hipEventRecord(s.dec_done, ds));
     s.busy = true;
     s.launch_seq = ++p->launches;
+    if (s.mode == 1 && s.part && s.oversub && (int)s.seqs.size() > part_seq_limit(s.part, s.W)) p->queue_launches++;
     return RD_OK;
 }
 
@@ -731,7 +733,10 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
             const double fwd_ms = (double)(g.rows + P.total_rows) * ns * 1e-6;
             // (a quarter over is tolerated: a partition 25 % behind the forward costs that much at worst; closing here costs the uncovered chain)
             if (work_ms <= 1.25 * fwd_ms && W <= rd_decode_lane_width() && !(use_lm && ctx->lm.hashed)) g.oversub = true;
-            else if ((rc = close_group(ctx, p))) return rc;
+            else {
+                p->limit_closes++;
+                if ((rc = close_group(ctx, p))) return rc;
+            }
         }
     }
     if ((rc = open_slot(ctx, p, mode, W, f16, use_lm, s_thr, r_thr, part, P.total_rows, expect_rows, &s))) return rc;
@@ -1009,6 +1014,15 @@ extern "C" int rd_pipe_submit_raw_chunk(rd_ctx* ctx, const int16_t* raw, const i
     RD_REQUIRE(labels_out && label_len && status, "rd_pipe_submit_raw_chunk: null output");
     return submit(ctx, 0, nullptr, raw, outlier_clip, read_off, n_reads, chunk_len, step, beam_width, 0, 0.0, 0.0, labels_out, nullptr, label_len,
                   status);
+}
+
+extern "C" int rd_pipe_stats(rd_ctx* ctx, int64_t* out, int n)
+{
+    RD_REQUIRE(ctx && out && n >= 1, "rd_pipe_stats: null argument");
+    const ReadsPipe* p = (const ReadsPipe*)ctx->rpipe;
+    const int64_t v[5] = {p ? p->submitted : 0, p ? p->delivered : 0, p ? p->launches : 0, p ? p->queue_launches : 0, p ? p->limit_closes : 0};
+    for (int i = 0; i < n && i < 5; i++) out[i] = v[i];
+    return RD_OK;
 }
 
 extern "C" int rd_pipe_submitted(rd_ctx* ctx, int64_t* submitted)
