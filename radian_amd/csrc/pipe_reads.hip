@@ -308,7 +308,8 @@ struct ReadsPipe {
     hipStream_t s_dec = nullptr;
     hipStream_t s_part = nullptr;   // the decode partition's stream (global mode), masked to part_cus CUs of every XCD
     int part_cus = 0;
-    RSlot slot[2];
+    static constexpr int NSLOT = 3;   // groups in existence: one gathering + up to two whose beam searches are queued on the decode stream
+    RSlot slot[NSLOT];
     RLane lane[2 * RD_MAX_LANES];   // per PHYSICAL lane: a lane and its partitioned twin are different streams, so each has its own staging / signal / descriptors
     int cur = 0;
     int next_lane = 0;
@@ -340,7 +341,7 @@ int rpipe_get(rd_ctx* ctx, ReadsPipe** out)
         int lo = 0, hi = 0;
         RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         RD_HIP(hipStreamCreateWithPriority(&p->s_dec, hipStreamNonBlocking, hi));
-        for (int i = 0; i < 2; i++) RD_HIP(hipEventCreateWithFlags(&p->slot[i].dec_done, hipEventDisableTiming));
+        for (int i = 0; i < ReadsPipe::NSLOT; i++) RD_HIP(hipEventCreateWithFlags(&p->slot[i].dec_done, hipEventDisableTiming));
         RD_HIP(hipEventCreateWithFlags(&p->ev_switch, hipEventDisableTiming));
         for (auto& f : p->calib.f) {                                       // (timing events: the policy's measurements)
             RD_HIP(hipEventCreate(&f.e0));
@@ -502,7 +503,7 @@ int close_group(rd_ctx* ctx, ReadsPipe* p)
 {
     int rc = slot_launch_decode(ctx, p, p->slot[p->cur]);
     if (rc) return rc;
-    p->cur ^= 1;
+    p->cur = (p->cur + 1) % ReadsPipe::NSLOT;
     return RD_OK;
 }
 
@@ -918,13 +919,19 @@ extern "C" int rd_pipe_policy_read(rd_ctx* ctx, int beam_width, int on_partition
 bool rd_rpipe_idle(const rd_ctx* ctx)
 {
     const ReadsPipe* p = (const ReadsPipe*)ctx->rpipe;
-    return !p || (p->slot[0].seqs.empty() && p->slot[1].seqs.empty() && !p->slot[0].busy && !p->slot[1].busy);
+    if (!p) return true;
+    for (const RSlot& s : p->slot)
+        if (!s.seqs.empty() || s.busy) return false;
+    return true;
 }
 
 int rd_rpipe_drain_decode(rd_ctx* ctx)
 {
     ReadsPipe* p = (ReadsPipe*)ctx->rpipe;
-    if (p && (p->slot[0].busy || p->slot[1].busy)) {
+    bool any_busy = false;
+    if (p)
+        for (const RSlot& s : p->slot) any_busy |= s.busy;
+    if (any_busy) {
         if (p->s_dec) RD_HIP(hipStreamSynchronize(p->s_dec));
         if (p->s_part) RD_HIP(hipStreamSynchronize(p->s_part));
     }
@@ -936,11 +943,14 @@ int rd_rpipe_flush(rd_ctx* ctx)
     ReadsPipe* p = (ReadsPipe*)ctx->rpipe;
     if (!p) return RD_OK;
     int rc;
-    RSlot& a = p->slot[p->cur ^ 1];   // launched before the open group, if at all
-    RSlot& b = p->slot[p->cur];
-    if ((rc = slot_launch_decode(ctx, p, b))) return rc;
-    if ((rc = slot_collect(p, a))) return rc;
-    return slot_collect(p, b);
+    if ((rc = slot_launch_decode(ctx, p, p->slot[p->cur]))) return rc;
+    for (;;) {   // every launched group, in launch order
+        RSlot* first = nullptr;
+        for (RSlot& s : p->slot)
+            if (s.busy && (!first || s.launch_seq < first->launch_seq)) first = &s;
+        if (!first) return RD_OK;
+        if ((rc = slot_collect(p, *first))) return rc;
+    }
 }
 
 void rd_rpipe_destroy(rd_ctx* ctx)
@@ -959,7 +969,7 @@ void rd_rpipe_destroy(rd_ctx* ctx)
         if (d.e0) (void)hipEventDestroy(d.e0);
         if (d.e1) (void)hipEventDestroy(d.e1);
     }
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < ReadsPipe::NSLOT; i++) {
         RSlot& s = p->slot[i];
         s.probs.release();
         s.mat.release();
@@ -1048,7 +1058,7 @@ extern "C" int rd_pipe_progress(rd_ctx* ctx, int64_t wait_for, int64_t* delivere
     for (;;) {
         // groups finish in launch order
         RSlot* first = nullptr;
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < ReadsPipe::NSLOT; i++)
             if (p->slot[i].busy && (!first || p->slot[i].launch_seq < first->launch_seq)) first = &p->slot[i];
         if (first) {
             const bool need = p->delivered < wait_for;
