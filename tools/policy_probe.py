@@ -18,6 +18,10 @@ sys.path.insert(0, R)
 CHUNK, STEP = 1024, 512
 
 
+class LoadWorkerFailed(RuntimeError):
+    pass
+
+
 def reads_of(n, length, seed):
     rng = np.random.default_rng(seed)
     return [np.round(rng.normal(500, 80, size=length)).astype(np.int16) for _ in range(n)]
@@ -86,7 +90,10 @@ def probe(prec="fp32", W=10, load=False, quick=False):
     bg = None
     if load:
         bg = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--load-worker", "240"], stdout=subprocess.PIPE, text=True)
-        assert "running" in bg.stdout.readline()
+        if "running" not in bg.stdout.readline():
+            bg.kill()
+            bg.wait()
+            raise LoadWorkerFailed("the background load process did not come up")
     be = Backend(0)
     try:
         be.load_weights(weights.synthetic_weights(seed=1234))
