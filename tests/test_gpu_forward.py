@@ -416,3 +416,33 @@ def test_first_conv_fused_is_bit_identical(oracle):
             assert float(np.abs(res[1][0][:3] - ref).max()) <= 1e-4, dil
     finally:
         be.close()
+
+
+def test_forward_against_stock_pytorch_operators():
+    """The HIP forward against a plain PyTorch reference of the same op, directly (not through the oracle): `F.conv1d(dilation=d)` after a
+    causal left pad, ReLU, block 0's 1x1 matching conv, Dense / ReLU / Dense / softmax in float64 on the CPU (tests/test_forward_torch_cpu.py
+    holds the statement) -- 12 windows x 1024 samples of MAD-normalised synthetic signal, the bench's He-normal weights and a soft-head set
+    (rows far from saturation, where a softmax difference cannot hide behind a saturated class), all three matrix-product modes.
+    Tolerance: north_star's 1e-4 on the softmax; observed ~1e-5.  PyTorch is test plumbing here (CPU), not the product."""
+    torch = pytest.importorskip("torch")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_forward_torch_cpu import _torch_forward
+    from radian_amd import Backend, weights, synthetic
+    from radian_amd.preprocess import mad_normalise
+    reads = synthetic.synthetic_reads(3, 4096, seed=11)
+    win = np.stack([mad_normalise(r, 4).astype(np.float32)[i * 1024:(i + 1) * 1024] for r in reads for i in range(4)])
+    win[5, :300] = 0.0
+    be = Backend(0)
+    try:
+        for tag, flat in (("he_normal", weights.synthetic_weights(seed=1234)), ("soft_head", weights.synthetic_weights(seed=77, head_gain=0.3))):
+            ref = _torch_forward(flat, win, weights.DEFAULT_DILATIONS)
+            be.load_weights(flat)
+            for prec, tol in (("fp32", 1e-4), ("bf16x3", 1e-4), ("f16x3", 1e-4)):
+                be.set_precision(prec)
+                got = be.forward(win)
+                err = float(np.abs(got - ref).max())
+                assert got.shape == ref.shape and err <= tol, (tag, prec, err)
+    finally:
+        be.set_precision("fp32")
+        be.close()
