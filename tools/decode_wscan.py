@@ -1,4 +1,5 @@
-"""Beam search alone, 512 windows x 1024 rows: us per time step against the beam width, both launch shapes."""
+"""Beam search alone, 512 windows x 1024 rows: us per time step against the beam width, the launch shapes of decode.hip and the general
+kernel of decode_wide.hip.  usage: decode_wscan.py [fast|glibc]"""
 import os, sys, time
 import numpy as np
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -18,7 +19,7 @@ d_p = be.dev_alloc(n * T * 5 * 4)
 be.forward_resident(d_w, n, T, d_p)
 valid = np.ascontiguousarray(valid_w, dtype=np.int32)
 labels = np.zeros((n, T), np.uint8); lens = np.zeros(n, np.int32)
-for W, form in ((10,"auto"),(12,"auto"),(13,"waves"),(13,"lanes"),(20,"waves"),(25,"waves"),(26,"waves"),(40,"waves"),(51,"waves"),(51,"lanes")):
+for W, form in ((10,"auto"),(12,"auto"),(13,"waves"),(13,"lanes"),(20,"waves"),(25,"waves"),(26,"waves"),(40,"waves"),(51,"waves"),(51,"lanes"),(52,"auto"),(64,"auto"),(100,"auto"),(256,"auto"),(1024,"auto"),(10,"queue")):   # (above 51: decode_wide.hip; queue: 16 waves of resident workgroups)
     be.set_decode_form(form)
     be.decode_resident(d_p, n, T, valid, W, labels, lens)
     be.timer_enable(RD_TIMER_DECODE, 8)
