@@ -232,6 +232,13 @@ inline int part_seq_limit(int part_cus, int W)
     const int waves3 = RD_XCDS * part_cus * 4 * 3;      // three waves per SIMD
     return W <= 6 ? 2 * waves3 : W <= 12 ? waves3 : W <= 25 ? waves3 / 2 : waves3 / 4;   // (W <= 6: two sequences per wave)
 }
+// sequences the work-queue search of an oversubscribed partition keeps resident: its workgroups are one sequence each (1 / 2 / 4 waves for
+// W <= 12 / 25 / 51 -- no two-sequences-per-wave form), three waves per SIMD
+inline int queue_resident_seqs(int part_cus, int W)
+{
+    const int waves3 = RD_XCDS * part_cus * 4 * 3;
+    return W <= 12 ? waves3 : W <= 25 ? waves3 / 2 : waves3 / 4;
+}
 constexpr int64_t kGroupRowsCap = 96ll << 20;   // rows a group may gather while it waits for coverage (~6 GB of probabilities + matrix)
 // CUs per XCD of the decode partition for a beam width (rd_set_decode_partition -1).  ALWAYS A MULTIPLE OF FOUR: a CU-masked
 // queue's bits are dealt round over the four shader engines of an XCD (bit j of an XCD -> engine j mod 4), and the dispatcher
@@ -459,7 +466,7 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
     // (an oversubscribed partition -- work queue, every slot taken from the start -- gives the pace at three waves per SIMD as long as its longest
     // chain, not its total work, decides when it ends: steps_total / slots well below the longest chain)
     const bool q_launch = on_part && (int)n > part_seq_limit(s.part, s.W);
-    if (s.mode == 1 && s.longest > 0 && (!q_launch || s.steps_total / part_seq_limit(s.part, s.W) <= s.longest * 4 / 5)) {
+    if (s.mode == 1 && s.longest > 0 && (!q_launch || s.steps_total / queue_resident_seqs(s.part, s.W) <= s.longest * 4 / 5)) {
         calib_harvest(p->calib);
         Calib::Dec& d = p->calib.d[p->calib.d_next % Calib::ND];
         if (!d.pending) {
@@ -730,7 +737,7 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
             const double ns = p->calib.ns_row[ctx->precision] > 0.0 ? p->calib.ns_row[ctx->precision] : kDefaultNsPerRow;
             const double* us3 = p->calib.find(Calib::key_of(W, 3, ctx->decode_math, ctx->precision, use_lm));
             const double pace3 = us3 ? *us3 : (double)chain_rows_default(W, true) * kDefaultNsPerRow * 1e-3;
-            const double work_ms = (double)(g.steps_total + (int64_t)n_samples) * pace3 * 1e-3 / (double)limit;
+            const double work_ms = (double)(g.steps_total + (int64_t)n_samples) * pace3 * 1e-3 / (double)queue_resident_seqs(part, W);
             const double fwd_ms = (double)(g.rows + P.total_rows) * ns * 1e-6;
             // (a quarter over is tolerated: a partition 25 % behind the forward costs that much at worst; closing here costs the uncovered chain)
             if (work_ms <= 1.25 * fwd_ms && W <= rd_decode_lane_width() && !(use_lm && ctx->lm.hashed)) g.oversub = true;
@@ -881,7 +888,7 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
         int64_t need = chain_rows(ctx, p->calib, W, m, use_lm) * s->longest;
         // An oversubscribed partition (decided when the crossing batch arrived, above) finishes no sooner than its total work allows: every resident slot steps at the saturated
         // pace, so the group's forward rows must also cover  steps_total x pace(3) / slots  (chain_rows(3) = that pace in forward rows + 20 %)
-        if (s->oversub) need = std::max(need, chain_rows(ctx, p->calib, W, 3, use_lm) * s->steps_total / limit);
+        if (s->oversub) need = std::max(need, chain_rows(ctx, p->calib, W, 3, use_lm) * s->steps_total / queue_resident_seqs(part, W));
         close = s->rows >= need || s->rows >= kGroupRowsCap;
         // (the very first group of a context closes with its first batch: nothing is decoding yet, and its chains start one
         // group's forward time earlier -- a quarter of a second on a job of long reads)

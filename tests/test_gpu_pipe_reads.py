@@ -284,9 +284,10 @@ def test_pipe_policy_follows_precision_changes_mid_stream(dev):
         dev.pipe_config(4)
 
 
-def test_group_larger_than_its_decode_partition_delivers_the_blocking_calls_labels(dev):
+@pytest.mark.parametrize("W", [6, 10, 25])
+def test_group_larger_than_its_decode_partition_delivers_the_blocking_calls_labels(dev, W):
     """Round 5: a global-mode group that gathers more sequences than its decode partition keeps resident (W = 10: 384) before its forward
-    rows cover its longest chain stays on the partition and is searched through the work queue (beam_search_queue_kernel: resident
+    rows cover its longest chain (W = 6: 768 two to a wave, W = 25: 192) stays on the partition and is searched through the work queue (beam_search_queue_kernel: resident
     workgroups take the sequences longest-first).  Thirty batches of 60 short reads behind one 30 000-sample read: the crossing batch
     decides (work keeps up with the forward), rd_pipe_stats counts the queue launch, and every batch's labels are the blocking call's --
     with an LM whose gate fires, in both arithmetics' default."""
@@ -303,9 +304,9 @@ def test_group_larger_than_its_decode_partition_delivers_the_blocking_calls_labe
             reads = [np.round(rng.normal(500, 80, size=30000)).astype(np.int16)] + reads
         batches.append(reads)
     try:
-        ref = [dev.basecall_raw_global(r, 4, CHUNK, 512, 10, True, 0.3, 2.0) for r in batches]
+        ref = [dev.basecall_raw_global(r, 4, CHUNK, 512, W, True, 0.3, 2.0) for r in batches]
         before = dev.pipe_stats()
-        tickets = [dev.pipe_submit_raw("global", r, 4, CHUNK, 512, 10, True, 0.3, 2.0) for r in batches]
+        tickets = [dev.pipe_submit_raw("global", r, 4, CHUNK, 512, W, True, 0.3, 2.0) for r in batches]
         got = [t.result() for t in tickets]
         after = dev.pipe_stats()
         assert after["queue_launches"] > before["queue_launches"], (before, after)
