@@ -753,6 +753,7 @@ __global__ __launch_bounds__(64) void beam_search2_kernel(DecodeArgs a, int n_se
     int nb = 1;              // beams currently kept (uniform within the half)
     int next_id = 1;         // next free trie node id of the half's sequence
     int cur = 0;             // (both halves flip together; a half that has ended stops writing)
+    int fin = 0;             // which of the half's two record buffers holds its latest beam set (steps that change nothing but the scores do not flip)
     bool missed = false;     // sparse LM: see beam_search_kernel
     // the longer of the two sequences bounds the loop (wave-uniform)
     const int T_other = __shfl_xor(T, 32);
@@ -992,6 +993,24 @@ __global__ __launch_bounds__(64) void beam_search2_kernel(DecodeArgs a, int n_se
             }
             const int nb_new = nvalid < W ? nvalid : W;
 
+            // ---------------- the step that changes nothing but the scores (see beam_search_kernel): taken when BOTH halves qualify -- the two
+            //                  sequences share the buffer flip -- where a half whose sequence has ended qualifies trivially
+            if constexpr (R == 1) {
+                const bool top = surv[0] && rank[0] < W;
+                const unsigned long long m_top = __ballot(top) & hmask, m_same = __ballot(top && dcopy[0] >= 0 && rank[0] == dcopy[0]) & hmask;
+                const bool ok_h = !live || (m_top == m_same && __popcll(m_top) == nb && nb_new == nb);
+                if (__all(ok_h)) {
+                    if (top) {
+                        Beam* const here = st_[h][cur] + rank[0];
+                        *(double2*)&here->ptot = make_double2(c_ptot[0], c_pb[0]);
+                        here->pnb = c_pnb[0];
+                    }
+                    fin = live ? cur : fin;
+                    wave_sync();
+                    continue;
+                }
+            }
+
             // ---------------- Phase E: the kept candidates move to their new beam slot
             auto scatter = [&](bool on) {
 #pragma unroll
@@ -1095,6 +1114,7 @@ __global__ __launch_bounds__(64) void beam_search2_kernel(DecodeArgs a, int n_se
             }
             nb = live ? nb_new : nb;
             cur ^= 1;
+            fin = live ? cur : fin;
             wave_sync();
         }
     }
@@ -1108,7 +1128,7 @@ __global__ __launch_bounds__(64) void beam_search2_kernel(DecodeArgs a, int n_se
         const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ka));
         const DecodeArgs* ap = (const DecodeArgs*)ka;
-        const Beam& fs = st_[h][T & 1][0];              // (the half stopped writing after its T steps: buffer = parity of T)
+        const Beam& fs = st_[h][fin][0];                // (the buffer the half's last live step left its records in)
         int n = fs.node;
         const int len = fs.len;
         uint8_t* out = ap->labels + ap->label_off[seq];
