@@ -90,6 +90,7 @@ struct Image {
 
 struct Msg {
     uint16_t type;
+    uint8_t flags;      // bit 1: the message is SHARED (its body is a reference to another object header / the shared-message heap)
     uint64_t data;
     uint32_t size;
 };
@@ -125,7 +126,7 @@ void header_messages(const Image& im, uint64_t at, std::vector<Msg>& out)
                 if (ca == kUndef) throw NoVerdict{"undefined continuation address"};
                 blocks.push_back({ca, im.u64(data + 8)});
             }
-            out.push_back({mtype, data, msize});
+            out.push_back({mtype, im.u8(p + 4), data, msize});
             p = data + msize;
         }
     }
@@ -254,6 +255,8 @@ void resolve_signal(const Image& im, uint64_t at, Signal& s)
     const Msg *dt = find_msg(ms, 0x0003), *sp = find_msg(ms, 0x0001), *lay = find_msg(ms, 0x0008);
     if (!dt || !sp || !lay) throw NoVerdict{"Signal is not a dataset"};
     if (find_msg(ms, 0x000B)) throw NoVerdict{"Signal is stored with a filter pipeline (compression)"};
+    if (find_msg(ms, 0x0007)) throw NoVerdict{"Signal lives in external files"};
+    if ((dt->flags | sp->flags | lay->flags) & 0x02) throw NoVerdict{"shared (committed) datatype / dataspace message"};
     // datatype: class 0 (fixed point), little-endian, signed, 2 bytes, 16-bit precision at offset 0
     const uint8_t cv = im.u8(dt->data), bits0 = im.u8(dt->data + 1);
     if ((cv & 0x0f) != 0 || (bits0 & 1) || !(bits0 & 8) || im.u32(dt->data + 4) != 2) throw NoVerdict{"Signal is not little-endian int16"};
@@ -334,8 +337,13 @@ bool string_attr(const Image& im, uint64_t at, const char* name, std::string& ou
 {
     std::vector<Msg> ms;
     header_messages(im, at, ms);
+    if (const Msg* ai = find_msg(ms, 0x0015)) {      // attribute info: attributes may live in a fractal heap ("dense" storage) instead of the header
+        const uint8_t fl = im.u8(ai->data + 1);
+        if (im.u64(ai->data + 2 + ((fl & 1) ? 2 : 0)) != kUndef) throw NoVerdict{"dense attribute storage"};
+    }
     for (const Msg& m : ms) {
         if (m.type != 0x000C) continue;
+        if (m.flags & 0x02) throw NoVerdict{"shared attribute message"};
         const uint8_t ver = im.u8(m.data);
         if (ver < 1 || ver > 3) continue;
         const unsigned nsz = im.u16(m.data + 2), tsz = im.u16(m.data + 4), ssz = im.u16(m.data + 6);
