@@ -47,7 +47,7 @@ const char* rd_last_error(void);
 int rd_version(void);                 /* ABI version, currently 1 */
 int rd_device_count(int* n);          /* number of visible HIP devices */
 int rd_decode_max_width(void);        /* largest supported --beam-width (1024; radian/decode.py:145 slices with any width) */
-int rd_decode_lane_width(void);       /* widths up to this (51) run on the wave-per-sequence kernels, wider ones on the general kernel */
+int rd_decode_lane_width(void);       /* widths up to this (64) run on the wave-per-sequence kernels, wider ones on the general kernel */
 
 /* ---- context ------------------------------------------------------------------------------- */
 int rd_create(int device_id, rd_ctx** out);
@@ -126,7 +126,7 @@ int rd_set_logits(rd_ctx* ctx, int mode);
  * Widths up to 6 (the reference's default, basecall.py:32) run two sequences per wave (one candidate per lane of a half-wave);
  * widths 7..12 run ONE sequence per wave under form 0 -- two per wave (two candidates per lane) exists and measured slower, so
  * only form 3 selects it; 3 = two per wave whenever the width allows (up to 12), 4 = always one per wave.  Widths above
- * rd_decode_lane_width() run on the general kernel whatever the form.  5 = every launch (widths up to rd_decode_lane_width(), no hashed
+ * rd_decode_lane_width() run on the general kernel whatever the form.  5 = every launch (widths up to 51, no hashed
  * contexts) through the work-queue kernel with 16 waves' worth of workgroups: the form the reads pipeline uses, with the partition's
  * resident count, for a group that holds more sequences than its decode partition.  For tests and measurements. */
 int rd_set_decode_form(rd_ctx* ctx, int form);

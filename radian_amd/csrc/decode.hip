@@ -53,6 +53,12 @@ struct Cfg {
     static constexpr int NC = 64 * R * NW;  // candidate capacity
     static constexpr int WM = NC / 5;       // max beam width
 };
+// four waves, two candidates per lane: 512 candidates would carry 102 beams, but a beam set is built by the lanes of ONE wave (the trie
+// phase), so this shape ends at 64 beams -- widths 52 ... 64 (round 5: 64 is the width people type after 32)
+template <>
+struct Cfg<2, 4> {
+    static constexpr int WM = 64;
+};
 
 
 // Hand-off between the waves of a sequence's workgroup.  One wave: see wave_sync.  Several waves: the LDS operations of
@@ -94,7 +100,7 @@ __device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int 
     constexpr int SEG = 64 + KG;        // doubles per segment: 64 keys + the padding of the last group
     constexpr int LOG_TN = R * NW <= 2 ? 9 : 10;
     constexpr int TN = 1 << LOG_TN;     // (LDS per sequence bounds the resident waves: 2 KiB / 4 KiB)
-    static_assert(WM < 64, "the kept beams fit the lanes of one wave");
+    static_assert(WM <= 64, "the kept beams fit the lanes of one wave");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1149,6 +1155,7 @@ __global__ __launch_bounds__(64) void beam_search2_kernel(DecodeArgs a, int n_se
 // (rd_set_decode_form pins one form, for tests and measurements.)
 constexpr int kMaxW = Cfg<1, 4>::WM;
 static_assert(Cfg<2, 2>::WM == kMaxW, "both forms cover the same widths");
+constexpr int kMaxW2 = Cfg<2, 4>::WM;   // 64: widths 52 ... 64 on four waves with two candidates per lane
 
 template <typename PT, int R, int NW, bool GX>
 int launch_g(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
@@ -1226,6 +1233,7 @@ int launch_pt(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm, int n_sim
     const bool mid = a.W <= Cfg<1, 2>::WM;
     const bool wide = form == 1 || (form == 0 && (long long)n_seq * (mid ? 2 : 4) <= n_simd);
     if (mid) return wide ? launch_r<PT, 1, 2>(st, a, n_seq, lm) : launch_r<PT, 2, 1>(st, a, n_seq, lm);
+    if (a.W > kMaxW) return launch_r<PT, 2, 4>(st, a, n_seq, lm);      // 52 ... 64
     return wide ? launch_r<PT, 1, 4>(st, a, n_seq, lm) : launch_r<PT, 2, 2>(st, a, n_seq, lm);
 }
 
@@ -1244,7 +1252,7 @@ __global__ void lm_gate_kernel(const double* __restrict__ entropy, size_t n, dou
 }  // namespace
 
 extern "C" int rd_decode_max_width(void) { return RD_WIDE_MAX_W; }
-extern "C" int rd_decode_lane_width(void) { return kMaxW; }
+extern "C" int rd_decode_lane_width(void) { return kMaxW2; }
 
 // Per-context gate bits: bit = (entropy(lm[ctx]) < r_threshold)   decode.py:85-93.
 // The entropies were computed once at rd_load_lm (glibc log, like the reference's math.log) and live in HBM.
@@ -1321,7 +1329,7 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_
              : ptype == 2 ? launch_queue_pt<_Float16>(st, a, n_seq, use_lm != 0, queue_wave_slots, counter)
                           : launch_queue_pt<float>(st, a, n_seq, use_lm != 0, queue_wave_slots, counter);
     } else
-    rc = W > kMaxW ? rd_decode_wide_launch(ctx, st, &a, ptype, n_seq, total_nodes, use_lm != 0)   // (decode_wide.hip: any wider beam)
+    rc = W > kMaxW2 ? rd_decode_wide_launch(ctx, st, &a, ptype, n_seq, total_nodes, use_lm != 0)   // (decode_wide.hip: any wider beam)
              : ptype == 1 ? launch_pt<double>(st, a, n_seq, use_lm != 0, n_simd, ctx->decode_form)
              : ptype == 2 ? launch_pt<_Float16>(st, a, n_seq, use_lm != 0, n_simd, ctx->decode_form) : launch_pt<float>(st, a, n_seq, use_lm != 0, n_simd, ctx->decode_form);
     if (rc) return rc;

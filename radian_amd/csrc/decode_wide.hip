@@ -1,8 +1,8 @@
-// decode_wide.hip -- CTC prefix beam search for beam widths above the wave-per-sequence kernels' 51 (decode.hip).
+// decode_wide.hip -- CTC prefix beam search for beam widths above the wave-per-sequence kernels' 64 (decode.hip).
 //
 // radian/decode.py:145 slices `sort_labelings()[:beam_width]` with whatever --beam-width the user gave (basecall.py:32), so
 // a width of 64 or 100 is a valid run of the reference.  decode.hip keeps a sequence's whole beam set in the lanes and LDS of
-// one to four waves, which ends at 51 beams; this kernel is the general form: one workgroup of four waves per sequence, the
+// one to four waves, which ends at 64 beams (a beam set is built by the lanes of one wave); this kernel is the general form: one workgroup of four waves per sequence, the
 // kept beams and the 5 W candidates of a time step in an HBM scratch block per sequence (L2-resident: <= 300 W bytes), only
 // the ranking keys in LDS (40 W bytes).  Same semantics, phase for phase, as beam_search_kernel:
 //   A  candidate q = 5 i + k (k = 0: the copy of kept beam i, decode.py:150-175; k = 1..4: its extension by label k - 1,
@@ -332,13 +332,13 @@ int launch_wide_pt(hipStream_t st, const DecodeArgs& a, const WideArgs& w, int n
 
 }  // namespace
 
-// Widths above rd_decode_lane_width() (51).  `a` is the argument block rd_decode_dev has filled (decode.hip); the scratch block and the
+// Widths above rd_decode_lane_width() (64).  `a` is the argument block rd_decode_dev has filled (decode.hip); the scratch block and the
 // slot map come out of the context's workspaces, which -- like the trie -- one beam search uses at a time.
 int rd_decode_wide_launch(rd_ctx* ctx, hipStream_t st, const void* args, int ptype, int n_seq, int64_t total_nodes, bool lm)
 {
     const DecodeArgs& a = *(const DecodeArgs*)args;
     RD_REQUIRE(a.W <= RD_WIDE_MAX_W, "beam_width %d out of range [1,%d]", a.W, RD_WIDE_MAX_W);
-    RD_REQUIRE(!(lm && a.hashed), "beam widths above %d do not combine with hashed long contexts (rd_load_lm_hashed)", 51);
+    RD_REQUIRE(!(lm && a.hashed), "beam widths above %d do not combine with hashed long contexts (rd_load_lm_hashed)", 64);
     WideArgs w;
     w.stride = wide_scratch_bytes(a.W);
     if (ctx->ws_wide.reserve(w.stride * (size_t)n_seq)) return RD_ERR_NOMEM;

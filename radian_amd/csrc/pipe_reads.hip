@@ -740,7 +740,7 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
             const double work_ms = (double)(g.steps_total + (int64_t)n_samples) * pace3 * 1e-3 / (double)queue_resident_seqs(part, W);
             const double fwd_ms = (double)(g.rows + P.total_rows) * ns * 1e-6;
             // (a quarter over is tolerated: a partition 25 % behind the forward costs that much at worst; closing here costs the uncovered chain)
-            if (work_ms <= 1.25 * fwd_ms && W <= rd_decode_lane_width() && !(use_lm && ctx->lm.hashed)) g.oversub = true;
+            if (work_ms <= 1.25 * fwd_ms && W <= 51 /* (the work-queue kernel's shapes) */ && !(use_lm && ctx->lm.hashed)) g.oversub = true;
             else {
                 p->limit_closes++;
                 if ((rc = close_group(ctx, p))) return rc;
