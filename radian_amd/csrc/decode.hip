@@ -459,7 +459,7 @@ __device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int 
             // When every entry of the new top W is a kept labeling -- its copy, or its copy merged with an extension -- at the rank of
             // its old slot, the beam set, its order, every trie id and every id-table entry stay as they are: the three scores go into
             // the records where they lie, and the scatter, the claim check and the trie phase (a quarter of the step) are skipped.
-            // On peaked rows that is almost every step (a patched oracle counted 97 % of the bench's steps at W = 10; on soft rows 1 %).
+            // On peaked rows that is almost every step (counted on the CPU over the bench's windows: 97 % of the steps at W = 10; on soft rows 1 %).
             // Conservative on ties: the count is of strictly greater keys, so two equal keys share a rank, one of them misses its
             // slot's number and the step takes the general path, which orders ties as the reference does.
             if constexpr (NW == 1 && R == 1) {
