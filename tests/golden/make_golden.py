@@ -717,6 +717,34 @@ def gen_beam_baseline():
     print("beam_baseline:", by, f"{time.time() - t_start:.0f}s")
 
 
+# ----------------------------------------------------------------------------------------------
+# 9. configs[2]'s chunk route at its own geometry, decode side (round 5): 4096 samples -> 8 windows of 1024 rows (step 512, last one
+#    trimmed by the pad, basecall.py:96) -> per-window beam search W = 10 without an LM (basecall.py:110-121) -> simple_assembly + argmax
+#    (basecall.py:122-123), on peaky and flat synthetic window probabilities; plus the reference's default step 128 (25 windows), W = 6
+# ----------------------------------------------------------------------------------------------
+def gen_pipeline_baseline():
+    rng = np.random.default_rng(20261008)
+    arrays, cases = {}, []
+    for ci, (step, kind, W) in enumerate(((512, "peaky", 10), (512, "flat", 10), (128, "peaky", 6), (512, "peaky", 1))):
+        windows, pad = ref_pre.get_windows(np.zeros(4096), 1024, step)
+        nW = windows.shape[0]
+        probs = np.stack([make_matrix(rng, 1024, kind, np.float32) for _ in range(nW)])
+        arrays[f"probs{ci}"] = probs
+        mats = [probs[i] for i in range(nW)]
+        mats[-1] = mats[-1][:-pad]
+        frags = [ref_decode.beam_search(m, BASES, W, None, None, None, None, None) for m in mats]
+        cons = ref_seq.simple_assembly(frags)
+        seq = ref_seq.index2base(np.argmax(cons, axis=0)) if cons.shape[1] else ""
+        cases.append({"probs": f"probs{ci}", "chunk": 1024, "step": step, "N": 4096, "pad": int(pad), "nW": int(nW), "kind": kind, "W": W,
+                      "chunk_fragments": frags, "chunk_seq": seq})
+        print(f"  pipeline_baseline step={step} {kind} W={W}: {nW} windows, fragments of {min(map(len, frags))}..{max(map(len, frags))} bases, consensus {len(seq)}", flush=True)
+    np.savez_compressed(os.path.join(HERE, "pipeline_baseline.npz"), **arrays)
+    with open(os.path.join(HERE, "pipeline_baseline_cases.json"), "w") as f:
+        json.dump({"source": "basecall.py:96,110-123 on synthetic window probabilities at BASELINE configs[2]'s geometry (sequence NOT yet reversed)",
+                   "cases": cases}, f, indent=0)
+    print("pipeline_baseline:", len(cases), "cases")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:       # regenerate single fixture sets: make_golden.py gen_seq_assembly_random ...
         for name in sys.argv[1:]:
@@ -732,5 +760,6 @@ if __name__ == "__main__":
     gen_fast5_signals()
     gen_pipeline()
     gen_beam_baseline()
+    gen_pipeline_baseline()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE))
     print("total bytes in tests/golden:", tot)

@@ -566,3 +566,26 @@ def test_work_queue_form_matches_the_reference(be, golden_dir, oracle):
     finally:
         be.load_lm(None, 0)
         be.set_decode_form("auto")
+
+
+def test_baseline_chunk_route_vs_reference(be, golden_dir):
+    """configs[2]'s chunk route at its own geometry against the imported reference directly: the reference's window probabilities -> the GPU's
+    per-window beam search (W = 10 / 6 / 1, valid rows = the pad trim) -> the native stitch (rd_stitch_chunk): fragments and consensus equal."""
+    from radian_amd.sequence_assembly import consensus_batch
+    g = json.load(open(os.path.join(golden_dir, "pipeline_baseline_cases.json")))
+    arr = np.load(os.path.join(golden_dir, "pipeline_baseline.npz"))
+    be.load_lm(None, 0)
+    for c in g["cases"]:
+        probs = arr[c["probs"]]
+        nW, T, _ = probs.shape
+        lens = np.full(nW, T, dtype=np.int32)
+        lens[-1] = T - c["pad"]
+        off = np.arange(nW, dtype=np.int64) * T
+        labs = be.decode_batch(probs.reshape(-1, 5), off, lens, c["W"])
+        assert [s_of(l) for l in labs] == c["chunk_fragments"], (c["step"], c["kind"], c["W"])
+        lab2d = np.zeros((nW, T), dtype=np.uint8)
+        ll = np.zeros(nW, dtype=np.int32)
+        for i, l in enumerate(labs):
+            lab2d[i, : len(l)] = l
+            ll[i] = len(l)
+        assert consensus_batch(lab2d, ll, [nW], threads=2) == [c["chunk_seq"]]

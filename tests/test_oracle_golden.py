@@ -303,3 +303,18 @@ def test_baseline_single_window_float32_with_lm(oracle, golden_dir):
         labels, final = oracle.beam_search_labels(mat, c["W"], lm, fdec(c["s_thr"]), fdec(c["r_thr"]), c["k"], max_final=1)
         assert "".join(BASES[x] for x in labels) == c["seq"], (c["mat"], c["lm"], c["W"])
         assert same_float(final[0][1], fdec(c["winner_pr_total"]))
+
+
+def test_baseline_chunk_route_decode_side(oracle, golden_dir):
+    """configs[2]'s chunk route at its own geometry, decode side, against the imported reference: 8 (step 512) / 26 (step 128) window matrices
+    of a 4096-sample read -> pad trim -> per-window beam search (W = 10, 6, 1; no LM) -> simple_assembly + argmax."""
+    g = _load(golden_dir, "pipeline_baseline_cases.json")
+    arr = np.load(os.path.join(golden_dir, "pipeline_baseline.npz"))
+    assert len(g["cases"]) == 4
+    for c in g["cases"]:
+        probs = arr[c["probs"]]
+        nW, chunk, _ = probs.shape
+        assert (nW, chunk) == (c["nW"], 1024)
+        frags = [oracle.beam_search(probs[i] if i < nW - 1 else probs[i][: chunk - c["pad"]], BASES, c["W"]) for i in range(nW)]
+        assert frags == c["chunk_fragments"], (c["step"], c["kind"], c["W"])
+        assert oracle.chunk_consensus(frags) == c["chunk_seq"]
