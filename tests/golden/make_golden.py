@@ -376,6 +376,10 @@ def gen_preprocess():
     spikes[rng.integers(0, 1000, size=30)] = -32000
     spikes[0] = 500
     add("spikes", spikes)
+    # BASELINE's own read: 4096 samples of round(N(500, 80)) (SURVEY 8d cfg 2; the bench's generator, seed 0), chunk 1024 at step 512 and 128
+    bench_read = np.round(np.random.default_rng(0).normal(500.0, 80.0, size=4096)).astype(np.int16)
+    add("baseline_4096_step512", bench_read, chunk=1024, step=512)
+    add("baseline_4096_step128", bench_read, chunk=1024, step=128)
     # get_windows argument errors
     errs = []
     for (chunk, step) in ((64, 0), (64, 65), (64, -1)):
