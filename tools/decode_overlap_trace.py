@@ -45,3 +45,21 @@ if din and dout:
 qs={}
 for c in conv: qs[c[3]]=qs.get(c[3],0)+1
 print("conv kernels per queue:", qs, "| beam searches per queue:", {q:sum(1 for e in dec if e[3]==q) for q in set(e[3] for e in dec)})
+# per search: start (ms), duration (ms), share of it with a conv kernel running
+t00 = min(e[0] for e in ev)
+rows = []
+for d0, d1, name, q in sorted(dec):
+    i = bisect.bisect_left(starts, d0 - 50_000_000)
+    segs = []
+    for c in conv[i:]:
+        if c[0] > d1: break
+        a = max(c[0], d0); b = min(c[1], d1)
+        if b > a: segs.append((a, b))
+    segs.sort(); u = 0; cur = None
+    for a, b in segs:
+        if cur is None: cur = [a, b]
+        elif a <= cur[1]: cur[1] = max(cur[1], b)
+        else: u += cur[1] - cur[0]; cur = [a, b]
+    if cur: u += cur[1] - cur[0]
+    rows.append(f"{(d0 - t00) / 1e6:.0f}:{(d1 - d0) / 1e6:.0f}ms:{u / (d1 - d0):.2f}")
+print("per search start:duration:covered ->", " ".join(rows))

@@ -19,10 +19,14 @@ if len(sys.argv) > 4 and sys.argv[4] == "load":
 be = Backend(0)
 be.load_weights(weights.synthetic_weights(seed=1234))
 be.set_precision(prec)
+if os.environ.get("FORM"):
+    be.set_decode_form(os.environ["FORM"])
 short, long_ = pp.reads_of(64, 4096, 1), pp.reads_of(6, 40960, 2) + pp.reads_of(4, 4096, 3)
-pp.stream(be, [short, long_], W, 80)
-r = [pp.stream(be, [short, long_], W, n) for _ in range(3)]
-print(json.dumps({"alternating_samples_per_s": r, "policy": {m: be.pipe_policy(W, m) for m in (0, 1, 2, 3)}}))
+kind = os.environ.get("STREAM", "alternating")       # alternating | long | short
+batches = {"alternating": [short, long_], "long": [long_], "short": [short]}[kind]
+pp.stream(be, batches, W, 80)
+r = [pp.stream(be, batches, W, n) for _ in range(3)]
+print(json.dumps({"stream": kind, "alternating_samples_per_s": r, "stats": be.pipe_stats(), "policy": {m: be.pipe_policy(W, m) for m in (0, 1, 2, 3)}}))
 be.close()
 if bg is not None:
     bg.terminate()
