@@ -1,3 +1,6 @@
+"""Host time of every rd_pipe_submit_raw_global call of a stream of small long-read batches (6 x 40960 + 4 x 4096 samples, W = 10): which
+submits take longer than 20 ms, when, and how many groups had been launched (DESIGN_LOG.md round 5: the staging-event wait of the
+uncovered mode).  usage (GPU box): python tools/submit_times.py"""
 import json, os, sys, time
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tools"))

@@ -1,3 +1,5 @@
+"""From a rocprofv3 --kernel-trace directory of a pipelined global-mode run: the kernel timeline (queue, kind, start, duration; runs of conv
+kernels compressed) from 30 ms before to 30 ms after one long beam search.  usage: trace_excerpt.py <dir> [index of the search = -6]"""
 import csv, glob, sys
 d=sys.argv[1]
 p=glob.glob(d+"/*/*_kernel_trace.csv")[0]
