@@ -26,6 +26,37 @@ using namespace rdi;
 
 namespace {
 
+// ---- copies as kernels on the stream's OWN queue ----------------------------------------------------------------------------------------
+// hipMemcpyAsync hands a copy to the runtime's copy path (SDMA engines, or its blit queue), which is shared by all streams and keeps its
+// order: a copy that waits for a kernel -- the labels going back to the host behind a 70-ms beam search -- holds up every later copy in it,
+// among them the next group's first host-to-device copies, and the forward lanes stand still for the length of the search.  Which engine a
+// copy lands on varies, so a stream of small long-read batches ran at 27.9 or at 20 M samples/s, flipping within a run; with
+// HSA_ENABLE_SDMA=0 (one shared blit queue) always at 17.3 (tools/policy_alt_run.py STREAM=long; DESIGN_LOG.md round 5).  The pipeline's
+// copies therefore run as an ordinary kernel in the queue of the stream they belong to: pinned host memory is device-addressable, the
+// volumes are small (0.5 MB of samples per batch in, a few MB of labels per group out), and nothing outside that stream waits behind them.
+__global__ void copy_bytes_kernel(char* __restrict__ dst, const char* __restrict__ src, size_t n)
+{
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 16;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
+        for (size_t i = i0; i + 16 <= n; i += stride) *(uint4*)(dst + i) = *(const uint4*)(src + i);
+        const size_t tail = n & ~(size_t)15;
+        if (blockIdx.x == 0 && threadIdx.x < (n & 15)) dst[tail + threadIdx.x] = src[tail + threadIdx.x];
+    } else {
+        for (size_t i = i0; i < n; i += stride)
+            for (size_t k = i; k < n && k < i + 16; k++) dst[k] = src[k];
+    }
+}
+int copy_on_stream(void* dst, const void* src, size_t n, hipStream_t st)
+{
+    if (n == 0) return RD_OK;
+    const size_t chunks = (n + 15) / 16;
+    const int blocks = (int)std::min<size_t>((chunks + 255) / 256, 1024);
+    hipLaunchKernelGGL(copy_bytes_kernel, dim3(blocks), dim3(256), 0, st, (char*)dst, (const char*)src, n);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
 // forward rows a group must hold per beam-search step of its longest read before it may close early (global mode):
 // forward ~29 M rows/s = 34 ns per row; a step costs 1.6-2.0 us (W <= 12), 2.7-3.1 us (W <= 25), 4-6 us beyond
 // Two regimes for the beam search of a global-mode group (a read's search is one serial chain of a step per sample):
@@ -459,7 +490,7 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
     s.dec_stream = ds;
     for (int l = 0; l < 2 * RD_MAX_LANES; l++)   // every forward / assembly that wrote into this group has finished
         if (s.lane_mask & (1u << l)) RD_HIP(hipStreamWaitEvent(ds, ctx->lanes[l].done, 0));
-    RD_HIP(hipMemcpyAsync(s.meta.p, s.h_meta, o_llen, hipMemcpyHostToDevice, ds));
+    if ((rc = copy_on_stream(s.meta.p, s.h_meta, o_llen, ds))) return rc;
     char* dm = (char*)s.meta.p;
     // global mode: the group's beam search is timed for the group policy (Calib)
     Calib::Dec* cd = nullptr;
@@ -495,10 +526,10 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
         RD_HIP(hipEventRecord(cd->e1, ds));
         cd->pending = true;
     }
-    RD_HIP(hipMemcpyAsync(s.h_out, s.labels.p, (size_t)s.labels_total, hipMemcpyDeviceToHost, ds));
-    RD_HIP(hipMemcpyAsync((char*)s.h_out + ho_len, dm + o_llen, n * 4, hipMemcpyDeviceToHost, ds));
+    if ((rc = copy_on_stream(s.h_out, s.labels.p, (size_t)s.labels_total, ds))) return rc;
+    if ((rc = copy_on_stream((char*)s.h_out + ho_len, dm + o_llen, n * 4, ds))) return rc;
     if (s.n_reads && s.status.p)
-        RD_HIP(hipMemcpyAsync((char*)s.h_out + s.status_off, s.status.p, (size_t)s.n_reads * 4, hipMemcpyDeviceToHost, ds));
+        if ((rc = copy_on_stream((char*)s.h_out + s.status_off, s.status.p, (size_t)s.n_reads * 4, ds))) return rc;
     RD_HIP(hipEventRecord(s.dec_done, ds));
     s.busy = true;
     s.launch_seq = ++p->launches;
@@ -609,7 +640,10 @@ int lane_plan_upload(FwdLane* L, RLane& R, char* hs)
             R.lists.rows[li] = R.lists.rows[0];
         }
     }
-    if (off) RD_HIP(hipMemcpyAsync(R.tiles.p, hs, off * sizeof(TileDesc), hipMemcpyHostToDevice, L->st));
+    if (off) {
+        int rc_ = copy_on_stream(R.tiles.p, hs, off * sizeof(TileDesc), L->st);
+        if (rc_) return rc_;
+    }
     // the host copies of the descriptors are not needed again (the per-sequence vectors of the plan are)
     for (int li = 0; li < RD_MAX_LAYERS; li++) std::vector<TileDesc>().swap(P.tiles[li]);
     R.valid = true;
@@ -838,8 +872,8 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
         memcpy(hs, read_off, (size_t)(n_reads + 1) * 8);
         memcpy(hs + o_raw, raw, n_samples * 2);
         char* base = (char*)R.raw.p;
-        RD_HIP(hipMemcpyAsync(base, hs, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, L->st));
-        RD_HIP(hipMemcpyAsync(base + d_raw, hs + o_raw, n_samples * 2, hipMemcpyHostToDevice, L->st));
+        if ((rc = copy_on_stream(base, hs, (size_t)(n_reads + 1) * 8, L->st))) return rc;
+        if ((rc = copy_on_stream(base + d_raw, hs + o_raw, n_samples * 2, L->st))) return rc;
         if ((rc = rd_normalise_dev(ctx, (const int16_t*)(base + d_raw), (const int64_t*)base, n_reads, clip, R.sig.as<float>(),
                                    (int32_t*)(base + d_st), L->st)))
             return rc;
@@ -850,7 +884,7 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
         return rc;
     }
     AsmRead* d_ar = (AsmRead*)((char*)R.tiles.p + d_asm);
-    if (n64) RD_HIP(hipMemcpyAsync(d_ar, hs + o_asm, (size_t)n64 * sizeof(AsmRead), hipMemcpyHostToDevice, L->st));
+    if (n64 && (rc = copy_on_stream(d_ar, hs + o_asm, (size_t)n64 * sizeof(AsmRead), L->st))) return rc;
     RD_HIP(hipEventRecord(R.staged, L->st));   // the staging block is free once these copies are done
     R.staged_pending = true;
     const size_t rb = f16 ? 10 : 20;
@@ -858,7 +892,7 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
     if (n64 && (rc = rd_assemble_batch_dev(L->st, s->probs.p, d_ar, n64, max_n, chunk_len, step, s->mat.as<double>(), R.streamed ? 1 : 0, f16)))
         return rc;
     if (raw)
-        RD_HIP(hipMemcpyAsync((char*)s->status.p + (size_t)s->n_reads * 4, (char*)R.raw.p + d_st, (size_t)n_reads * 4, hipMemcpyDeviceToDevice, L->st));
+        if ((rc = copy_on_stream((char*)s->status.p + (size_t)s->n_reads * 4, (char*)R.raw.p + d_st, (size_t)n_reads * 4, L->st))) return rc;
     RD_HIP(hipEventRecord(L->done, L->st));   // the decode stream waits for this before it reads the group
     if (cf) {   // the policy's forward-pace measurement: the end of this submit's lane work
         RD_HIP(hipEventRecord(cf->e1, L->st));

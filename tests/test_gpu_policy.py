@@ -7,9 +7,10 @@ things it does not measure itself and on input it was not tuned on (VERDICT r4 #
   * a stream whose batches ALTERNATE between 64 reads of 4 096 samples and 6 reads of 40 960 (the longest read jumps 10x from one batch to
     the next, same samples per batch) keeps up with the steady state (the harmonic mean of the two uniform streams) -- at the metric's
     width in exact fp32, and at W = 25 in bf16x3, where round 4's "close at the partition's sequence limit" rule fell to 0.25 (6.5 M against
-    32 / 22 M samples/s).  Round 5 (work-aware close rule, work-queue beam search, the busy-slot fix in open_slot): 0.73-1.3 over a
-    dozen runs, median ~0.9, and 0.83-1.19 over the 21 samples taken after the last fix (profiles/r05_policy_probe.txt) -- the stream-to-stream spread of ONE configuration is
-    +-20 %, so the assertion is 0.6: what separates "keeps up" from round 4's collapse, not the verdict's 0.8, which single runs miss.
+    32 / 22 M samples/s).  Round 5 (work-aware close rule, work-queue beam search, the busy-slot fix in open_slot, a third group slot, and --
+    what removed the run-to-run spread -- the pipeline's copies as kernels on their own stream's queue instead of hipMemcpyAsync, whose shared
+    copy path let the labels' copy behind a running search hold up the next group's host-to-device copies): all three streams run at the
+    forward's pace, alternating / steady 0.98-1.06 (profiles/r05_policy_probe.txt).  Asserted: the verdict's 0.8 and 2x.
 Streams are ~100 M samples each."""
 import os
 import sys
@@ -42,7 +43,7 @@ def test_policy_figures_and_alternating_stream_fp32_beam10():
     d = policy_probe.probe("fp32", 10, load=False)
     print({k: v for k, v in d.items() if not k.startswith("policy")})
     _check_figures(d)
-    assert d["alternating_over_steady"] >= 0.6, d["alternating_over_steady"]
+    assert d["alternating_over_steady"] >= 0.8, d["alternating_over_steady"]
     assert min(d["samples_per_s_short"], d["samples_per_s_long"], d["samples_per_s_alternating"]) > 12e6      # (nothing collapsed: ~20-28 M each)
 
 
@@ -54,7 +55,7 @@ def test_policy_follows_a_gpu_shared_with_another_process():
         pytest.skip(str(e))
     print({k: v for k, v in d.items() if not k.startswith("policy")})
     _check_figures(d)
-    assert d["alternating_over_steady"] >= 0.6, d["alternating_over_steady"]
+    assert d["alternating_over_steady"] >= 0.8, d["alternating_over_steady"]
 
 
 def test_alternating_stream_wide_beam_bf16x3():
@@ -62,4 +63,4 @@ def test_alternating_stream_wide_beam_bf16x3():
     d = policy_probe.probe("bf16x3", 25, load=False)
     print({k: v for k, v in d.items() if not k.startswith("policy")})
     _check_figures(d, factor=2.5)       # (W = 25: three chains per SIMD step at 4.3-5.8 us against a lone chain's 2.5)
-    assert d["alternating_over_steady"] >= 0.6, d["alternating_over_steady"]
+    assert d["alternating_over_steady"] >= 0.8, d["alternating_over_steady"]
