@@ -47,9 +47,15 @@ __global__ void copy_bytes_kernel(char* __restrict__ dst, const char* __restrict
             for (size_t k = i; k < n && k < i + 16; k++) dst[k] = src[k];
     }
 }
-int copy_on_stream(void* dst, const void* src, size_t n, hipStream_t st)
+// (as_kernel = false: the runtime's copy path -- chunk-mode groups, whose searches last a millisecond: nothing waits behind them for long, and an
+// SDMA copy of the group's 4 MB of labels costs the forward nothing, where the copy kernel's waves cost the headline 1 %)
+int copy_on_stream(void* dst, const void* src, size_t n, hipStream_t st, bool as_kernel = true)
 {
     if (n == 0) return RD_OK;
+    if (!as_kernel) {
+        RD_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDefault, st));
+        return RD_OK;
+    }
     const size_t chunks = (n + 15) / 16;
     const int blocks = (int)std::min<size_t>((chunks + 255) / 256, 1024);
     hipLaunchKernelGGL(copy_bytes_kernel, dim3(blocks), dim3(256), 0, st, (char*)dst, (const char*)src, n);
@@ -490,7 +496,8 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
     s.dec_stream = ds;
     for (int l = 0; l < 2 * RD_MAX_LANES; l++)   // every forward / assembly that wrote into this group has finished
         if (s.lane_mask & (1u << l)) RD_HIP(hipStreamWaitEvent(ds, ctx->lanes[l].done, 0));
-    if ((rc = copy_on_stream(s.meta.p, s.h_meta, o_llen, ds))) return rc;
+    const bool kc = s.mode == 1;     // global mode: the search behind these copies runs for tens of milliseconds
+    if ((rc = copy_on_stream(s.meta.p, s.h_meta, o_llen, ds, kc))) return rc;
     char* dm = (char*)s.meta.p;
     // global mode: the group's beam search is timed for the group policy (Calib)
     Calib::Dec* cd = nullptr;
@@ -526,10 +533,10 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
         RD_HIP(hipEventRecord(cd->e1, ds));
         cd->pending = true;
     }
-    if ((rc = copy_on_stream(s.h_out, s.labels.p, (size_t)s.labels_total, ds))) return rc;
-    if ((rc = copy_on_stream((char*)s.h_out + ho_len, dm + o_llen, n * 4, ds))) return rc;
+    if ((rc = copy_on_stream(s.h_out, s.labels.p, (size_t)s.labels_total, ds, kc))) return rc;
+    if ((rc = copy_on_stream((char*)s.h_out + ho_len, dm + o_llen, n * 4, ds, kc))) return rc;
     if (s.n_reads && s.status.p)
-        if ((rc = copy_on_stream((char*)s.h_out + s.status_off, s.status.p, (size_t)s.n_reads * 4, ds))) return rc;
+        if ((rc = copy_on_stream((char*)s.h_out + s.status_off, s.status.p, (size_t)s.n_reads * 4, ds, kc))) return rc;
     RD_HIP(hipEventRecord(s.dec_done, ds));
     s.busy = true;
     s.launch_seq = ++p->launches;
