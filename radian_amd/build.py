@@ -37,7 +37,7 @@ def build(force=False, verbose=False, defines=(), out=None):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out or LIB] + objs + ["-ldl"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out or LIB] + objs + ["-ldl", "-lz"]
     subprocess.check_call(cmd)
     return out or LIB
 

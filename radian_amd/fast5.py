@@ -9,7 +9,7 @@ with the id in that group's `read_id` attribute.  VBZ-compressed signals need ON
 Two readers behind the same interface.  The NATIVE batch reader (csrc/fast5.hip, rd_fast5_*: a bounds-checked walk of the classic HDF5
 layout over a mapping of the file) resolves and copies a block of reads per call, with the interpreter lock released -- ~2 us per
 4096-sample read against ~63 through libhdf5 plus the per-read Python hand-off; it answers RD_ERR_FORMAT without a verdict for anything it
-does not recognise (newer layouts, compressed signals, other sample types), and then -- for that file, from that read on -- the ctypes ->
+does not recognise (newer layouts, filters other than HDF5's built-in deflate / shuffle / Fletcher-32, other sample types), and then -- for that file, from that read on -- the ctypes ->
 libhdf5 reader (h5.py) does the work as before and its errors are the verdict.  RADIAN_FAST5_NATIVE=0 switches the native reader off."""
 import ctypes
 import os
@@ -235,12 +235,13 @@ class ListSource:
         pass
 
 
-def write_multi_fast5(path, reads):
-    """Write {read_id: int16 array} as a multi-read fast5 (fixtures / synthetic runs)."""
+def write_multi_fast5(path, reads, filters=(), chunk=4096):
+    """Write {read_id: int16 array} as a multi-read fast5 (fixtures / synthetic runs).  filters: h5.File.write's, e.g. (("deflate", 1),)
+    = the gzip level-1 signals of pre-VBZ MinKNOW files."""
     with h5.File(path, "w") as f:
         for rid, sig in reads.items():
             sig = np.ascontiguousarray(sig, dtype=np.int16)
             g = f"/read_{rid}"
             f.create_group(g + "/Raw")
-            f.write(g + "/Raw/Signal", sig, chunks=(max(1, min(len(sig), 4096)),))
+            f.write(g + "/Raw/Signal", sig, chunks=(max(1, min(len(sig), chunk)),), filters=filters)
             f.set_attr_str(g + "/Raw", "read_id", rid)

@@ -91,6 +91,9 @@ def lib():
         "H5Aclose": (herr_t, [hid_t]),
         "H5Pcreate": (hid_t, [hid_t]),
         "H5Pset_chunk": (herr_t, [hid_t, ctypes.c_int, ctypes.POINTER(hsize_t)]),
+        "H5Pset_deflate": (herr_t, [hid_t, ctypes.c_uint]),
+        "H5Pset_shuffle": (herr_t, [hid_t]),
+        "H5Pset_fletcher32": (herr_t, [hid_t]),
         "H5Pclose": (herr_t, [hid_t]),
         "H5Eset_auto2": (herr_t, [hid_t, ctypes.c_void_p, ctypes.c_void_p]),
     }
@@ -299,7 +302,8 @@ class File:
                 raise H5Error(f"cannot create group {cur!r}")
             L.H5Gclose(gid)
 
-    def write(self, path, array, chunks=None):
+    def write(self, path, array, chunks=None, filters=()):
+        """filters (chunked datasets only), applied in the order given: "shuffle", "fletcher32", ("deflate", level)"""
         L = lib()
         a = np.ascontiguousarray(array)
         parent = path.rsplit("/", 1)[0]
@@ -312,6 +316,11 @@ class File:
             dcpl = L.H5Pcreate(_types["dcpl"])
             cd = (hsize_t * a.ndim)(*chunks)
             L.H5Pset_chunk(dcpl, a.ndim, cd)
+            for f in filters:
+                rc = (L.H5Pset_shuffle(dcpl) if f == "shuffle" else L.H5Pset_fletcher32(dcpl) if f == "fletcher32"
+                      else L.H5Pset_deflate(dcpl, int(f[1])) if f[0] == "deflate" else -1)
+                if rc < 0:
+                    raise H5Error(f"cannot add filter {f!r} (this libhdf5 may lack it)")
         did = L.H5Dcreate2(self.id, _b(path), _types[a.dtype], sid, H5P_DEFAULT, dcpl, H5P_DEFAULT)
         if did < 0:
             raise H5Error(f"cannot create dataset {path!r}")
