@@ -145,7 +145,7 @@ def total_note(lengths, dt):
     return f"{int(np.sum(lengths)) / dt / 1e6:.2f} M samples/s ({dt:.2f} s)"
 
 
-def driver_leg(device, pool, cli, lengths, seed, weights_flat, lm=None, warm_reads=1536, desc=""):
+def driver_leg(device, pool, cli, lengths, seed, weights_flat, lm=None, warm_reads=1536, desc="", files=None):
     """A job through the product's driver loop (radian_amd.basecall.run = basecall.py:69-141) with the CLI flags `cli`:
     host int16 reads -> H2D -> MAD normalisation on the device -> streamed forward -> (assembly) -> beam search -> labels to
     the host -> strings (chunk mode: simple_assembly natively on host threads), results in input order; everything but fast5
@@ -176,13 +176,60 @@ def driver_leg(device, pool, cli, lengths, seed, weights_flat, lm=None, warm_rea
                 dt = time.perf_counter() - t0
             assert len(res) == len(lens) and all(len(r[2]) > 0 for r in res)
             return dt, float(np.mean([len(r[2]) for r in res]))
+        def go_files(lens, filters):
+            """the whole job as the command line runs it: a directory of multi-read fast5 files (4000 reads each, as MinKNOW writes them)
+            -> reads-<n>.fasta files on disk.  The files are written before the clock starts (memory-backed directory where there is one)."""
+            import shutil
+            import tempfile
+            from radian_amd import fast5
+            root = tempfile.mkdtemp(prefix="radian_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None)
+            try:
+                os.mkdir(root + "/in")
+                os.mkdir(root + "/out")
+                for lo in range(0, len(lens), 4000):
+                    fast5.write_multi_fast5(f"{root}/in/batch_{lo // 4000}.fast5",
+                                            {f"{i:08d}-0000-4000-8000-{i:012d}": np.rint(rng.normal(500.0, 80.0, size=int(lens[i]))).astype(np.int16)
+                                             for i in range(lo, min(lo + 4000, len(lens)))}, filters=filters)
+                size = sum(os.path.getsize(f"{root}/in/{f}") for f in os.listdir(root + "/in"))
+                args.fast5_dir, args.fasta_dir = root + "/in", root + "/out"
+                with open(os.devnull, "w") as dn, contextlib.redirect_stdout(dn):
+                    t0 = time.perf_counter()
+                    writer = basecall.FastaWriter(args.fasta_dir)
+                    try:
+                        basecall.run(args, bes, writer=writer, stitch_pool=pool if args.decode_type == "chunk" else None)
+                    finally:
+                        writer.close()
+                    dt = time.perf_counter() - t0
+                n_rec = n_base = 0
+                for f in os.listdir(root + "/out"):
+                    for line in open(f"{root}/out/{f}"):
+                        if line.startswith(">"):
+                            n_rec += 1
+                        else:
+                            n_base += len(line) - 1
+                assert n_rec == len(lens), (n_rec, len(lens))
+                return dt, n_base / max(1, n_rec), size
+            finally:
+                shutil.rmtree(root, ignore_errors=True)
+
         go(lengths[:warm_reads])                  # warm-up with full-size device batches on every forward lane: allocations happen here
-        dt, mean_bases = go(lengths)
+        file_bytes = None
+        if files is None:
+            dt, mean_bases = go(lengths)
+        else:
+            dt, mean_bases, file_bytes = go_files(lengths, files)
         note(f"  {total_note(lengths, dt)}")
     finally:
         for b in bes:
             b.close()
     total = int(np.sum(lengths))
+    if files is not None:
+        return {"value": total / dt, "unit": "samples/s", "reads": int(len(lengths)), "samples": total, "seconds": dt,
+                "mean_bases_per_read": mean_bases, "cli": " ".join(cli), "fast5_bytes": file_bytes,
+                "signal_storage": "raw int16 chunks" if not files else "chunks through " + " + ".join(f if isinstance(f, str) else f"{f[0]}({f[1]})" for f in files),
+                "path": desc + "; multi-read fast5 files (4000 reads each) -> native reader (csrc/fast5.hip) -> H2D -> on-device mad_normalise -> streamed "
+                               "forward -> beam search -> labels D2H -> strings -> reads-<n>.fasta on disk, through radian_amd.basecall.run as "
+                               "basecall.main drives it: NOTHING excluded but start-up (weights, contexts)"}
     return {"value": total / dt, "unit": "samples/s", "reads": int(len(lengths)), "samples": total, "seconds": dt,
             "mean_bases_per_read": mean_bases, "cli": " ".join(cli),
             "device_contexts": len(bes), "pipelined": not args.no_pipeline,
@@ -681,6 +728,14 @@ def main():
                 note(key)
                 try:
                     sec[key] = driver_leg(device, stitch_pool, cli, lens, 70002, wf, lm=lm, desc=desc)
+                except Exception as e:
+                    print(f"[bench] {key} failed: {e}", file=sys.stderr)
+            # the same job from files to files
+            for key, filters in (("secondary_e2e_fast5_to_fasta", ()), ("secondary_e2e_gzip_fast5_to_fasta", (("deflate", 1),))):
+                note(key)
+                try:
+                    sec[key] = driver_leg(device, stitch_pool, chunk_cli, np.full(args.e2e_reads // 2, READ_LEN, dtype=np.int64), 70003, w0, desc=(
+                        "BASELINE configs[2] from a fast5 directory to FASTA files"), files=filters)
                 except Exception as e:
                     print(f"[bench] {key} failed: {e}", file=sys.stderr)
         del table
