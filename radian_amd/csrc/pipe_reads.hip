@@ -927,13 +927,13 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
         const bool few = part && ((int)s->seqs.size() <= limit || s->oversub);
         const int m = few ? std::min(3, part_waves_per_simd(part, W, (int64_t)s->seqs.size())) : 0;
         int64_t need = chain_rows(ctx, p->calib, W, m, use_lm) * s->longest;
-        // An oversubscribed partition (decided when the crossing batch arrived, above) finishes no sooner than its total work allows: every resident slot steps at the saturated
-        // pace, so the group's forward rows must also cover  steps_total x pace(3) / slots  (chain_rows(3) = that pace in forward rows + 20 %)
-        // (without the chain rule's 20 %: that margin is for the one chain that decides a covered group's end; the work term is a rate
-        // against a rate, and with the margin a partition at 0.9 of the forward's pace could never "cover" itself: the group grew to its
-        // buffer's cap -- 27 batches, half-second searches, 20 M samples/s on 64 x 4096-sample batches at W = 25.  A partition slower than
-        // the forward covers nothing however long the group: there the group ends with its chain covered and three rounds of resident
-        // sequences gathered.)
+        // An oversubscribed partition (decided when the crossing batch arrived, above) finishes no sooner than its total work allows: every
+        // resident slot steps at the saturated pace, so the group's forward rows must also cover  steps_total x pace(3) / slots  -- a rate
+        // against a rate, hence WITHOUT the 20 % that chain_rows adds for the one chain that decides a covered group's end (x 5/6): with
+        // the margin a partition at 0.9 of the forward's pace could never "cover" itself and the group grew to its buffer's cap -- 27
+        // batches, half-second searches, 20 M samples/s on 64 x 4096-sample batches at W = 25.  A partition slower than the forward (the
+        // pre-check tolerates 1.25x) covers nothing however long the group: there the group ends with its chain covered and three rounds
+        // of resident sequences gathered.
         const int resident = part ? queue_resident_seqs(part, W) : 1;
         const int64_t need_chain = need;
         if (s->oversub) need = std::max(need, chain_rows(ctx, p->calib, W, 3, use_lm) * 5 / 6 * s->steps_total / resident);
