@@ -11,7 +11,7 @@ usage: host_feed_bench.py read [n_reads=16384] [len=4096]
        host_feed_bench.py ranks [world=8] [n_reads=100000] [len=4096] [files=8] [mode=global|chunk]
        host_feed_bench.py merger [world=8] [n_records=200000] [seq_len=2048]
 Every worker of `ranks` takes its host budget exactly as launch.worker does (launch.rank_budget: core slice + thread counts) and reports
-the threads it had alive at its busiest."""
+the threads it had alive at its busiest.  FEED_GZIP=1: the files' signals are deflate-compressed (pre-VBZ MinKNOW files)."""
 import json, os, shutil, sys, tempfile, time
 import numpy as np
 R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -63,7 +63,8 @@ def write_files(d, n_reads, length, n_files):
         if k <= 0:
             break
         fast5.write_multi_fast5(os.path.join(d, f"f{fi:03d}.fast5"),
-                                {f"{fi:03d}-{i:07d}": base[(i % 63) * length: (i % 63) * length + length] for i in range(k)})
+                                {f"{fi:03d}-{i:07d}": base[(i % 63) * length: (i % 63) * length + length] for i in range(k)},
+                                filters=(("deflate", 1),) if os.environ.get("FEED_GZIP") == "1" else ())
         done += k
     return done
 
