@@ -753,8 +753,8 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
     // ---- the group this batch joins (may close / deliver earlier groups)
     RSlot* s = nullptr;
     int64_t expect_rows = 0;
+    int64_t longest_b = 0;
     if (mode == 1) {
-        int64_t longest_b = 0;
         for (int r = 0; r < n_reads; r++) longest_b = std::max<int64_t>(longest_b, read_off[r + 1] - read_off[r]);
         calib_harvest(p->calib);
         expect_rows = std::min<int64_t>(kGroupRowsCap, chain_rows(ctx, p->calib, W, part ? 2 : 0, use_lm) * longest_b + 2 * P.total_rows);
@@ -780,8 +780,14 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
             const double pace3 = us3 ? *us3 : (double)chain_rows_default(W, true) * kDefaultNsPerRow * 1e-3;
             const double work_ms = (double)(g.steps_total + (int64_t)n_samples) * pace3 * 1e-3 / (double)queue_resident_seqs(part, W);
             const double fwd_ms = (double)(g.rows + P.total_rows) * ns * 1e-6;
-            // (a quarter over is tolerated: a partition 25 % behind the forward costs that much at worst; closing here costs the uncovered chain)
-            if (work_ms <= 1.25 * fwd_ms && W <= 51 /* (the work-queue kernel's shapes) */ && !(use_lm && ctx->lm.hashed)) g.oversub = true;
+            // (a quarter over is tolerated: a partition 25 % behind the forward costs that much at worst; closing here costs the uncovered chain.
+            // Beyond that the group closes here only if its longest chain is covered by now: a partition that cannot keep up is the
+            // bottleneck whatever the groups' size, but a group closed with a 150-ms chain over 20 ms of forward stalls the lanes for the
+            // difference -- bf16x3 at W = 25, where the partition runs at 0.9-1.5 of the forward's pace depending on what the pace
+            // measurements last saw, alternated between 36 and 24 M samples/s on this rule alone: 11 of 37 groups closed here uncovered.)
+            const int64_t chain_need = chain_rows(ctx, p->calib, W, 3, use_lm) * std::max<int64_t>(g.longest, longest_b);
+            const bool uncovered = g.rows + P.total_rows < chain_need;
+            if ((work_ms <= 1.25 * fwd_ms || uncovered) && W <= 51 /* (the work-queue kernel's shapes) */ && !(use_lm && ctx->lm.hashed)) g.oversub = true;
             else {
                 p->limit_closes++;
                 if ((rc = close_group(ctx, p))) return rc;
