@@ -388,3 +388,25 @@ def test_cli_beam_width_above_the_lane_kernels(tmp_path, golden_dir, oracle, W):
         basecall.main([in_dir, str(out), "--decode-type", mode, "--beam-width", str(W), "--step-size", "512", "--sig-model", "synthetic:1234",
                        "--sig-config", "none"] + extra)
         assert _read_fasta(str(out)) == exp, mode
+
+
+def test_cli_reads_filtered_fast5_like_raw(tmp_path, golden_dir):
+    """The same five signals stored raw and through HDF5's shuffle + deflate + Fletcher-32 filters (csrc/fast5.hip undoes them natively;
+    pre-VBZ MinKNOW files are gzip-compressed): identical FASTA from the CLI."""
+    from radian_amd import basecall, fast5
+    ids, sig, in_dir, _ = _make_inputs(tmp_path, golden_dir)
+    gz_dir = tmp_path / "fast5_gz"
+    gz_dir.mkdir()
+    fast5.write_multi_fast5(str(gz_dir / "reads.fast5"), {r: sig[r] for r in ids}, filters=("shuffle", ("deflate", 1), "fletcher32"), chunk=1500)
+    nf = fast5.NativeFile(str(gz_dir / "reads.fast5"))          # (no fall-back behind this call)
+    names, samples, off = nf.batch(0, nf.n)
+    nf.close()
+    assert names == sorted(ids) and all(np.array_equal(samples[off[i]:off[i + 1]], sig[r]) for i, r in enumerate(names))
+    outs = []
+    for d in (in_dir, str(gz_dir)):
+        out = tmp_path / ("out_" + os.path.basename(d))
+        out.mkdir()
+        basecall.main([d, str(out), "--decode-type", "chunk", "--beam-width", "3", "--step-size", "512", "--sig-model", "synthetic:7",
+                       "--sig-config", "none", "--rna-model", "None"])
+        outs.append(_read_fasta(str(out)))
+    assert outs[0] == outs[1] and len(outs[0]) == len(ids)
