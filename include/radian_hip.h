@@ -344,7 +344,7 @@ int rd_lm_json_fill(const char* buf, size_t n, int k, double* table, int64_t* n_
  *   rd_fast5_read_batch  reads [lo, hi) copied back to back into samples (capacity cap), offsets[hi - lo + 1] = where each starts (the
  *                        last entry = the total); ids (nullable): the read ids, NUL-terminated, id_stride bytes apart.
  * Anything else in the file (newer superblock / object headers, fractal-heap groups, any other filter such as VBZ, a chunk that fails to
- * inflate or fails its checksum, another sample type, variable-length string ids, an address outside the file) returns RD_ERR_FORMAT and decides nothing: the caller reads the file
+ * inflate or fails its checksum, another sample type, an address outside the file) returns RD_ERR_FORMAT and decides nothing: the caller reads the file
  * through libhdf5, whose errors are then the verdict.  ~2 us per 4096-sample read on one core (libhdf5: ~63; deflated signals 60 M samples/s against 18 M); no GPU is touched, no
  * context is needed, a handle is used by one thread at a time. */
 typedef struct rd_fast5 rd_fast5;

@@ -12,7 +12,7 @@
 // with the interpreter lock released.
 //
 // ANYTHING else -- superblock >= 2, version-2 object headers, dense (fractal-heap) groups, any other filter (VBZ = 32020, szip, n-bit,
-// scale-offset), a chunk that does not inflate to exactly one chunk or fails its checksum, a signal that is not little-endian int16, variable-length string ids, or any offset that points outside the file -- returns RD_ERR_FORMAT and decides
+// scale-offset), a chunk that does not inflate to exactly one chunk or fails its checksum, a signal that is not little-endian int16, or any offset that points outside the file -- returns RD_ERR_FORMAT and decides
 // NOTHING: the caller (radian_amd/fast5.py) reads that file through libhdf5 as before, whose errors are then the verdict.
 //
 // Read order = ont_fast5_api's = HDF5's name order: multi-read files iterate the root's `read_<id>` groups by name (id = the name without the
@@ -457,7 +457,7 @@ void copy_signal(const Image& im, const Signal& s, int16_t* out, Scratch& sc)
     }
 }
 
-// a fixed-length string attribute of an object (version 1-3 attribute messages); false: the object has no such attribute
+// a string attribute of an object -- fixed-length, or variable-length out of the global heap (version 1-3 attribute messages); false: the object has no such attribute
 bool string_attr(const Image& im, uint64_t at, const char* name, std::string& out)
 {
     std::vector<Msg> ms;
@@ -483,7 +483,33 @@ bool string_attr(const Image& im, uint64_t at, const char* name, std::string& ou
         p += pad(ssz);
         if (!mine) continue;
         const uint8_t cls = im.u8(tp) & 0x0f;
-        if (cls != 3) throw NoVerdict{"read_id attribute is not a fixed-length string"};
+        if (cls == 9) {      // variable-length string (what h5py writes for a Python str: ont_fast5_api's multi_to_single output): the value is in the global heap
+            if ((im.u8(tp + 1) & 0x0f) != 1) throw NoVerdict{"read_id attribute is a variable-length sequence, not a string"};
+            if (p > m.data + m.size || 16 > m.data + m.size - p) throw NoVerdict{"attribute value runs past its message"};
+            const uint32_t len = im.u32(p), idx = im.u32(p + 12);
+            const uint64_t col = im.addr(p + 4);
+            if (col == kUndef || len == 0) {      // (a null / empty string)
+                out.clear();
+                return true;
+            }
+            if (!im.tag(col, "GCOL") || im.u8(col + 4) != 1) throw NoVerdict{"bad global heap collection"};
+            const uint64_t csize = im.u64(col + 8);
+            im.need(col, csize);
+            for (uint64_t q = col + 16; q + 16 <= col + csize;) {
+                const unsigned oi = im.u16(q);
+                const uint64_t osz = im.u64(q + 8);
+                if (oi == 0) break;               // (the collection's free space)
+                if (osz > col + csize - (q + 16)) throw NoVerdict{"global heap object runs past its collection"};
+                if (oi == idx) {
+                    if (len > osz) throw NoVerdict{"variable-length string longer than its heap object"};
+                    out.assign((const char*)im.p + q + 16, strnlen((const char*)im.p + q + 16, len));
+                    return true;
+                }
+                q += 16 + ((osz + 7) & ~(uint64_t)7);
+            }
+            throw NoVerdict{"variable-length string not found in its heap collection"};
+        }
+        if (cls != 3) throw NoVerdict{"read_id attribute is not a string"};
         const uint32_t size = im.u32(tp + 4);
         if (p > m.data + m.size || size > m.data + m.size - p) throw NoVerdict{"attribute value runs past its message"};
         im.need(p, size);

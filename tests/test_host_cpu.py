@@ -778,15 +778,15 @@ def test_apply_binds_a_child_rank_to_its_slice():
     assert not d["bound"] and d["after"] == d["before"]
 
 
-def _write_single_read_fast5(path, read_id, sig, group="Read_17"):
+def _write_single_read_fast5(path, read_id, sig, group="Read_17", id_kind="nullterm", filters=()):
     from radian_amd import h5
     with h5.File(path, "w") as f:
         f.create_group("/Raw")
         f.create_group("/Raw/Reads")
         f.create_group(f"/Raw/Reads/{group}")
-        f.write(f"/Raw/Reads/{group}/Signal", np.ascontiguousarray(sig, dtype=np.int16), chunks=(max(1, min(len(sig), 1000)),))
+        f.write(f"/Raw/Reads/{group}/Signal", np.ascontiguousarray(sig, dtype=np.int16), chunks=(max(1, min(len(sig), 1000)),), filters=filters)
         if read_id is not None:
-            f.set_attr_str(f"/Raw/Reads/{group}", "read_id", read_id)
+            f.set_attr_str(f"/Raw/Reads/{group}", "read_id", read_id, kind=id_kind)
 
 
 @pytest.mark.skipif(not _have_hdf5(), reason="libhdf5 not available")
@@ -854,6 +854,38 @@ def test_native_fast5_reader_matches_libhdf5(tmp_path, golden_dir, monkeypatch):
     assert fast5._open_native(p6) is None
     with pytest.raises(h5.H5Error):
         list(fast5.iter_reads(p6))
+
+
+@pytest.mark.skipif(not _have_hdf5(), reason="libhdf5 not available")
+def test_native_fast5_reader_single_read_files_as_h5py_writes_them(tmp_path):
+    """Single-read files as ont_fast5_api's multi_to_single_fast5 leaves them: h5py stores a Python str attribute as a VARIABLE-LENGTH string
+    (its bytes live in the file's global heap), and the signal gzip-compressed.  csrc/fast5.hip alone: the id and the samples libhdf5 reads."""
+    from radian_amd import fast5
+    rng = np.random.default_rng(12)
+    for i, (rid, kind, filters) in enumerate([("0a1b2c3d-0000-1111-2222-333344445555", "vlen", (("deflate", 1),)),
+                                              ("f" * 36, "vlen", ()), ("7e57-id", "nullpad", ("shuffle", ("deflate", 3))), ("", "vlen", ())]):
+        sig = np.round(rng.normal(500, 80, size=int(rng.integers(1, 5000)))).astype(np.int16)
+        p = str(tmp_path / f"s{i}.fast5")
+        _write_single_read_fast5(p, rid, sig, group=f"Read_{40 + i}", id_kind=kind, filters=filters)
+        nf = fast5.NativeFile(p)
+        names, samples, off = nf.batch(0, nf.n)
+        nf.close()
+        ref = _iter_libhdf5(p)
+        assert names == [ref[0][0]] and np.array_equal(samples, ref[0][1]) and np.array_equal(samples, sig), (i, names, ref[0][0])
+        assert names == [rid], (i, names)
+
+
+def _iter_libhdf5(path):
+    from radian_amd import fast5
+    old = os.environ.get("RADIAN_FAST5_NATIVE")
+    os.environ["RADIAN_FAST5_NATIVE"] = "0"
+    try:
+        return [(r.read_id, np.asarray(r.get_raw_data())) for r in fast5.iter_reads(path)]      # (read while the file is open)
+    finally:
+        if old is None:
+            del os.environ["RADIAN_FAST5_NATIVE"]
+        else:
+            os.environ["RADIAN_FAST5_NATIVE"] = old
 
 
 @pytest.mark.skipif(not _have_hdf5(), reason="libhdf5 not available")
@@ -934,6 +966,8 @@ def test_native_fast5_reader_under_address_sanitizer(tmp_path, golden_dir):
     fast5.write_multi_fast5(p1, reads)
     p2 = str(tmp_path / "single.fast5")
     _write_single_read_fast5(p2, "0a1b2c3d-0000-1111-2222-333344445555", np.arange(2300) % 700)
+    p4 = str(tmp_path / "single_vlen.fast5")    # (id in the global heap)
+    _write_single_read_fast5(p4, "0a1b2c3d-9999-1111-2222-333344445555", np.arange(1200) % 650, id_kind="vlen", filters=(("deflate", 1),))
     p3 = str(tmp_path / "filtered.fast5")     # every chunk through shuffle + deflate + Fletcher-32: the mutations land in compressed streams and checksums too
     fast5.write_multi_fast5(p3, dict(list(reads.items())[:12]), filters=("shuffle", ("deflate", 1), "fletcher32"), chunk=700)
     exe = tmp_path / "asan_fast5"
@@ -943,9 +977,10 @@ def test_native_fast5_reader_under_address_sanitizer(tmp_path, golden_dir):
     if r.returncode != 0 and b"sanitize" in r.stderr and b"cannot find" in r.stderr:
         pytest.skip("the sanitizer runtimes are not installed")
     assert r.returncode == 0, r.stderr.decode()[-3000:]
-    r = subprocess.run([str(exe), "3000", p1, p2, p3], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    r = subprocess.run([str(exe), "2500", p1, p2, p3, p4], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0 and b"no sanitizer report" in r.stdout, (r.stdout.decode()[-800:], r.stderr.decode()[-3000:])
     lines = r.stdout.decode().splitlines()
     assert lines[0].split(": ")[1].startswith("40 reads") and lines[1].split(": ")[1].startswith("1 reads") and lines[2].split(": ")[1].startswith("12 reads")
+    assert lines[3].split(": ")[1].startswith("1 reads")
     opened, refused = int(lines[-1].split()[0]), int(lines[-1].split()[2])
     assert opened > 2000 and refused > 300          # the mutations reach both outcomes
