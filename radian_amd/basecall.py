@@ -313,8 +313,8 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
     `sources` (fast5.Fast5Source per file: the multi-GPU launcher's form).
     shard=(rank, world): this process handles reads whose index % world == rank -- or, with a queue shared by the ranks
     of the node (dist.WorkQueue over read indices / dist.FileReadQueue over files then reads), the blocks it claims --
-    and returns [(key, read_id, sequence)] instead of writing when writer is None; on_result(key, read_id, sequence), if
-    given, receives each result as it is finished (in order) instead of the list growing.
+    and returns [(key, read_id, sequence)] when neither a writer nor on_result takes the records (an empty list otherwise: a
+    consumed record is not kept); on_result(key, read_id, sequence), if given, receives each result as it is finished (in order).
     `be` is one Backend or a list of Backends on the same GPU (independent rd_ctx / HIP streams): batches go to them
     round robin on one thread each, so the MFMA-bound forward of one batch overlaps the latency-bound beam search of
     the previous one.  Reading/batching (HDF5 through ctypes), the device calls and the host work on the results
@@ -330,6 +330,9 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
         raise ValueError("Step size must be <= window size")
     use_lm = getattr(args, "_lm_loaded", False) and args.decode_type == "global"
     rank, world = shard
+    # a record that a writer or on_result has consumed is written and forgotten, as the reference does (basecall.py:129): the list
+    # only grows when it is the one way out (a whole run's sequences are O(total bases): ~1 GB per million 1-kb reads)
+    collect_results = writer is None and on_result is None
     results = []
     batch, batch_idx, n_win = [], [], 0
     dev_pools = [ThreadPoolExecutor(max_workers=1) for _ in backends]   # an rd_ctx is not thread-safe: one thread each
@@ -377,7 +380,7 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
                 writer.write(rid, seq)
             if on_result is not None:
                 on_result(idx, rid, seq)
-            else:
+            if collect_results:
                 results.append((idx, rid, seq))
             print(f"Basecalled read {rid} in {dur:.2f} sec.")
 

@@ -984,3 +984,67 @@ def test_native_fast5_reader_under_address_sanitizer(tmp_path, golden_dir):
     assert lines[3].split(": ")[1].startswith("1 reads")
     opened, refused = int(lines[-1].split()[0]), int(lines[-1].split()[2])
     assert opened > 2000 and refused > 300          # the mutations reach both outcomes
+
+
+def test_driver_loop_forgets_consumed_records(tmp_path):
+    """basecall.run with a writer (the single-process command line's route, basecall.main): the reference writes a record and forgets it
+    (basecall.py:129); a run over 200 000 tiny reads returns an empty list and the process's resident memory stays flat over the last
+    150 000 reads (kept records would add > 60 MB: tuple + 400-char sequence + read id each).  The list is still what comes back when
+    neither a writer nor on_result takes the records."""
+    import contextlib
+    import gc
+    import os
+    from radian_amd import basecall
+
+    page = os.sysconf("SC_PAGE_SIZE")
+
+    def rss():
+        with open("/proc/self/statm") as f:
+            return int(f.read().split()[1]) * page
+
+    class Stub:
+        """Backend stand-in with the blocking per-batch entry point only (--no-pipeline): 400 labels per read, no arithmetic"""
+        lab = (np.arange(400) % 4).astype(np.uint8)
+
+        def basecall_raw_global(self, raws, *a):
+            return [self.lab] * len(raws), [0] * len(raws)
+
+    class R:
+        sig = np.zeros(8, dtype=np.int16)
+
+        def __init__(self, i):
+            self.read_id = f"{i:08d}-0000-4000-8000-{i:012d}"
+
+        def get_raw_data(self):
+            return self.sig
+
+    class Writer(basecall.FastaWriter):
+        marks = {}
+
+        def write(self, rid, seq):
+            super().write(rid, seq)
+            n = self.n * 1000 + self.i
+            if n in (50000, 200000):
+                gc.collect()
+                self.marks[n] = rss()
+
+    args = basecall.build_parser().parse_args(["-", str(tmp_path), "--no-pipeline", "--gpu-batch-windows", "512"])
+    args._lm_loaded = False
+    w = Writer(str(tmp_path))
+    with open(os.devnull, "w") as dn, contextlib.redirect_stdout(dn):
+        try:
+            res = basecall.run(args, Stub(), reads=(R(i) for i in range(200000)), writer=w)
+        finally:
+            w.close()
+    assert res == []
+    assert set(w.marks) == {50000, 200000}
+    grown = (w.marks[200000] - w.marks[50000]) / 1e6
+    assert grown < 25.0, f"resident memory grew by {grown:.0f} MB over 150 000 written reads"
+    n_rec = sum(1 for f in os.listdir(tmp_path) for line in open(tmp_path / f) if line.startswith(">"))
+    assert n_rec == 200000 and len(os.listdir(tmp_path)) == 201      # 200 full files + the empty trailing one (basecall.py:133-138)
+    # on_result alone: consumed as well; neither: the list is the way out
+    seen = []
+    with open(os.devnull, "w") as dn, contextlib.redirect_stdout(dn):
+        assert basecall.run(args, Stub(), reads=(R(i) for i in range(10)), writer=None, on_result=lambda *r: seen.append(r)) == []
+        kept = basecall.run(args, Stub(), reads=(R(i) for i in range(10)), writer=None)
+    assert len(seen) == 10 and [tuple(k) for k in kept] == seen
