@@ -220,6 +220,32 @@ def test_cli_default_artifact_route(tmp_path, golden_dir, oracle, monkeypatch):
     assert _read_fasta(str(out_c)) == exp
 
 
+def test_cli_literal_entry_point_from_a_models_directory(tmp_path, golden_dir, oracle):
+    """The command a RADIAN user types (README.md:56-59, basecall.py:28-30,143-144): `python3 <repo>/basecall.py fast5_dir fasta_dir`
+    from a working directory that holds models/ -- a fresh interpreter, no flags for the artefacts, the package found beside the script
+    (not through the cwd).  FASTA == the oracle's decode of the GPU's probabilities; stdout carries the reference's per-read lines."""
+    import subprocess
+    from radian_amd import Backend, weights, lm
+    ids, sig, in_dir, _ = _make_inputs(tmp_path, golden_dir)
+    cwd = tmp_path / "cwd"
+    cwd.mkdir()
+    _write_default_artifacts(cwd, 1234, 3)
+    out = tmp_path / "out"
+    out.mkdir()
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "basecall.py"), in_dir, str(out), "--context-len", "3"], cwd=str(cwd), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("Basecalled read ")]
+    assert [ln.split()[2] for ln in lines] == list(ids) and all(ln.endswith(" sec.") for ln in lines)
+    table, k = lm.load_json(str(cwd / "models" / "rnamodel_12mer_pc.json"))
+    be = Backend(0)
+    be.load_weights(weights.synthetic_weights(seed=1234))
+    exp = _expected(be, oracle, ids, sig, 1024, 128, 6, "global", table, k)
+    be.close()
+    assert _read_fasta(str(out)) == exp
+
+
 def test_cli_default_artifact_route_two_stacks_and_rejections(tmp_path, golden_dir, oracle, monkeypatch):
     """sig2seq.yaml drives the graph: nb_stacks 2 x dilations [1, 2, 4] (six blocks with dilations 1,2,4,1,2,4) loads a
     matching .h5 and basecalls like the oracle; a config the backend does not implement (batch norm, another filter count) and an

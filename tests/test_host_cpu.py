@@ -1048,3 +1048,101 @@ def test_driver_loop_forgets_consumed_records(tmp_path):
         assert basecall.run(args, Stub(), reads=(R(i) for i in range(10)), writer=None, on_result=lambda *r: seen.append(r)) == []
         kept = basecall.run(args, Stub(), reads=(R(i) for i in range(10)), writer=None)
     assert len(seen) == 10 and [tuple(k) for k in kept] == seen
+
+
+def test_literal_entry_point_exists_and_parses_the_reference_command_line(tmp_path):
+    """`python basecall.py --help` at the repository root (the reference's own entry, basecall.py:143-144) from a foreign working directory:
+    the 13 reference flags with their defaults are there and nothing touches a GPU for it."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "basecall.py"), "--help"], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    for flag in ("--local", "--chunk-len", "--step-size", "--batch-size", "--outlier-clip", "--rna-model", "--sig-model", "--sig-config",
+                 "--beam-width", "--decode-type", "--sig-threshold", "--rna-threshold", "--context-len"):
+        assert flag in p.stdout
+    assert "fast5_dir" in p.stdout and "fasta_dir" in p.stdout
+
+
+def test_keras_h5_names_are_checked_not_only_shapes(tmp_path, capsys):
+    """Round 6: conv1D_0 and conv1D_1 of blocks 1..5 all have shape [3,256,256]; a file whose order differs from
+    load_weights order (model.py:44) must not load silently wrong.  Two same-shaped datasets swapped in the name list -> ValueError naming
+    both; the same file converts by name (order='by_name', tools/verify_h5.py --by-name) to exactly the original parameters; a file whose
+    names follow no known scheme loads positionally with a warning; session-numbered layer names (tcn_1, dense_2/dense_3) load."""
+    import importlib.util
+    from radian_amd import h5, h5weights, weights
+    dil = (1, 2, 4)
+    w = weights.synthetic_weights(seed=3, dilations=dil)
+    shapes = weights.tensor_shapes(dil)
+
+    def write(path, order, rename=lambda n: n):
+        off, arrs = 0, []
+        for name, shape in shapes:
+            n = int(np.prod(shape))
+            arrs.append((name, w[off:off + n].reshape(shape)))
+            off += n
+        arrs = [arrs[i] for i in order]
+        by_layer = {}
+        for name, a in arrs:
+            by_layer.setdefault(name.split("/")[0], []).append((rename(name) + ":0", a))
+        with h5.File(path, "w") as f:
+            for layer in ("tcn", "dense", "dense_1"):
+                f.create_group("/" + layer)
+                for wn, a in by_layer[layer]:
+                    f.write(f"/{layer}/{wn}", a)
+                f.set_attr_str("/" + layer, "weight_names", [wn for wn, _ in by_layer[layer]], kind="nullpad")
+            f.set_attr_str("/", "layer_names", ["tcn", "dense", "dense_1"], kind="nullpad")
+
+    n = len(shapes)
+    good = str(tmp_path / "good.h5")
+    write(good, list(range(n)))
+    assert np.array_equal(h5weights.read_keras_weights(good, dil), w)
+    # block 1's conv1D_0 kernel <-> conv1D_1 kernel: same shape, different place
+    names = [s[0] for s in shapes]
+    i, j = names.index("tcn/residual_block_1/conv1D_0/kernel"), names.index("tcn/residual_block_1/conv1D_1/kernel")
+    order = list(range(n))
+    order[i], order[j] = order[j], order[i]
+    swapped = str(tmp_path / "swapped.h5")
+    write(swapped, order)
+    with pytest.raises(ValueError, match="residual_block_1/conv1D_1/kernel.*position.*residual_block_1/conv1D_0/kernel"):
+        h5weights.read_keras_weights(swapped, dil)
+    assert np.array_equal(h5weights.read_keras_weights(swapped, dil, order="by_name"), w)
+    # blocks 1 and 2 swapped wholesale (every shape still fits)
+    b1 = [k for k, nm in enumerate(names) if "residual_block_1/" in nm]
+    b2 = [k for k, nm in enumerate(names) if "residual_block_2/" in nm]
+    order = list(range(n))
+    for a, b in zip(b1, b2):
+        order[a], order[b] = b, a
+    write(str(tmp_path / "blocks.h5"), order)
+    with pytest.raises(ValueError, match="order differs"):
+        h5weights.read_keras_weights(str(tmp_path / "blocks.h5"), dil)
+    # unknown naming scheme: positional, with a warning that the order is unverifiable
+    write(str(tmp_path / "renamed.h5"), list(range(n)), rename=lambda nm: nm.replace("residual_block_", "rb").replace("conv1D_", "c"))
+    with pytest.warns(UserWarning, match="taken on trust"):
+        assert np.array_equal(h5weights.read_keras_weights(str(tmp_path / "renamed.h5"), dil), w)
+    with pytest.raises(ValueError, match="cannot be placed by name"):
+        h5weights.read_keras_weights(str(tmp_path / "renamed.h5"), dil, order="by_name")
+    # session-numbered names (a second model built in the same Keras session): tcn_1/..., dense_2, dense_3
+    write(str(tmp_path / "numbered.h5"), list(range(n)),
+          rename=lambda nm: nm.replace("tcn/", "tcn_1/").replace("dense_1/", "dense_3/").replace("dense/", "dense_2/"))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert np.array_equal(h5weights.read_keras_weights(str(tmp_path / "numbered.h5"), dil), w)
+    # the tool: table + exit code; --by-name writes a blob --sig-model accepts
+    spec = importlib.util.spec_from_file_location("verify_h5", os.path.join(ROOT, "tools", "verify_h5.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    cfg = tmp_path / "cfg.yaml"
+    import yaml
+    cfg.write_text(yaml.safe_dump({"model": {"relu_units": 128, "softmax_units": 5, "tcn": {
+        "nb_filters": 256, "kernel_size": 3, "nb_stacks": 1, "dilations": list(dil), "padding": "causal", "use_skip_connections": False,
+        "dropout_rate": 0.0, "activation": "relu", "use_batch_norm": False}}}))
+    assert tool.main([good, "--sig-config", str(cfg)]) == 0
+    assert "OK: loads as it is" in capsys.readouterr().out
+    assert tool.main([swapped, "--sig-config", str(cfg)]) == 1
+    text = capsys.readouterr().out
+    assert "PROBLEM:" in text and "name says 1/conv1D_1/kernel" in text
+    blob = str(tmp_path / "fixed.rdnw")
+    assert tool.main([swapped, "--sig-config", str(cfg), "--by-name", blob]) == 0
+    flat, d2 = weights.unpack_blob(open(blob, "rb").read())
+    assert tuple(d2) == dil and np.array_equal(flat, w)
