@@ -5,6 +5,8 @@
  * The reference (comprna/radian) has no FFI; the seam is five in-process Python calls made by
  * radian/basecall.py.  Each entry point below names the reference call it replaces (file:line under
  * the reference tree).  INTEGRATION.md shows the ctypes binding a maintainer adds to basecall.py.
+ * This header lists what a RADIAN maintainer binds and nothing else: the measurement switches, kernel timers and pipeline
+ * read-outs that bench.py, tools/ and tests/ use live in radian_hip_diag.h (same library; none of them changes a result).
  *
  * Conventions
  *   - every function returns 0 on success or a negative RD_ERR_* code; rd_last_error() then returns
@@ -61,18 +63,6 @@ int rd_sync(rd_ctx* ctx);             /* wait for the context's stream */
  *     fp32's exponent range), the six cross products down to 2^-16 relative accumulated in fp32 on the bf16 matrix pipe;
  *     the dropped terms are below one fp32 rounding of the product. */
 int rd_set_precision(rd_ctx* ctx, int mode);
-/* Workgroup shape of the fp32 matrix-product kernels (no effect on results; for measurements): 0 (default) = 128 time steps x 256
- * channels per 256-thread workgroup, two workgroups per CU; 1 = 256 x 256 per 512-thread workgroup, one per CU (the weight
- * tile is shared by twice the rows: a third less LDS-DMA volume per FLOP, no second workgroup to run under an epilogue).
- * Applies to the exact-fp32 mode only: the split-f16 kernels exist in shape 0, the bf16x3 kernels in shape 1 (rd_set_precision). */
-int rd_set_conv_shape(rd_ctx* ctx, int shape);
-/* Block 0's first conv (one input channel: three multiply-adds and a ReLU per output; model.py:71, keras-tcn conv1D_0 of
- * residual_block_0) computed inside the kernel of the block's second conv instead of by a kernel of its own (no effect on
- * results: bit-identical; exact-fp32 mode, dilation <= 2): 1 (default) / 0.  For measurements and the identity test. */
-int rd_set_conv_fuse(rd_ctx* ctx, int on);
-/* Diagnostic of mode 2: split n fp32 values on the device exactly as the kernels do; terms_out[t * n + i] is the bf16 bit
- * pattern of term t (0 hi, 1 mid, 2 lo) of values[i]. */
-int rd_split3(rd_ctx* ctx, const float* values, size_t n, uint16_t* terms_out);
 
 /* ---- model artefacts ----------------------------------------------------------------------- */
 /* Replaces model.load_weights(checkpoint) -- radian/model.py:42-45.
@@ -121,15 +111,6 @@ int rd_load_lm_hashed(rd_ctx* ctx, const double* table, int table_order, int con
  * (10 B per time step; rounded to nearest by the head kernel, widened exactly by the decoder / assembly).  Not a
  * reference option (BASELINE configs[4] "fp16 logits"): labels equal the oracle's on the same f16-rounded rows. */
 int rd_set_logits(rd_ctx* ctx, int mode);
-/* Launch shape of the beam search (no effect on results; no reference counterpart): 0 = chosen per launch (default).  Widths
- * above 12: several waves per sequence while the launch leaves SIMDs idle, else two candidates per lane; 1 / 2 pin either.
- * Widths up to 6 (the reference's default, basecall.py:32) run two sequences per wave (one candidate per lane of a half-wave);
- * widths 7..12 run ONE sequence per wave under form 0 -- two per wave (two candidates per lane) exists and measured slower, so
- * only form 3 selects it; 3 = two per wave whenever the width allows (up to 12), 4 = always one per wave.  Widths above
- * rd_decode_lane_width() run on the general kernel whatever the form.  5 = every launch (widths up to 51, no hashed
- * contexts) through the work-queue kernel with 16 waves' worth of workgroups: the form the reads pipeline uses, with the partition's
- * resident count, for a group that holds more sequences than its decode partition.  For tests and measurements. */
-int rd_set_decode_form(rd_ctx* ctx, int form);
 /* Decode partition of the global-mode reads pipeline (rd_pipe_submit_reads_global / rd_pipe_submit_raw_global; no effect on
  * results, no reference counterpart): cus_per_xcd CUs of each of the 8 XCDs are kept free of forward workgroups (the
  * pipeline's forward streams are CU-masked to the others) and run the beam search.  A read's search is one serial chain of
@@ -299,23 +280,9 @@ int rd_pipe_submit_raw_chunk(rd_ctx* ctx, const int16_t* raw, const int64_t* rea
  * wait_for <= 0; otherwise returns once at least wait_for of the batches submitted so far (counted since the context was
  * created) have been delivered, closing the open group if what is awaited sits in it.  *delivered = that count. */
 int rd_pipe_progress(rd_ctx* ctx, int64_t wait_for, int64_t* delivered);
-/* The global-mode groups close by COVERAGE: when the forward rows gathered so far take the next group's forwards as long as the
- * beam search of this group's longest read will take (a read's search is one serial chain; radian/basecall.py:99-109 runs it
- * inline, here it runs under the next reads' forwards).  Both sides of that rule are measured by the context itself with HIP
- * events -- ns per forward row (per matrix-product mode) and us per time step of a group's longest chain (per beam width,
- * arithmetic, LM, and per occupancy of the decode partition: on_partition = 1..3 waves per SIMD, 0 = the whole chip, where the
- * built-in figure stays in force, scaled by the measured forward pace) -- starting from built-in figures for the exact-fp32
- * mode.  Read-out for tools and tests: 0 = not measured yet; *rows_per_step = the rule in force (forward rows per time step
- * of the longest read). */
-int rd_pipe_policy_read(rd_ctx* ctx, int beam_width, int on_partition, int use_lm, double* ns_per_row, double* us_per_step,
-                        int64_t* rows_per_step);
 /* Batches submitted to the reads-level pipeline so far: right after a submit, the number rd_pipe_progress must reach for
  * that batch to have been delivered. */
 int rd_pipe_submitted(rd_ctx* ctx, int64_t* submitted);
-/* Counters of the reads-level pipeline over the context's life (no reference counterpart; for tools and tests): out[0..n) of
- * { batches submitted, batches delivered, groups whose beam search was launched, of those: global-mode groups that held more sequences than
- * their decode partition keeps resident and were searched through the work queue, groups closed at that limit instead }. */
-int rd_pipe_stats(rd_ctx* ctx, int64_t* out, int n);
 
 /* RNA model file -> dense table, without a JSON object tree.  radian/basecall.py:48-57 (json.load, then every "ACGT..." key re-keyed as a
  * tuple of label indices).  The reference's default model has 4^11 keys in ~420 MB of text; these two calls scan the one shape such a
@@ -364,14 +331,6 @@ int rd_fast5_read_batch(rd_fast5* f, int64_t lo, int64_t hi, int16_t* samples, i
  * reads.  No GPU is touched and no context is needed. */
 int rd_stitch_chunk(const uint8_t* labels, const int32_t* label_len, int chunk_len, const int32_t* read_win_off, int n_reads,
                     uint8_t* seq_out, const int64_t* seq_off, int32_t* seq_len, int n_threads);
-
-/* ---- kernel timing on the launch stream (HIP events) --------------------------------------- */
-#define RD_TIMER_CONV 0   /* dilated conv 256->256 (MFMA), the dominant kernel */
-#define RD_TIMER_DECODE 1 /* beam search */
-#define RD_TIMER_HEAD 2   /* dense head + softmax */
-#define RD_TIMER_IN 3     /* block-0 first conv (C_in = 1) */
-int rd_timer_enable(rd_ctx* ctx, int which, int max_launches); /* 0 disables */
-int rd_timer_read(rd_ctx* ctx, int which, double* total_ms, int* launches, double* flops, double* bytes);
 
 /* ---- multi-GPU start-up: one RCCL broadcast of weights + LM table over xGMI ------------------- */
 /* librccl can be loaded in this process (dlopen + symbol lookup; creates nothing).  Ranks other than the one that draws the

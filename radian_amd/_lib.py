@@ -27,15 +27,11 @@ SIGNATURES = {
     "rd_destroy": (c_i, [c_vp]),
     "rd_sync": (c_i, [c_vp]),
     "rd_set_precision": (c_i, [c_vp, c_i]),
-    "rd_set_conv_fuse": (c_i, [c_vp, c_i]),
-    "rd_set_conv_shape": (c_i, [c_vp, c_i]),
-    "rd_split3": (c_i, [c_vp, c_vp, c_sz, c_vp]),
     "rd_load_weights": (c_i, [c_vp, c_vp, c_sz]),
     "rd_load_lm": (c_i, [c_vp, c_vp, c_i]),
     "rd_load_lm_absent": (c_i, [c_vp, c_i]),
     "rd_load_lm_hashed": (c_i, [c_vp, c_vp, c_i, c_i]),
     "rd_set_logits": (c_i, [c_vp, c_i]),
-    "rd_set_decode_form": (c_i, [c_vp, c_i]),
     "rd_set_decode_math": (c_i, [c_vp, c_i]),
     "rd_set_decode_partition": (c_i, [c_vp, c_i]),
     "rd_forward": (c_i, [c_vp, c_vp, c_i, c_i, c_vp]),
@@ -53,9 +49,7 @@ SIGNATURES = {
     "rd_pipe_submit_raw_global": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp, c_vp]),
     "rd_pipe_submit_raw_chunk": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
     "rd_pipe_progress": (c_i, [c_vp, c_i64, c_i64p]),
-    "rd_pipe_policy_read": (c_i, [c_vp, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
     "rd_pipe_submitted": (c_i, [c_vp, c_i64p]),
-    "rd_pipe_stats": (c_i, [c_vp, c_i64p, c_i]),
     "rd_normalise_reads": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_vp, c_vp]),
     "rd_basecall_raw_chunk": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
     "rd_basecall_raw_global": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_vp, c_vp, c_vp, c_vp]),
@@ -82,8 +76,6 @@ SIGNATURES = {
     "rd_pipe_set_lanes": (c_i, [c_vp, c_i]),
     "rd_pipe_submit": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_i, c_vp, c_vp]),
     "rd_pipe_flush": (c_i, [c_vp]),
-    "rd_timer_enable": (c_i, [c_vp, c_i, c_i]),
-    "rd_timer_read": (c_i, [c_vp, c_i, c_dp, ctypes.POINTER(c_i), c_dp, c_dp]),
     "rd_rccl_probe": (c_i, []),
     "rd_rccl_unique_id": (c_i, [c_vp]),
     "rd_rccl_init": (c_i, [c_vp, c_i, c_i, c_vp]),
@@ -93,6 +85,19 @@ SIGNATURES = {
     "rd_rccl_barrier": (c_i, [c_vp]),
     "rd_rccl_comm_count": (c_i, [c_vp, ctypes.POINTER(c_i)]),
     "rd_rccl_finalize": (c_i, [c_vp]),
+}
+
+# every symbol include/radian_hip_diag.h declares (measurement switches, kernel timers, pipeline read-outs: bench.py, tools/, tests/;
+# the command line calls none of them)
+DIAG_SIGNATURES = {
+    "rd_set_conv_fuse": (c_i, [c_vp, c_i]),
+    "rd_set_conv_shape": (c_i, [c_vp, c_i]),
+    "rd_split3": (c_i, [c_vp, c_vp, c_sz, c_vp]),
+    "rd_set_decode_form": (c_i, [c_vp, c_i]),
+    "rd_pipe_policy_read": (c_i, [c_vp, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
+    "rd_pipe_stats": (c_i, [c_vp, c_i64p, c_i]),
+    "rd_timer_enable": (c_i, [c_vp, c_i, c_i]),
+    "rd_timer_read": (c_i, [c_vp, c_i, c_dp, ctypes.POINTER(c_i), c_dp, c_dp]),
 }
 
 _lib = None
@@ -108,7 +113,7 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -m radian_amd.build` (hipcc --offload-arch=gfx950). "
             "radian_amd has no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in {**SIGNATURES, **DIAG_SIGNATURES}.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args

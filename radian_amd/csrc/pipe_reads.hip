@@ -16,6 +16,7 @@
 #include "common.h"
 #include "plan.h"
 #include "../../include/radian_hip.h"
+#include "../../include/radian_hip_diag.h"   // measurement / diagnostic entry points defined in this file
 
 #include <stdio.h>
 #include <time.h>

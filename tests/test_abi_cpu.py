@@ -1,5 +1,5 @@
 """No-GPU checks of the C-ABI boundary: the library builds/loads and exports every symbol
-include/radian_hip.h declares; without a GPU the product fails loudly (no CPU fallback)."""
+include/radian_hip.h (the boundary) and include/radian_hip_diag.h (measurement entry points) declare; without a GPU the product fails loudly (no CPU fallback)."""
 import ctypes
 import os
 import re
@@ -16,8 +16,8 @@ def lib():
     return _lib.load()
 
 
-def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "radian_hip.h")).read()
+def declared_symbols(header="radian_hip.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(rd_[a-z0-9_]+)\s*\(", txt)))
 
@@ -30,6 +30,37 @@ def test_header_symbols_all_exported(lib):
         assert hasattr(lib, n), f"libradian_hip.so does not export {n}"
     # and the ctypes table binds exactly the declared set
     assert sorted(_lib.SIGNATURES) == names
+
+
+def test_diag_header_holds_the_measurement_entry_points_and_the_product_header_none(lib):
+    """Round 6: include/radian_hip.h lists what a RADIAN maintainer binds; launch-shape switches, kernel timers and
+    pipeline read-outs live in include/radian_hip_diag.h (same library).  Both headers together == the library's exported rd_ symbols ==
+    the two ctypes tables; the command-line route (basecall / launch / dist and the readers) calls no diagnostic entry point."""
+    import subprocess
+    from radian_amd import _lib
+    diag = declared_symbols("radian_hip_diag.h")
+    prod = declared_symbols()
+    assert sorted(_lib.DIAG_SIGNATURES) == diag and len(diag) == 8
+    assert not set(diag) & set(prod)
+    for n in diag:
+        assert hasattr(lib, n), f"libradian_hip.so does not export {n}"
+    for word in ("rd_timer_", "rd_set_conv_shape", "rd_set_conv_fuse", "rd_set_decode_form", "rd_split3", "rd_pipe_stats", "rd_pipe_policy_read", "RD_TIMER_"):
+        assert word not in open(os.path.join(ROOT, "include", "radian_hip.h")).read(), word
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if re.search(r"\s[TW]\s+rd_[a-z0-9_]+$", ln)})
+    assert exported == sorted(prod + diag), sorted(set(exported) ^ set(prod + diag))
+    # the command line's modules never reach a diagnostic wrapper of Backend
+    wrappers = ("set_conv_shape", "set_conv_fuse", "split3", "set_decode_form", "pipe_policy_read", "pipe_stats", "timer_enable", "timer_read")
+    pkg = os.path.join(ROOT, "radian_amd")
+    for f in sorted(os.listdir(pkg)):
+        if f.endswith(".py") and f not in ("backend.py", "_lib.py"):
+            src = open(os.path.join(pkg, f)).read()
+            for w in wrappers:
+                assert not re.search(r"\b" + w + r"\(", src), (f, w)
+    # INTEGRATION.md binds the product header only
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for n in diag:
+        assert n not in integ, n
 
 
 def test_version_and_limits(lib):
