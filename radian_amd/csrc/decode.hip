@@ -213,7 +213,7 @@ __device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int 
 
         const int tend = (T - t0) < 64 ? (T - t0) : 64;
         for (int tt = 0; tt < tend; tt++) {
-            const Beam* __restrict__ os = st[cur];
+            const Beam* os = st[cur];                 // (no __restrict__: the scores-only step below writes these records in place)
             Beam* __restrict__ ns = st[cur ^ 1];
             const int ncand = 5 * nb;
 
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(64) void beam_search2_kernel(DecodeArgs a, int n_se
         const int tend = (Tmax - t0) < TS ? (Tmax - t0) : TS;
         for (int tt = 0; tt < tend; tt++) {
             const bool live = t0 + tt < T;                  // this half's sequence still has a row (uniform within the half)
-            const Beam* __restrict__ os = st_[h][cur];
+            const Beam* os = st_[h][cur];           // (no __restrict__: the scores-only step writes these records in place)
             Beam* __restrict__ ns = st_[h][cur ^ 1];
             const int ncand = live ? 5 * nb : 0;
 
