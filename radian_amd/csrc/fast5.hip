@@ -358,8 +358,45 @@ void unfilter_chunk(const Signal& s, const uint8_t* src, size_t n, uint32_t fmas
     memcpy(out, cur, raw);
 }
 
-void resolve_signal(const Image& im, uint64_t at, Signal& s)
+// a fill value other than zero (fill-value message 0x0005, versions 1-3; the old message 0x0004): libhdf5 reads unallocated storage
+// and missing chunks as that value, this reader as zero
+bool nonzero_fill(const Image& im, const std::vector<Msg>& ms)
 {
+    auto any = [&](uint64_t p, uint64_t size, const Msg& m) {
+        if (p > m.data + m.size || size > m.data + m.size - p) throw NoVerdict{"fill value runs past its message"};
+        im.need(p, size);
+        for (uint64_t i = 0; i < size; i++)
+            if (im.p[p + i]) return true;
+        return false;
+    };
+    if (const Msg* fv = find_msg(ms, 0x0005)) {
+        if (fv->flags & 0x02) throw NoVerdict{"shared fill-value message"};
+        const uint8_t ver = im.u8(fv->data);
+        if (ver == 1 || ver == 2) {
+            const bool defined = im.u8(fv->data + 3) != 0;
+            if ((ver == 1 || defined) && fv->size >= 8) {
+                const uint32_t size = im.u32(fv->data + 4);
+                if (any(fv->data + 8, size, *fv)) return true;
+            }
+        } else if (ver == 3) {
+            if (im.u8(fv->data + 1) & 0x20) {
+                const uint32_t size = im.u32(fv->data + 2);
+                if (any(fv->data + 6, size, *fv)) return true;
+            }
+        } else {
+            throw NoVerdict{"unknown fill-value message version"};
+        }
+    }
+    if (const Msg* old = find_msg(ms, 0x0004)) {
+        if (old->flags & 0x02) throw NoVerdict{"shared fill-value message"};
+        if (old->size >= 4 && any(old->data + 4, im.u32(old->data), *old)) return true;
+    }
+    return false;
+}
+
+void resolve_signal(const Image& im, uint64_t at, Signal& result)
+{
+    Signal s;                // (filled here, handed over only when everything about the dataset is understood: a failed attempt leaves `result` as it was)
     std::vector<Msg> ms;
     header_messages(im, at, ms);
     const Msg *dt = find_msg(ms, 0x0003), *sp = find_msg(ms, 0x0001), *lay = find_msg(ms, 0x0008);
@@ -367,6 +404,7 @@ void resolve_signal(const Image& im, uint64_t at, Signal& s)
     const Msg* fl = find_msg(ms, 0x000B);
     if (fl) parse_filters(im, *fl, s.filters);
     if (find_msg(ms, 0x0007)) throw NoVerdict{"Signal lives in external files"};
+    if (nonzero_fill(im, ms)) throw NoVerdict{"Signal has a fill value other than zero"};
     if ((dt->flags | sp->flags | lay->flags) & 0x02) throw NoVerdict{"shared (committed) datatype / dataspace message"};
     // datatype: class 0 (fixed point), little-endian, signed, 2 bytes, 16-bit precision at offset 0
     const uint8_t cv = im.u8(dt->data), bits0 = im.u8(dt->data + 1);
@@ -400,6 +438,7 @@ void resolve_signal(const Image& im, uint64_t at, Signal& s)
     if (!s.filters.empty() && s.cls != 2) throw NoVerdict{"filters on a dataset that is not chunked"};
     if (!s.filters.empty() && s.chunk_len > (1u << 24)) throw NoVerdict{"implausibly large filtered chunk"};
     s.resolved = true;
+    result = std::move(s);
 }
 
 struct Scratch {
@@ -482,6 +521,7 @@ bool string_attr(const Image& im, uint64_t at, const char* name, std::string& ou
         p += pad(tsz);
         p += pad(ssz);
         if (!mine) continue;
+        if (ver >= 2 && (im.u8(m.data + 1) & 0x03)) throw NoVerdict{"read_id attribute with a shared (committed) datatype / dataspace"};
         const uint8_t cls = im.u8(tp) & 0x0f;
         if (cls == 9) {      // variable-length string (what h5py writes for a Python str: ont_fast5_api's multi_to_single output): the value is in the global heap
             if ((im.u8(tp + 1) & 0x0f) != 1) throw NoVerdict{"read_id attribute is a variable-length sequence, not a string"};
@@ -510,6 +550,7 @@ bool string_attr(const Image& im, uint64_t at, const char* name, std::string& ou
             throw NoVerdict{"variable-length string not found in its heap collection"};
         }
         if (cls != 3) throw NoVerdict{"read_id attribute is not a string"};
+        if ((im.u8(tp + 1) & 0x0f) > 1) throw NoVerdict{"read_id attribute is a space-padded string"};   // (0 NUL-terminated, 1 NUL-padded: what strnlen below undoes)
         const uint32_t size = im.u32(tp + 4);
         if (p > m.data + m.size || size > m.data + m.size - p) throw NoVerdict{"attribute value runs past its message"};
         im.need(p, size);

@@ -80,6 +80,7 @@ def lib():
         "H5Tcopy": (hid_t, [hid_t]),
         "H5Tset_size": (herr_t, [hid_t, ctypes.c_size_t]),
         "H5Tset_strpad": (herr_t, [hid_t, ctypes.c_int]),
+        "H5Tget_strpad": (ctypes.c_int, [hid_t]),
         "H5Tclose": (herr_t, [hid_t]),
         "H5Aexists": (ctypes.c_int, [hid_t, ctypes.c_char_p]),
         "H5Aopen": (hid_t, [hid_t, ctypes.c_char_p, hid_t]),
@@ -94,6 +95,7 @@ def lib():
         "H5Pset_deflate": (herr_t, [hid_t, ctypes.c_uint]),
         "H5Pset_shuffle": (herr_t, [hid_t]),
         "H5Pset_fletcher32": (herr_t, [hid_t]),
+        "H5Pset_fill_value": (herr_t, [hid_t, hid_t, ctypes.c_void_p]),
         "H5Pclose": (herr_t, [hid_t]),
         "H5Eset_auto2": (herr_t, [hid_t, ctypes.c_void_p, ctypes.c_void_p]),
     }
@@ -272,7 +274,10 @@ class File:
                         raw = ctypes.create_string_buffer(size * n)
                         if L.H5Aread(aid, tid, raw) < 0:
                             raise H5Error(f"H5Aread failed on {obj_path}@{name}")
-                        vals = [raw.raw[i * size:(i + 1) * size].split(b"\0")[0].decode("utf-8", "replace") for i in range(n)]
+                        vals = [raw.raw[i * size:(i + 1) * size].split(b"\0")[0] for i in range(n)]
+                        if L.H5Tget_strpad(tid) == 2:          # H5T_STR_SPACEPAD: h5py's conversion to a NumPy 'S' type drops the blanks
+                            vals = [v.rstrip(b" ") for v in vals]
+                        vals = [v.decode("utf-8", "replace") for v in vals]
                     return vals[0] if nd == 0 else vals
                 if cls in (H5T_INTEGER, H5T_FLOAT):
                     sign = L.H5Tget_sign(tid)
@@ -302,8 +307,10 @@ class File:
                 raise H5Error(f"cannot create group {cur!r}")
             L.H5Gclose(gid)
 
-    def write(self, path, array, chunks=None, filters=()):
-        """filters (chunked datasets only), applied in the order given: "shuffle", "fletcher32", ("deflate", level)"""
+    def write(self, path, array, chunks=None, filters=(), fill=None, store=True):
+        """filters (chunked datasets only), applied in the order given: "shuffle", "fletcher32", ("deflate", level).
+        fill: the dataset's fill value (H5Pset_fill_value); store=False creates the dataset without writing its elements -- storage
+        stays unallocated and reads return the fill value (fixtures for the native fast5 reader's "no verdict" cases)."""
         L = lib()
         a = np.ascontiguousarray(array)
         parent = path.rsplit("/", 1)[0]
@@ -312,8 +319,13 @@ class File:
         dims = (hsize_t * max(a.ndim, 1))(*a.shape)
         sid = L.H5Screate_simple(a.ndim, dims, None)
         dcpl = H5P_DEFAULT
-        if chunks is not None and a.size:
+        if fill is not None or (chunks is not None and a.size):
             dcpl = L.H5Pcreate(_types["dcpl"])
+        if fill is not None:
+            fv = np.asarray(fill, dtype=a.dtype).reshape(1)
+            if L.H5Pset_fill_value(dcpl, _types[a.dtype], fv.ctypes.data_as(ctypes.c_void_p)) < 0:
+                raise H5Error("cannot set the fill value")
+        if chunks is not None and a.size:
             cd = (hsize_t * a.ndim)(*chunks)
             L.H5Pset_chunk(dcpl, a.ndim, cd)
             for f in filters:
@@ -324,7 +336,7 @@ class File:
         did = L.H5Dcreate2(self.id, _b(path), _types[a.dtype], sid, H5P_DEFAULT, dcpl, H5P_DEFAULT)
         if did < 0:
             raise H5Error(f"cannot create dataset {path!r}")
-        if a.size and L.H5Dwrite(did, _types[a.dtype], H5S_ALL, H5S_ALL, H5P_DEFAULT, a.ctypes.data_as(ctypes.c_void_p)) < 0:
+        if store and a.size and L.H5Dwrite(did, _types[a.dtype], H5S_ALL, H5S_ALL, H5P_DEFAULT, a.ctypes.data_as(ctypes.c_void_p)) < 0:
             raise H5Error(f"H5Dwrite failed on {path!r}")
         L.H5Dclose(did)
         L.H5Sclose(sid)
@@ -335,7 +347,7 @@ class File:
         """String attribute: scalar (str) or 1-D array (list of str), in one of the three forms found in the wild:
         kind "nullterm" fixed-length, NUL-terminated (the C default); "nullpad" fixed-length NUL-padded with no room for
         a terminator -- what h5py writes for a NumPy 'S' array, i.e. Keras 2.4's `layer_names` / `weight_names`;
-        "vlen" variable-length strings -- what h5py 3 writes for str objects."""
+        "vlen" variable-length strings -- what h5py 3 writes for str objects; "spacepad" fixed-length padded with blanks (Fortran's form)."""
         L = lib()
         vals = [value] if isinstance(value, str) else list(value)
         enc = [v.encode("utf-8") for v in vals]
@@ -347,13 +359,15 @@ class File:
             buf = (ctypes.c_char_p * len(enc))(*[ctypes.cast(k, ctypes.c_char_p) for k in keep])
         else:
             longest = max(len(e) for e in enc) if enc else 0
-            size = max(1, longest + (0 if kind == "nullpad" else 1))
+            size = max(1, longest + (0 if kind == "nullpad" else 4 if kind == "spacepad" else 1))
             L.H5Tset_size(tid, size)
             if kind == "nullpad":
                 L.H5Tset_strpad(tid, 1)                      # H5T_STR_NULLPAD
+            elif kind == "spacepad":
+                L.H5Tset_strpad(tid, 2)                      # H5T_STR_SPACEPAD
             elif kind != "nullterm":
                 raise ValueError(f"unknown string attribute kind {kind!r}")
-            buf = ctypes.create_string_buffer(b"".join(e.ljust(size, b"\0") for e in enc), max(1, size * len(enc)))
+            buf = ctypes.create_string_buffer(b"".join(e.ljust(size, b" " if kind == "spacepad" else b"\0") for e in enc), max(1, size * len(enc)))
         if isinstance(value, str):
             sid = L.H5Screate(0)  # H5S_SCALAR
         else:

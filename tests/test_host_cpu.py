@@ -875,6 +875,70 @@ def test_native_fast5_reader_single_read_files_as_h5py_writes_them(tmp_path):
         assert names == [rid], (i, names)
 
 
+@pytest.mark.skipif(not _have_hdf5(), reason="libhdf5 not available")
+def test_native_fast5_reader_gives_no_verdict_on_what_it_does_not_model(tmp_path):
+    """ADVICE r5 (csrc/fast5.hip): cases the native reader used to answer silently now end without a verdict and libhdf5 reads the file --
+    a Signal with a fill value other than zero (libhdf5 returns that value for storage that was never written: contiguous and chunked),
+    a space-padded fixed-length read_id.  A zero fill value and NUL-padded ids stay native.  A failed resolve leaves no state behind:
+    asking the same handle again gives the same answer."""
+    from radian_amd import fast5, h5, _lib
+    import ctypes
+    L = _lib.load()
+
+    def native(path):
+        h = ctypes.c_void_p()
+        assert L.rd_fast5_open(path.encode(), ctypes.byref(h)) == 0
+        n = ctypes.c_int64()
+        assert L.rd_fast5_count(h, ctypes.byref(n)) == 0
+        lens = np.zeros(n.value, dtype=np.int64)
+        rcs = [L.rd_fast5_lengths(h, 0, n.value, lens.ctypes.data_as(ctypes.c_void_p)) for _ in range(2)]   # (twice: a retry on the same entry)
+        msg = L.rd_last_error().decode()
+        out = None
+        if rcs[0] == 0:
+            samples = np.zeros(int(lens.sum()) + 1, dtype=np.int16)
+            off = np.zeros(n.value + 1, dtype=np.int64)
+            ids = ctypes.create_string_buffer(64 * n.value)
+            rc = L.rd_fast5_read_batch(h, 0, n.value, samples.ctypes.data_as(ctypes.c_void_p), samples.size, off.ctypes.data_as(ctypes.c_void_p), ids, 64)
+            msg = L.rd_last_error().decode()
+            out = (rc, samples[: int(lens.sum())], [ids.raw[i * 64:(i + 1) * 64].split(b"\0")[0].decode() for i in range(n.value)])
+        L.rd_fast5_close(h)
+        return rcs, msg, out
+
+    sig = np.arange(1, 2501, dtype=np.int16)
+    cases = []
+    for name, kw in (("fill7_contig_unwritten", dict(fill=7, store=False)), ("fill7_chunked_unwritten", dict(fill=7, store=False, chunks=(1000,))),
+                     ("fill7_chunked_written", dict(fill=7, chunks=(1000,))), ("fill0_contig_unwritten", dict(fill=0, store=False)),
+                     ("fill0_chunked_written", dict(fill=0, chunks=(1000,), filters=(("deflate", 1),)))):
+        p = str(tmp_path / (name + ".fast5"))
+        with h5.File(p, "w") as f:
+            f.create_group("/read_a/Raw")
+            f.write("/read_a/Raw/Signal", sig, **kw)
+        cases.append((name, p, kw))
+    for name, p, kw in cases:
+        rcs, msg, out = native(p)
+        ref = _iter_libhdf5(p)
+        exp = np.full(2500, kw["fill"], dtype=np.int16) if not kw.get("store", True) else sig
+        assert ref[0][0] == "a" and np.array_equal(ref[0][1], exp), name
+        if kw["fill"] == 7:
+            assert rcs == [-6, -6] and "fill value" in msg, (name, rcs, msg)            # RD_ERR_FORMAT, both times
+        else:
+            assert rcs == [0, 0] and out[0] == 0 and np.array_equal(out[1], exp), (name, rcs, msg)
+        got = [(r.read_id, np.asarray(r.get_raw_data())) for r in fast5.iter_reads(p)]        # the product's route: native first, libhdf5 takes over
+        assert got[0][0] == "a" and np.array_equal(got[0][1], exp), name
+    # single-read files: a space-padded read_id has no native verdict; libhdf5 (like h5py) hands the id without its blanks
+    for kind, native_ok in (("spacepad", False), ("nullpad", True), ("nullterm", True)):
+        p = str(tmp_path / f"id_{kind}.fast5")
+        _write_single_read_fast5(p, "0a1b-id", sig, id_kind=kind)
+        rcs, msg, out = native(p)
+        if native_ok:
+            assert rcs == [0, 0] and out[2] == ["0a1b-id"] and np.array_equal(out[1], sig), (kind, rcs, msg)
+        else:
+            assert rcs == [-6, -6] and "space-padded" in msg, (kind, rcs, msg)
+        got = [(r.read_id, np.asarray(r.get_raw_data())) for r in fast5.iter_reads(p)]
+        assert got == [] or (got[0][0] == "0a1b-id" and np.array_equal(got[0][1], sig)), (kind, got[0][0])
+        assert len(got) == 1
+
+
 def _iter_libhdf5(path):
     from radian_amd import fast5
     old = os.environ.get("RADIAN_FAST5_NATIVE")
