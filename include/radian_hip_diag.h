@@ -35,6 +35,12 @@ int rd_set_conv_fuse(rd_ctx* ctx, int on);
  * resident count, for a group that holds more sequences than its decode partition.  For tests and measurements. */
 int rd_set_decode_form(rd_ctx* ctx, int form);
 
+/* Workspace one beam-search launch may ask for, in bytes (default 24 GiB; 0 restores it).  A launch needs (1 + W * rows) trie nodes of
+ * 20-24 B per sequence for all its sequences at once; launches that would need more are cut into runs of sequences that go one after the
+ * other on the same stream and share the workspace (at least one sequence per run).  No effect on results: the test that cuts small
+ * launches into many runs sets this. */
+int rd_set_trie_budget(rd_ctx* ctx, int64_t bytes);
+
 /* ---- numerics diagnostic -------------------------------------------------------------------- */
 /* Diagnostic of rd_set_precision mode 2 (bf16x3): split n fp32 values on the device exactly as the kernels do; terms_out[t * n + i] is the bf16 bit
  * pattern of term t (0 hi, 1 mid, 2 lo) of values[i]. */

@@ -96,6 +96,7 @@ DIAG_SIGNATURES = {
     "rd_set_decode_form": (c_i, [c_vp, c_i]),
     "rd_pipe_policy_read": (c_i, [c_vp, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
     "rd_pipe_stats": (c_i, [c_vp, c_i64p, c_i]),
+    "rd_set_trie_budget": (c_i, [c_vp, c_i64]),
     "rd_timer_enable": (c_i, [c_vp, c_i, c_i]),
     "rd_timer_read": (c_i, [c_vp, c_i, c_dp, ctypes.POINTER(c_i), c_dp, c_dp]),
 }

@@ -190,6 +190,11 @@ class Backend:
         """'f32' (default) or 'f16': storage of the softmax rows on the reads-level paths (rd_set_logits)."""
         self._check(self._L.rd_set_logits(self._h, {"f32": 0, "f16": 1}[mode] if isinstance(mode, str) else int(mode)))
 
+    def set_trie_budget(self, nbytes):
+        """workspace one beam-search launch may ask for (rd_set_trie_budget; 0 = the default 24 GiB): launches beyond it run as several
+        runs of sequences sharing the workspace.  No effect on results -- tests set it small to exercise the cut."""
+        self._check(self._L.rd_set_trie_budget(self._h, int(nbytes)))
+
     def set_conv_fuse(self, on):
         """block 0's first conv inside its second conv's kernel (default) or as a kernel of its own (rd_set_conv_fuse); same bits"""
         self._check(self._L.rd_set_conv_fuse(self._h, 1 if on else 0))

@@ -527,6 +527,8 @@ def load_artifacts(args, cache_dir=None):
             if k != args.context_len and getattr(args, "lm_hashed_context", False):
                 if not (k < args.context_len <= 256):   # (a shorter context has a dense table of its own: not what the flag is for)
                     raise ValueError(f"--lm-hashed-context: --context-len must be longer than the RNA model's {k}-label contexts, at most 256")
+                if args.beam_width > 64:                # (hashed contexts exist in the wave-per-sequence kernels only; said here, before any read is touched)
+                    raise ValueError("--lm-hashed-context: --beam-width must be at most 64 (wider beams run on the general kernel, which has no hashed contexts)")
                 art["lm_table"], art["lm_k"], art["lm_hashed_order"] = table, args.context_len, k
                 return art
             if k != args.context_len:

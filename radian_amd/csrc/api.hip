@@ -607,6 +607,14 @@ extern "C" int rd_set_decode_form(rd_ctx* ctx, int form)
     return RD_OK;
 }
 
+extern "C" int rd_set_trie_budget(rd_ctx* ctx, int64_t bytes)
+{
+    RD_REQUIRE(ctx, "rd_set_trie_budget: null context");
+    RD_REQUIRE(bytes >= 0, "rd_set_trie_budget: negative budget");
+    ctx->trie_budget = bytes ? bytes : (int64_t)24 << 30;
+    return RD_OK;
+}
+
 extern "C" int rd_set_conv_shape(rd_ctx* ctx, int shape)
 {
     RD_REQUIRE(ctx, "rd_set_conv_shape: null context");
@@ -648,7 +656,8 @@ struct SeqMeta {
     int64_t *d_seq_off, *d_seq_off2, *d_node_off, *d_label_off;
     int32_t *d_seq_len, *d_split, *d_label_len;
     double* d_score;
-    int64_t total_nodes, total_labels;
+    int64_t total_labels;
+    std::vector<TrieRun> runs;   // launches that share the trie workspace, one after the other (rd_plan_trie_runs)
 };
 
 // uploads per-sequence metadata; seq_off2/split may be null (single source region per sequence)
@@ -656,16 +665,16 @@ int prepare_seq_meta(rd_ctx* ctx, const int64_t* seq_off, const int64_t* seq_off
                      int n_seq, int W, SeqMeta& sm, std::vector<int64_t>& label_off_used)
 {
     std::vector<int64_t> node_off(n_seq), lab_off(n_seq);
-    int64_t nodes = 0, labs = 0;
+    int64_t labs = 0;
     for (int i = 0; i < n_seq; i++) {
         RD_REQUIRE(seq_len[i] >= 0, "decode: negative sequence length at %d", i);
         RD_REQUIRE(rd_decode_len_ok(W, seq_len[i]), "decode: sequence %d has %d rows; beam width %d supports at most %lld (1 + W * rows < 2^29)", i,
                    seq_len[i], W, (long long)((((int64_t)1 << 29) - 2) / W));
-        node_off[i] = nodes;
-        nodes += 1 + (int64_t)W * seq_len[i];
         lab_off[i] = labs;
         labs += seq_len[i];
     }
+    sm.runs.clear();
+    rd_plan_trie_runs(ctx, W, 0, n_seq, [&](int k) { return (int64_t)seq_len[k]; }, node_off.data(), sm.runs);
     label_off_used = lab_off;
     const size_t n = (size_t)n_seq;
     const size_t a8 = align_up(n * 8, 256), a4 = align_up(n * 4, 256);
@@ -679,7 +688,6 @@ int prepare_seq_meta(rd_ctx* ctx, const int64_t* seq_off, const int64_t* seq_off
     sm.d_seq_len = (int32_t*)p; p += a4;
     sm.d_split = (int32_t*)p; p += a4;
     sm.d_label_len = (int32_t*)p;
-    sm.total_nodes = nodes;
     sm.total_labels = labs;
     // The metadata goes through the context's pinned staging block in ONE copy that needs no host-side wait: the block
     // is only rewritten by the next call on this context, and a caller that runs to completion ends with a stream
@@ -738,10 +746,12 @@ int decode_and_fetch(rd_ctx* ctx, const void* d_probs, int is_f64, const int64_t
     hipStream_t ds = ctx->stream_hi;
     RD_HIP(hipEventRecord(ctx->ev_chain, ctx->stream));
     RD_HIP(hipStreamWaitEvent(ds, ctx->ev_chain, 0));
-    rc = rd_decode_dev(ctx, d_probs, is_f64, sm.d_seq_off, sm.d_seq_len, sm.d_node_off, sm.d_label_off, n_seq, sm.total_nodes, W,
-                       use_lm, s_thr, r_thr, d_labels, sm.d_label_len, best_score ? sm.d_score : nullptr, ds, sm.d_seq_off2,
-                       sm.d_split);
-    if (rc) return rc;
+    for (const TrieRun& r : sm.runs) {
+        rc = rd_decode_dev(ctx, d_probs, is_f64, sm.d_seq_off + r.k0, sm.d_seq_len + r.k0, sm.d_node_off + r.k0, sm.d_label_off + r.k0, r.k1 - r.k0,
+                           r.nodes, W, use_lm, s_thr, r_thr, d_labels, sm.d_label_len + r.k0, best_score ? sm.d_score + r.k0 : nullptr, ds,
+                           sm.d_seq_off2 ? sm.d_seq_off2 + r.k0 : nullptr, sm.d_split ? sm.d_split + r.k0 : nullptr);
+        if (rc) return rc;
+    }
     std::vector<uint8_t> hl((size_t)sm.total_labels + 16);
     RD_HIP(hipMemcpyAsync(hl.data(), d_labels, (size_t)sm.total_labels, hipMemcpyDeviceToHost, ds));
     RD_HIP(hipMemcpyAsync(label_len, sm.d_label_len, (size_t)n_seq * 4, hipMemcpyDeviceToHost, ds));
@@ -810,6 +820,7 @@ extern "C" int rd_decode_batch(rd_ctx* ctx, const void* probs, int prob_is_f64, 
     RD_REQUIRE(seq_off && seq_len && labels_out && label_off && label_len, "rd_decode_batch: null argument");
     RD_REQUIRE(beam_width >= 1 && beam_width <= rd_decode_max_width(), "rd_decode_batch: beam_width %d out of range [1,%d]",
                beam_width, rd_decode_max_width());
+    RD_REQUIRE_WIDTH_LM(ctx, beam_width, use_lm);
     RD_HIP(hipSetDevice(ctx->device));
     int64_t rows = 0;
     for (int i = 0; i < n_seq; i++) {
@@ -894,6 +905,7 @@ extern "C" int rd_basecall_global(rd_ctx* ctx, const float* windows, int chunk_l
     RD_REQUIRE(n_reads >= 1 && chunk_len >= 1, "rd_basecall_global: bad shape");
     RD_REQUIRE(step >= 1 && step <= chunk_len, "rd_basecall_global: step %d must be in [1, chunk_len]", step);
     RD_REQUIRE(beam_width >= 1 && beam_width <= rd_decode_max_width(), "beam_width %d out of range", beam_width);
+    RD_REQUIRE_WIDTH_LM(ctx, beam_width, use_lm);
     RD_HIP(hipSetDevice(ctx->device));
     const int nW = read_win_off[n_reads];
     RD_REQUIRE(nW >= n_reads, "rd_basecall_global: every read needs at least one window");
@@ -1093,12 +1105,9 @@ int pipe_launch_decode(rd_ctx* ctx, Pipe* p, PipeSlot& s)
     memcpy(hm + o_off2, s.off2.data(), n * 8);
     memcpy(hm + o_len, s.valid.data(), n * 4);
     memcpy(hm + o_split, s.split.data(), n * 4);
-    int64_t nodes = 0;
-    for (int i = 0; i < s.nwin; i++) {
-        h_lab[i] = (int64_t)i * s.T;
-        h_node[i] = nodes;
-        nodes += 1 + (int64_t)s.W * s.valid[i];
-    }
+    for (int i = 0; i < s.nwin; i++) h_lab[i] = (int64_t)i * s.T;
+    std::vector<TrieRun> runs;
+    rd_plan_trie_runs(ctx, s.W, 0, s.nwin, [&](int k) { return (int64_t)s.valid[k]; }, h_node, runs);
     if (s.labels.reserve(nT + 16)) return RD_ERR_NOMEM;
     if ((rc = pinned_reserve(&s.h_out, &s.h_out_cap, align_up(nT, 256) + n * 4))) return rc;
     if ((rc = rd_rpipe_drain_decode(ctx))) return rc;   // (beam searches of the other pipeline use the same trie workspace)
@@ -1106,10 +1115,12 @@ int pipe_launch_decode(rd_ctx* ctx, Pipe* p, PipeSlot& s)
         if (s.lane_mask & (1u << l)) RD_HIP(hipStreamWaitEvent(p->s_dec, ctx->lanes[l].done, 0));
     RD_HIP(hipMemcpyAsync(s.meta.p, s.h_meta, o_llen, hipMemcpyHostToDevice, p->s_dec));
     char* dm = (char*)s.meta.p;
-    rc = rd_decode_dev(ctx, s.probs.p, s.f16 ? 2 : 0, (const int64_t*)dm, (const int32_t*)(dm + o_len), (const int64_t*)(dm + o_node),
-                       (const int64_t*)(dm + o_lab), s.nwin, nodes, s.W, 0, 0.0, 0.0, s.labels.as<uint8_t>(),
-                       (int32_t*)(dm + o_llen), nullptr, p->s_dec, (const int64_t*)(dm + o_off2), (const int32_t*)(dm + o_split));
-    if (rc) return rc;
+    for (const TrieRun& r : runs) {
+        rc = rd_decode_dev(ctx, s.probs.p, s.f16 ? 2 : 0, (const int64_t*)dm + r.k0, (const int32_t*)(dm + o_len) + r.k0, (const int64_t*)(dm + o_node) + r.k0,
+                           (const int64_t*)(dm + o_lab) + r.k0, r.k1 - r.k0, r.nodes, s.W, 0, 0.0, 0.0, s.labels.as<uint8_t>(),
+                           (int32_t*)(dm + o_llen) + r.k0, nullptr, p->s_dec, (const int64_t*)(dm + o_off2) + r.k0, (const int32_t*)(dm + o_split) + r.k0);
+        if (rc) return rc;
+    }
     RD_HIP(hipMemcpyAsync(s.h_out, s.labels.p, nT, hipMemcpyDeviceToHost, p->s_dec));
     RD_HIP(hipMemcpyAsync((char*)s.h_out + align_up(nT, 256), dm + o_llen, n * 4, hipMemcpyDeviceToHost, p->s_dec));
     RD_HIP(hipEventRecord(s.dec_done, p->s_dec));
@@ -1529,6 +1540,7 @@ extern "C" int rd_basecall_reads_global_resident(rd_ctx* ctx, const float* d_sig
     int rc = check_reads_args(ctx, d_signal, read_off, n_reads, chunk_len, step, beam_width);
     if (rc) return rc;
     RD_REQUIRE(labels_out && label_off && label_len, "rd_basecall_reads_global: null output");
+    RD_REQUIRE_WIDTH_LM(ctx, beam_width, use_lm);
     RD_HIP(hipSetDevice(ctx->device));
     const ReadsPlan* P = nullptr;
     const TileLists* tl = nullptr;

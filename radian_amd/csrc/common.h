@@ -164,6 +164,7 @@ struct rd_ctx {
     DevBuf ws_in, ws_probs, ws_mat, ws_seq, ws_nodes_child, ws_nodes_back, ws_labels, ws_misc;
     DevBuf ws_queue;                // the work-queue counter of beam_search_queue_kernel (decode.hip)
     DevBuf ws_wide, ws_wide_slot;   // beam widths above 51 (decode_wide.hip): per-sequence scratch block, per-trie-node slot map
+    int64_t trie_budget = (int64_t)24 << 30;   // bytes of beam-search workspace one launch may ask for (rd_plan_trie_runs; rd_set_trie_budget)
     // pinned host staging
     void* h_stage = nullptr;
     size_t h_stage_cap = 0;
@@ -234,3 +235,48 @@ constexpr int RD_WIDE_MAX_W = 1024;
 int rd_decode_wide_launch(rd_ctx* ctx, hipStream_t st, const void* decode_args, int ptype, int n_seq, int64_t total_nodes, bool lm);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// decode_wide.hip's per-sequence scratch block: beams [2][W] of 48 B | c_ptot, c_pb, c_pnb [5W] doubles | c_pj, c_src [5W] ints | mq [W] ints
+inline size_t rd_wide_scratch_bytes(int W)
+{
+    const size_t b = (size_t)2 * W * 48 + (size_t)3 * 5 * W * 8 + (size_t)2 * 5 * W * 4 + (size_t)W * 4;
+    return (b + 255) & ~(size_t)255;
+}
+
+// One beam-search launch needs (1 + W * rows) trie nodes per sequence -- 20 B each (child table + back pointer), 24 B above the lane
+// kernels' width (the slot map of decode_wide.hip) plus that kernel's scratch block per sequence -- for ALL its sequences at once: W x the
+// rows of the launch.  A pipeline group of 96 M rows at W = 100, or a few thousand windows at W = 1024, would ask for hundreds of GB and die
+// with RD_ERR_NOMEM in the middle of a job.  So every caller that builds a launch's node offsets cuts its sequences -- in launch
+// order -- into RUNS whose workspace fits the context's budget (at least one sequence per run); the runs go to rd_decode_dev one after the
+// other on the same stream and share the workspace.  Node offsets restart at 0 in every run.  Results do not depend on the cut.
+struct TrieRun {
+    int k0, k1;          // sequences [k0, k1) of the launch order
+    int64_t nodes;       // their trie nodes
+};
+template <typename LenOf>
+inline void rd_plan_trie_runs(const rd_ctx* ctx, int W, int k_begin, int k_end, LenOf len_of, int64_t* node_off, std::vector<TrieRun>& runs)
+{
+    const int64_t per_node = W > 64 ? 24 : 20;
+    const int64_t per_seq = W > 64 ? (int64_t)rd_wide_scratch_bytes(W) : 0;
+    int64_t nodes = 0, bytes = 0;
+    int k0 = k_begin;
+    for (int k = k_begin; k < k_end; k++) {
+        const int64_t nk = 1 + (int64_t)W * len_of(k), bk = nk * per_node + per_seq;
+        if (k > k0 && bytes + bk > ctx->trie_budget) {
+            runs.push_back({k0, k, nodes});
+            k0 = k;
+            nodes = bytes = 0;
+        }
+        node_off[k] = nodes;
+        nodes += nk;
+        bytes += bk;
+    }
+    if (k_end > k0) runs.push_back({k0, k_end, nodes});
+}
+
+// Hashed long contexts (rd_load_lm_hashed) exist in the lane kernels only: refused where the arguments are checked, not when a group
+// of batches is launched after earlier reads were written
+#define RD_REQUIRE_WIDTH_LM(ctx, W, use_lm)                                                                                     \
+    RD_REQUIRE(!((use_lm) && (ctx)->lm.loaded && (ctx)->lm.hashed && (W) > 64),                                                  \
+               "beam width %d with a hashed long-context RNA model (rd_load_lm_hashed): widths above 64 run on the general kernel, " \
+               "which has no hashed contexts", (W))

@@ -29,17 +29,10 @@ struct __attribute__((aligned(16))) WBeam {
 static_assert(sizeof(WBeam) == 48, "WBeam is three 16-B words");
 
 struct WideArgs {
-    char* scratch;          // per sequence: wide_scratch_bytes(W)
+    char* scratch;          // per sequence: rd_wide_scratch_bytes(W) (common.h)
     size_t stride;
     int* slot_of_node;      // per trie node (indexed like backptr): slot of the kept beam that carries it, -1 = not kept now
 };
-
-__host__ __device__ inline size_t wide_scratch_bytes(int W)
-{
-    // beams [2][W] | c_ptot, c_pb, c_pnb [5W] doubles | c_pj, c_src [5W] ints | mq [W] ints
-    size_t b = (size_t)2 * W * sizeof(WBeam) + (size_t)3 * 5 * W * 8 + (size_t)2 * 5 * W * 4 + (size_t)W * 4;
-    return (b + 255) & ~(size_t)255;
-}
 
 template <bool GX>
 __device__ __forceinline__ double lae_m(double x, double y, const uint64_t* gx_exp)
@@ -340,7 +333,7 @@ int rd_decode_wide_launch(rd_ctx* ctx, hipStream_t st, const void* args, int pty
     RD_REQUIRE(a.W <= RD_WIDE_MAX_W, "beam_width %d out of range [1,%d]", a.W, RD_WIDE_MAX_W);
     RD_REQUIRE(!(lm && a.hashed), "beam widths above %d do not combine with hashed long contexts (rd_load_lm_hashed)", 64);
     WideArgs w;
-    w.stride = wide_scratch_bytes(a.W);
+    w.stride = rd_wide_scratch_bytes(a.W);
     if (ctx->ws_wide.reserve(w.stride * (size_t)n_seq)) return RD_ERR_NOMEM;
     if (ctx->ws_wide_slot.reserve((size_t)total_nodes * sizeof(int))) return RD_ERR_NOMEM;
     w.scratch = (char*)ctx->ws_wide.p;

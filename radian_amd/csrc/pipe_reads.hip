@@ -467,18 +467,19 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
     char* hm = (char*)s.h_meta;
     int64_t *h1 = (int64_t*)hm, *h2 = (int64_t*)(hm + o_off2), *hn = (int64_t*)(hm + o_node), *hl = (int64_t*)(hm + o_lab);
     int32_t *hlen = (int32_t*)(hm + o_len), *hsp = (int32_t*)(hm + o_split);
-    int64_t nodes[2] = {0, 0};
     for (size_t k = 0; k < n; k++) {
         const RSeq& q = s.seqs[s.order[k]];
-        const int pass = (int)k < s.n64 ? 0 : 1;
         h1[k] = q.off1;
         h2[k] = q.off2;
         hsp[k] = q.split;
         hlen[k] = q.len;
         hl[k] = q.label_off;
-        hn[k] = nodes[pass];                       // the two passes run one after the other and share the trie workspace
-        nodes[pass] += 1 + (int64_t)s.W * q.len;
     }
+    // the two passes -- and, inside a pass, the runs a wide beam or a very large group is cut into (rd_plan_trie_runs) -- go one after the
+    // other on the decode stream and share the trie workspace
+    std::vector<TrieRun> runs[2];
+    rd_plan_trie_runs(ctx, s.W, 0, s.n64, [&](int k) { return (int64_t)hlen[k]; }, hn, runs[0]);
+    rd_plan_trie_runs(ctx, s.W, s.n64, (int)n, [&](int k) { return (int64_t)hlen[k]; }, hn, runs[1]);
     if (s.labels.reserve((size_t)s.labels_total + 16)) return RD_ERR_NOMEM;
     const size_t ho_len = align_up((size_t)s.labels_total + 16, 256);
     s.status_off = ho_len + align_up(n * 4, 256);
@@ -516,14 +517,14 @@ int slot_launch_decode(rd_ctx* ctx, ReadsPipe* p, RSlot& s)
             RD_HIP(hipEventRecord(d.e0, ds));
         }
     }
-    for (int pass = 0; pass < 2; pass++) {
-        const int k0 = pass == 0 ? 0 : s.n64, k1 = pass == 0 ? s.n64 : (int)n;
-        if (k1 == k0) continue;
+    for (int pass = 0; pass < 2; pass++)
+    for (const TrieRun& run : runs[pass]) {
+        const int k0 = run.k0, k1 = run.k1;
         const bool chunk = s.mode == 0;
         const void* src = pass == 0 ? s.mat.p : s.probs.p;
         const int ptype = pass == 0 ? 1 : (s.f16 ? 2 : 0);
         rc = rd_decode_dev(ctx, src, ptype, (const int64_t*)dm + k0, (const int32_t*)(dm + o_len) + k0, (const int64_t*)(dm + o_node) + k0,
-                           (const int64_t*)(dm + o_lab) + k0, k1 - k0, nodes[pass], s.W, s.use_lm, s.s_thr, s.r_thr, s.labels.as<uint8_t>(),
+                           (const int64_t*)(dm + o_lab) + k0, k1 - k0, run.nodes, s.W, s.use_lm, s.s_thr, s.r_thr, s.labels.as<uint8_t>(),
                            (int32_t*)(dm + o_llen) + k0, nullptr, ds, chunk ? (const int64_t*)(dm + o_off2) + k0 : nullptr,
                            chunk ? (const int32_t*)(dm + o_split) + k0 : nullptr, on_part ? RD_XCDS * s.part : 0,
                            // an oversubscribed partition (s.oversub): resident workgroups + a work queue, three waves per SIMD
@@ -684,6 +685,7 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
            int32_t* status)
 {
     int rc;
+    RD_REQUIRE_WIDTH_LM(ctx, W, use_lm && mode == 1);   // (refused at the submit, before anything of the job is queued -- not when the group is launched)
     RD_HIP(hipSetDevice(ctx->device));
     ReadsPipe* p = nullptr;
     if ((rc = rpipe_get(ctx, &p))) return rc;

@@ -315,3 +315,96 @@ def test_group_larger_than_its_decode_partition_delivers_the_blocking_calls_labe
     finally:
         dev.pipe_flush()
         dev.load_lm(None, 0)
+
+
+@pytest.mark.parametrize("W", [10, 25, 100])
+def test_beam_search_workspace_budget_cuts_launches_without_changing_results(dev, W):
+    """a launch's trie is W x ALL its rows (20-24 B per node, + decode_wide's scratch per sequence) -- a big group at a
+    wide beam asked for hundreds of GB and died with RD_ERR_NOMEM mid-job.  Launches beyond the context's budget now run as several
+    runs of sequences that share the workspace (rd_plan_trie_runs).  With a budget of 2 MB -- a handful of sequences per run -- every
+    route gives the labels the default (one run) gives: rd_decode_batch, the blocking raw calls, the chunk pipeline over resident windows and
+    the reads pipeline in both modes (global: float64 and float32 passes, LM on)."""
+    from radian_amd import synthetic
+    rng = np.random.default_rng(900 + W)
+    table = np.random.default_rng(1).dirichlet([0.3] * 4, size=4 ** 3)
+    dev.load_lm(table, 3)
+    step = 512
+    try:
+        reads = _ragged(rng, 14, hi=5000, special=(1, CHUNK - 1, CHUNK, 3000))
+        # probabilities of a few sequences for the plain decode entry point
+        good = [r for r in reads if len(r) >= 64]
+        windows, valid, _, _ = synthetic.reads_to_windows(good, CHUNK, step)
+        win = windows[:12]
+        probs = dev.forward(win)
+        mats = probs.reshape(-1, 5)
+        lens = np.asarray([CHUNK, 1000, 17, CHUNK, 1, 512, CHUNK, 3, 900, CHUNK, 64, 700][: win.shape[0]], dtype=np.int32)
+        off = np.arange(win.shape[0], dtype=np.int64) * CHUNK
+        d_win = dev.dev_alloc(windows.nbytes)
+        dev.h2d(d_win, windows)
+
+        def everything():
+            out = {}
+            out["batch"] = dev.decode_batch(mats, off, lens, W, with_scores=True)
+            out["batch_lm"] = dev.decode_batch(mats.astype(np.float64), off, lens, W, use_lm=True, s_threshold=0.2, r_threshold=0.9)
+            out["raw_global"] = dev.basecall_raw_global(reads, 4, CHUNK, step, W, True, 0.2, 0.9)
+            out["raw_chunk"] = dev.basecall_raw_chunk(reads, 4, CHUNK, step, W)
+            dev.pipe_flush()
+            dev.pipe_config(2)
+            t = [dev.pipe_submit_raw(mode, reads, 4, CHUNK, step, W, True, 0.2, 0.9) if mode == "global" else dev.pipe_submit_raw(mode, reads, 4, CHUNK, step, W)
+                 for mode in ("global", "chunk", "global")]
+            dev.pipe_flush()
+            out["pipe"] = [x.result() for x in t]
+            lab = np.zeros((windows.shape[0], CHUNK), dtype=np.uint8)
+            ln = np.full(windows.shape[0], -1, dtype=np.int32)
+            dev.pipe_submit(d_win, windows.shape[0], CHUNK, valid, W, lab, ln)
+            dev.pipe_flush()
+            out["pipe_windows"] = (lab.copy(), ln.copy())
+            return out
+
+        def same(a, b, path=""):
+            if isinstance(a, (list, tuple)):
+                assert type(a) is type(b) and len(a) == len(b), path
+                for i, (x, y) in enumerate(zip(a, b)):
+                    same(x, y, f"{path}[{i}]")
+            elif a is None:
+                assert b is None, path
+            else:
+                assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True), path
+
+        ref = everything()
+        dev.set_trie_budget(2 << 20)
+        try:
+            got = everything()
+        finally:
+            dev.set_trie_budget(0)
+        for key in ref:
+            same(ref[key], got[key], key)
+        ln = ref["pipe_windows"][1]
+        assert ln.min() >= 0 and ln.sum() > 0 and any(len(x) for x in ref["raw_global"][0] if x is not None)
+        dev.dev_free(d_win)
+    finally:
+        dev.load_lm(None, 0)
+        dev.pipe_config(4)
+
+
+def test_hashed_long_contexts_with_a_wide_beam_are_refused_at_the_submit(dev):
+    """hashed contexts exist in the lane kernels (W <= 64) only; the combination with a wider beam used to fail when the group was
+    LAUNCHED, after earlier reads had been written.  Now RD_ERR_ARG comes from the submit / the blocking call itself, and the pipeline
+    stays usable."""
+    from radian_amd import RadianHipError
+    rng = np.random.default_rng(5)
+    table = np.random.default_rng(1).dirichlet([0.3] * 4, size=4 ** 3)
+    reads = _ragged(rng, 4, lo=1200, hi=3000)
+    dev.load_lm_hashed(table, 3, 40)
+    try:
+        ok = dev.basecall_raw_global(reads, 4, CHUNK, 512, 25, True, 0.2, 0.9)
+        for call in (lambda: dev.pipe_submit_raw("global", reads, 4, CHUNK, 512, 100, True, 0.2, 0.9),
+                     lambda: dev.basecall_raw_global(reads, 4, CHUNK, 512, 65, True, 0.2, 0.9)):
+            with pytest.raises(RadianHipError, match="hashed long-context"):
+                call()
+        # without the LM a wide beam is fine on the same context, and the pipeline still works at a lane-kernel width
+        dev.pipe_submit_raw("global", reads, 4, CHUNK, 512, 100, False, 0.0, 0.0).result()
+        got = dev.pipe_submit_raw("global", reads, 4, CHUNK, 512, 25, True, 0.2, 0.9).result()
+        assert all(np.array_equal(a, b) for a, b in zip(got[0], ok[0]))
+    finally:
+        dev.load_lm(None, 0)
