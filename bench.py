@@ -329,6 +329,179 @@ def global_leg(device, batches_host, read_off, reads_per_batch, steps, W, table,
                              "next group's forwards; two_contexts_unpipelined = round 2's scheme (two contexts on two host threads)"}
 
 
+def files_leg_reads(file_index, reads_per_file, read_len, seed=70003):
+    """the reads of one input file of the N-rank leg: seeded by the file's index, so any process can regenerate any file"""
+    rng = np.random.default_rng([seed, file_index])
+    base = file_index * reads_per_file
+    return {f"{base + i:08d}-0000-4000-8000-{base + i:012d}": np.rint(rng.normal(500.0, 80.0, size=int(read_len))).astype(np.int16)
+            for i in range(reads_per_file)}
+
+
+def files_leg(rank, world, be_src, host_budget, rdv_dir, cli, device=0, files_per_rank=4, reads_per_file=4096, read_len=READ_LEN,
+              warm_reads=1536, timeout=60.0, backend_factory=None, comm_info=None, keep=None):
+    """secondary_e2e_fast5_to_fasta at N > 1 -- the whole job as `radian_amd.basecall ... --gpus N` runs it, inside the bench's ranks:
+    a memory-backed directory of multi-read fast5 shards -> per-node FileReadQueue (blocks of 256 reads, file by file) -> native reader ->
+    H2D -> mad_normalise -> streamed forward -> beam search -> labels -> strings (chunk mode: native stitch on the rank's host threads) ->
+    rank files -> StreamMerger in a process of its own (a child of rank 0 that never touches a GPU) -> reads-<n>.fasta, every rank on the
+    core slice hostbudget gave it.  That loop is what the ranks replace (radian/basecall.py:70-76,129-138) and what SURVEY 8e names as the
+    scaling limit; the headline's inputs are resident in HBM.  launch.run_rank / launch.merge_watch are the product's own halves.
+
+    Every rank calls this after the headline's timed region.  No RCCL call inside: the ranks meet through files in rdv_dir with a
+    deadline, a rank that fails says so in its "done" note, and whatever goes wrong comes back as {"skipped": reason} on rank 0 --
+    the headline line is never at stake.  Returns the leg's dict on rank 0, None elsewhere."""
+    import contextlib
+    import shutil
+    import subprocess
+    import tempfile
+    from radian_amd import basecall, dist, fast5, hostbudget, launch
+    t_enter = time.time()
+    rdv = dist.Rendezvous(os.path.join(rdv_dir, "files_leg"), rank, world, timeout=timeout)
+    root, bes, merger, result = None, [], None, None
+    mine = {"rank": rank, "error": None}
+    met = set()
+
+    def meet(phase, value="ok"):
+        """all ranks reach `phase`, or everyone learns at once that one of them cannot (no waiting for the deadline)"""
+        met.add(phase)
+        vals = rdv.gather(phase, value)
+        bad = [f"rank {r}: {v[7:]}" for r, v in enumerate(vals) if v.startswith("failed:")]
+        if bad:
+            raise RuntimeError("; ".join(bad))
+        return vals
+    try:
+        # ---- a directory every rank can see: rank 0 makes it, the others learn its name
+        if rank == 0:
+            base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+            root = tempfile.mkdtemp(prefix="radian_bench_nrank_", dir=base)
+            for d in ("in", "out", "scratch"):
+                os.mkdir(os.path.join(root, d))
+        root = meet("root", root or "-")[0]
+        n_files = files_per_rank * world
+        for k in range(files_per_rank):          # every rank writes its share of the input (written before any clock starts)
+            fi = rank + k * world
+            fast5.write_multi_fast5(os.path.join(root, "in", f"batch_{fi:04d}.fast5"), files_leg_reads(fi, reads_per_file, read_len))
+        # ---- this rank's device contexts, as the command line builds them, with the artefacts of the context that received the broadcast
+        args = basecall.build_parser().parse_args([os.path.join(root, "in"), os.path.join(root, "out")] + list(cli))
+        n_mine = len(host_budget["cpus"]) if (host_budget.get("bound") or host_budget.get("how") != "all") else max(1, len(host_budget["cpus"]) // max(1, world))
+        if args.stitch_workers is None and args.decode_type == "chunk":
+            args.stitch_workers = hostbudget.threads_for(n_mine, "chunk")["stitch_threads"]
+        make = backend_factory or (lambda: __import__("radian_amd").Backend(device))
+        for i in range(basecall.n_contexts(args)):
+            b = make()
+            bes.append(b)
+            basecall.apply_artifacts(args, b, None, clone_from=be_src)
+        args._lm_loaded = False
+        if warm_reads:
+            warm = [_MemRead(f"w{i}", r) for i, r in enumerate(list(files_leg_reads(10 ** 6 + rank, min(warm_reads, reads_per_file), read_len).values()))]
+            with open(os.devnull, "w") as dn, contextlib.redirect_stdout(dn):
+                basecall.run(args, bes, reads=iter(warm), writer=None, on_result=lambda *a: None)
+        meet("ready")
+        if rank == 0:
+            with open(os.path.join(root, "scratch", "files.json"), "w") as f:
+                json.dump(fast5.list_files(args.fast5_dir), f)
+            merger = subprocess.Popen([sys.executable, "-m", "radian_amd.launch", "--merge", os.path.join(root, "scratch"), str(world),
+                                       args.fasta_dir, str(4 * timeout)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT)
+        meet("go")
+        with open(os.path.join(root, "scratch", "files.json")) as f:
+            paths = json.load(f)
+        assert len(paths) == n_files, (len(paths), n_files)
+        sources = [fast5.Fast5Source(p) for p in paths]
+        stats = {}
+        mine["t0"] = time.time()
+        with open(os.devnull, "w") as dn, contextlib.redirect_stdout(dn):
+            launch.run_rank(args, bes[0], None, os.path.join(root, "scratch"), sources, rank, world, backends=bes, stats=stats)
+        mine["t1"] = time.time()
+        mine.update(reads=stats.get("reads", 0), samples=stats.get("samples", 0), cores=len(host_budget["cpus"]), cpus=host_budget["cpus"],
+                    cpu_split=host_budget.get("how"), cpu_bound=host_budget.get("bound"), numa_node=host_budget.get("numa_node"),
+                    stitch_threads=args.stitch_workers, device_contexts=len(bes))
+    except BaseException as e:   # noqa: BLE001 -- nothing of this leg may cost the headline
+        mine["error"] = f"{type(e).__name__}: {e}"
+        for phase in ("root", "ready", "go"):      # the ranks that wait for this one at a later meeting point learn it now
+            if phase not in met:
+                try:
+                    rdv.publish(phase, "failed:" + mine["error"][:300])
+                except OSError:
+                    pass
+        if root and root != "-" and os.path.isdir(os.path.join(root, "scratch")):
+            try:   # a rank that never got to its run still has to end its rank file, or the merger waits for it
+                p_rank = os.path.join(root, "scratch", f"rank{rank}.jsonl")
+                if not os.path.exists(p_rank):
+                    with open(p_rank, "w") as f:
+                        f.write(json.dumps({"end": True}) + "\n")
+            except OSError:
+                pass
+    finally:
+        for b in bes:
+            try:
+                b.close()
+            except Exception:
+                pass
+    try:
+        notes = [json.loads(x) for x in rdv.gather("done", json.dumps(mine))]
+    except Exception as e:
+        notes = None
+        mine["error"] = mine["error"] or f"{type(e).__name__}: {e}"
+    if rank == 0:
+        try:
+            merged = None
+            if merger is not None:
+                try:
+                    mo, me = merger.communicate(timeout=2 * timeout)
+                    if merger.returncode == 0:
+                        merged = json.loads(mo.decode().strip().splitlines()[-1])
+                    else:
+                        mine["error"] = mine["error"] or ("merger: " + me.decode(errors="replace").strip().splitlines()[-1][:300])
+                except subprocess.TimeoutExpired:
+                    merger.kill()
+                    merger.communicate()
+                    mine["error"] = mine["error"] or "merger: no end within its deadline"
+            errs = [f"rank {n['rank']}: {n['error']}" for n in (notes or []) if n.get("error")] + ([f"rank 0: {mine['error']}"] if mine["error"] and not notes else [])
+            if errs or notes is None or merged is None:
+                result = {"skipped": "; ".join(errs) or mine["error"] or "no result", "n_ranks": world}
+            else:
+                total_reads, total = sum(n["reads"] for n in notes), sum(n["samples"] for n in notes)
+                t0, t1 = min(n["t0"] for n in notes), max(n["t1"] for n in notes)
+                n_rec = n_base = 0
+                import hashlib
+                h = hashlib.sha256()
+                for fn in sorted(os.listdir(os.path.join(root, "out")), key=lambda x: int(x.split("-")[1].split(".")[0]) if x.startswith("reads-") else -1):
+                    with open(os.path.join(root, "out", fn), "rb") as f:
+                        data = f.read()
+                    h.update(data)
+                    n_rec += data.count(b">")
+                    n_base += len(data)
+                assert n_rec == total_reads == merged["records"] == n_files * reads_per_file, (n_rec, total_reads, merged["records"], n_files * reads_per_file)
+                result = {
+                    "value": total / (t1 - t0), "unit": "samples/s", "n_ranks": world, "reads": total_reads, "samples": total, "seconds": t1 - t0,
+                    "value_to_merged_fasta": total / (merged["t_done"] - t0), "seconds_to_merged_fasta": merged["t_done"] - t0,
+                    "records_written": n_rec, "fasta_sha256": h.hexdigest(), "fast5_files": n_files, "reads_per_file": reads_per_file, "cli": " ".join(cli),
+                    "file_order": [os.path.basename(p) for p in paths],      # the directory's own enumeration order, as the reference's rglob gives it (basecall.py:70)
+                    "per_rank": [{"rank": n["rank"], "reads": n["reads"], "samples": n["samples"], "seconds": n["t1"] - n["t0"],
+                                  "value": n["samples"] / max(1e-9, n["t1"] - n["t0"]), "cores": n["cores"], "cpus": n["cpus"], "cpu_split": n["cpu_split"],
+                                  "cpu_bound": n["cpu_bound"], "numa_node": n["numa_node"], "stitch_threads": n["stitch_threads"],
+                                  "device_contexts": n["device_contexts"]} for n in notes],
+                    "startup_comm": (comm_info or {}).get("startup_comm"), "rccl_nranks": (comm_info or {}).get("rccl_nranks"),
+                    "leg_seconds_incl_input_files_and_warmup": time.time() - t_enter,
+                    "path": "BASELINE configs[2] from a fast5 directory to FASTA files at N ranks: " + str(n_files) + " multi-read fast5 files (" + str(reads_per_file)
+                            + " reads each, written by the ranks before the clock starts, memory-backed) -> per-node FileReadQueue (blocks of 256 reads) -> native "
+                              "reader (csrc/fast5.hip) on each rank's read-ahead thread -> H2D -> on-device mad_normalise -> streamed forward -> beam search -> "
+                              "labels D2H -> native stitch on the rank's host threads -> rank files -> StreamMerger in a child process of rank 0 (no GPU; it shares "
+                              "rank 0's core slice) -> reads-<n>.fasta; value = samples / (last rank's end - first rank's start), value_to_merged_fasta = until the "
+                              "merged FASTA is closed and renamed into place; ranks synchronise through files, no collective inside the leg",
+                }
+                if keep:
+                    shutil.copytree(os.path.join(root, "out"), keep)
+        except BaseException as e:   # noqa: BLE001
+            result = {"skipped": f"{type(e).__name__}: {e}", "n_ranks": world}
+        finally:
+            if merger is not None and merger.poll() is None:
+                merger.kill()
+            if root and root != "-":
+                shutil.rmtree(root, ignore_errors=True)
+            shutil.rmtree(os.path.join(rdv_dir, "files_leg"), ignore_errors=True)
+    return result
+
+
 def self_launch(world, argv, worker_cmd=None):
     """--gpus N without a launcher: be the launcher.  Never creates a Backend, never loads the HIP library: the ranks are
     fresh child processes (radian_amd.launch.run_ranks: one failing rank stops the others, exit codes come back).  Rank 0's
@@ -382,6 +555,9 @@ def main():
     ap.add_argument("--conv-shape", type=int, default=0, choices=[0, 1],
                     help="fp32 conv workgroup shape: 0 = 128 x 256 tiles, two workgroups per CU (product); 1 = 256 x 256, one per CU (measurement)")
     ap.add_argument("--cpu-reads", type=int, default=0, help="reads in the CPU-baseline sample (0: sized to the usable core count)")
+    ap.add_argument("--nrank-files-per-rank", type=int, default=4,
+                    help="N > 1: multi-read fast5 files (4096 reads x 4096 samples each) per rank in the files -> FASTA leg through the multi-GPU "
+                         "route (secondary_e2e_fast5_to_fasta; ~3 s of basecalling per rank at the default); 0 = no such leg")
     ap.add_argument("--e2e-reads", type=int, default=32768,
                     help="reads of the raw end-to-end secondary leg (the other driver legs take a half or a sixteenth of it): jobs of a few "
                          "seconds each, so that the fill and drain of the beam-search groups are a few per cent of a leg, as in a real run")
@@ -395,7 +571,9 @@ def main():
     args.gpus = world
     # host budget before the first GPU call (radian_amd/hostbudget.py): each rank on its own slice of the usable cores, NUMA-local to its GPU
     from radian_amd import hostbudget
-    host_budget = hostbudget.apply(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    host_budget = hostbudget.apply(local_rank, local_world,
+                                   devices=[int(os.environ["RD_BENCH_DEVICE"])] * local_world if "RD_BENCH_DEVICE" in os.environ else None)
 
     from radian_amd import Backend, weights, synthetic
     from radian_amd.backend import RD_TIMER_CONV, RD_TIMER_DECODE, RD_TIMER_HEAD
@@ -739,6 +917,30 @@ def main():
                 except Exception as e:
                     print(f"[bench] {key} failed: {e}", file=sys.stderr)
         del table
+    if world > 1 and args.precision == "fp32" and not args.no_secondary and not args.windowed and args.nrank_files_per_rank > 0:
+        # The one leg of the N > 1 line: the job from a fast5 directory to FASTA files through the product's multi-GPU
+        # route, every rank on its own core slice -- the host feed SURVEY 8e names as the scaling limit.  Every rank takes part; the
+        # ranks meet through files (own launcher: its rendezvous directory; foreign launcher: a directory named after its pid).
+        note(f"rank {rank}: secondary_e2e_fast5_to_fasta at {world} ranks")
+        try:
+            from radian_amd import dist as _dist
+            leg_dir = os.environ.get("RD_BENCH_RDV") or (_dist.uid_path() + "_legs")
+            os.makedirs(leg_dir, exist_ok=True)
+            leg = files_leg(rank, world, be, host_budget, leg_dir,
+                            ["--decode-type", "chunk", "--step-size", str(STEP), "--chunk-len", str(CHUNK), "--beam-width", str(BEAM), "--rna-model", "None"],
+                            device=device, files_per_rank=args.nrank_files_per_rank, comm_info={"startup_comm": comm_kind, "rccl_nranks": rccl_nranks})
+            if rank == 0:
+                sec["secondary_e2e_fast5_to_fasta"] = leg
+                note(f"  {leg['value'] / 1e6:.2f} M samples/s over {world} ranks ({leg['seconds']:.2f} s; merged FASTA after {leg['seconds_to_merged_fasta']:.2f} s)"
+                     if leg and "value" in leg else f"  skipped: {leg}")
+                if "RD_BENCH_RDV" not in os.environ:
+                    try:
+                        os.rmdir(leg_dir)
+                    except OSError:
+                        pass
+        except BaseException as e:   # noqa: BLE001 -- never at the headline's cost
+            if rank == 0:
+                sec["secondary_e2e_fast5_to_fasta"] = {"skipped": f"{type(e).__name__}: {e}", "n_ranks": world}
     if stitch_pool is not None:
         stitch_pool.shutdown()
     halo = 252

@@ -308,13 +308,14 @@ def _read_ahead(pairs, max_reads=8192, max_samples=48 << 20, block=128):
         t.join(timeout=30.0)
 
 
-def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue=None, sources=None, on_result=None):
+def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue=None, sources=None, on_result=None, stats=None):
     """The driver loop (basecall.py:69-141) over `reads` (default: every read under args.fast5_dir), or over file-level
     `sources` (fast5.Fast5Source per file: the multi-GPU launcher's form).
     shard=(rank, world): this process handles reads whose index % world == rank -- or, with a queue shared by the ranks
     of the node (dist.WorkQueue over read indices / dist.FileReadQueue over files then reads), the blocks it claims --
     and returns [(key, read_id, sequence)] when neither a writer nor on_result takes the records (an empty list otherwise: a
     consumed record is not kept); on_result(key, read_id, sequence), if given, receives each result as it is finished (in order).
+    stats: a dict that receives what this process took on -- {"reads", "samples"} (per-rank rates of a multi-GPU job).
     `be` is one Backend or a list of Backends on the same GPU (independent rd_ctx / HIP streams): batches go to them
     round robin on one thread each, so the MFMA-bound forward of one batch overlaps the latency-bound beam search of
     the previous one.  Reading/batching (HDF5 through ctypes), the device calls and the host work on the results
@@ -462,6 +463,9 @@ def run(args, be, reads=None, writer=None, shard=(0, 1), stitch_pool=None, queue
     try:
         for idx, read_id, raw in _read_ahead(_owned_reads(args, reads, shard, queue, sources)):
             n = raw.shape[0]
+            if stats is not None:
+                stats["reads"] = stats.get("reads", 0) + 1
+                stats["samples"] = stats.get("samples", 0) + int(n)
             if n == 0:
                 flush()                  # keep the reference's message order
                 drain()

@@ -122,7 +122,12 @@ def plan(local_rank, local_world, usable=None, gpu_nodes="auto", devices=None, s
     if not gpu_nodes:
         return even
     if devices is None:
-        devices = [r % len(gpu_nodes) for r in range(local_world)]
+        # A visible list shorter than the local world means the launcher narrowed every process to its own device(s)
+        # (HIP_VISIBLE_DEVICES=<r> per rank): this process cannot see which GPU its peers use, every rank would count all the others as
+        # neighbours on ITS node and take 1 / local_world of that node's cores -- on a two-socket box half the cores idle.  Even split.
+        if len(gpu_nodes) < local_world:
+            return even
+        devices = [r for r in range(local_world)]
     nodes = [gpu_nodes[d] if 0 <= d < len(gpu_nodes) else -1 for d in devices]
     if any(n < 0 for n in nodes):
         return even
@@ -146,15 +151,35 @@ def threads_for(n_cores, decode_type="global"):
             "total": 4 + (max(1, min(16, n - 2)) if decode_type == "chunk" else 0)}
 
 
+def _bind_all_threads(cpus):
+    """sched_setaffinity(0, ...) binds the CALLING thread only; threads that exist already (a BLAS / OpenMP pool started at `import numpy`
+    under a launcher that did not cap it) keep the node-wide mask.  Bind every thread of the process."""
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = [0]
+    ok = True
+    for t in tids or [0]:
+        try:
+            os.sched_setaffinity(t, cpus)
+        except OSError:
+            ok = ok and t != 0 and t != os.getpid()     # (a helper thread that ended meanwhile is no failure)
+    return ok
+
+
 def apply(local_rank, local_world, mode="auto", devices=None):
-    """Bind this process to its slice (mode 'auto'; 'none': leave it) and return the plan with its thread counts.  Call before the
-    first GPU call and before any thread is started."""
+    """Bind this process -- every thread it has so far; later ones inherit -- to its slice (mode 'auto'; 'none': leave it) and return the plan
+    with its thread counts.  Call before the first GPU call.  devices: the HIP device of every local rank when it is not rank r -> device r
+    (an override such as RD_CLI_DEVICE / RD_BENCH_DEVICE that puts several ranks on one GPU)."""
     mode = os.environ.get("RADIAN_CPU_AFFINITY", mode)
+    # (BLAS pools: nothing in a rank calls BLAS; a pool that starts later must not be sized by the node)
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    os.environ.setdefault("MKL_NUM_THREADS", "1")
     p = plan(local_rank, local_world, devices=devices)
     if mode != "none" and local_world > 1 and p["cpus"] and hasattr(os, "sched_setaffinity"):
         try:
             os.sched_setaffinity(0, p["cpus"])
-            p["bound"] = True
+            p["bound"] = _bind_all_threads(p["cpus"])
         except OSError:
             p["bound"] = False
     else:

@@ -163,6 +163,26 @@ def merge_to_fasta(scratch, world, fasta_dir):
     return StreamMerger(scratch, world, fasta_dir).finish()
 
 
+def merge_watch(scratch, world, fasta_dir, timeout=600.0, poll=0.02):
+    """The merging half of run_multi_gpu for a process that did not start the ranks itself (bench.py's N-rank files -> FASTA leg: the ranks
+    are the launcher's, the merger is a child of rank 0 that never touches a GPU): merge while the ranks write, until every rank file
+    carries its end mark; a rank that never ends makes this raise TimeoutError after `timeout` s with nothing left behind.
+    -> {"records", "t_done"}"""
+    m = StreamMerger(scratch, world, fasta_dir)
+    t0 = time.time()
+    try:
+        while not all(m.ended):
+            m.poll()
+            if time.time() - t0 > timeout:
+                raise TimeoutError(f"merge_watch: ranks {[r for r in range(world) if not m.ended[r]]} wrote no end mark within {timeout:.0f} s")
+            time.sleep(poll)
+    except BaseException:
+        m.abort()
+        raise
+    n = m.finish()
+    return {"records": n, "t_done": time.time()}
+
+
 def wait_all(procs, poll=0.05, on_poll=None):
     """Wait for every worker; as soon as one exits non-zero, stop the others (they may be blocked in a collective that
     will never complete) and return the exit codes.  on_poll() runs once per poll interval while workers are alive."""
@@ -280,20 +300,24 @@ class _RankFile:
             self.f.close()
 
 
-def run_rank(args, be, comm, scratch, sources, rank, world, stitch_pool=None, backends=None):
+def run_rank(args, be, comm, scratch, sources, rank, world, stitch_pool=None, backends=None, stats=None):
     """One rank's share of the job, after the artefacts are on its device: claim work, basecall on `backends` (the device
-    contexts of this rank's GPU; default: the one that received the broadcast), write rank{r}.jsonl as it goes, barrier."""
+    contexts of this rank's GPU; default: the one that received the broadcast), write rank{r}.jsonl as it goes, barrier
+    (comm None: no barrier -- the caller synchronises its ranks by other means).  stats: see basecall.run."""
     from .basecall import run
     from .dist import FileReadQueue
     out = _RankFile(os.path.join(scratch, f"rank{rank}.jsonl"))
     queue = None
     if args.queue_block > 0:
         queue = FileReadQueue(os.path.join(scratch, "queue"), args.queue_block, on_claim=out.claim)
-    run(args, backends or be, writer=None, shard=(rank, world), stitch_pool=stitch_pool, queue=queue, sources=sources, on_result=out.emit)
-    out.end()
-    if queue is not None:
-        queue.close()
-    comm.barrier()
+    try:
+        run(args, backends or be, writer=None, shard=(rank, world), stitch_pool=stitch_pool, queue=queue, sources=sources, on_result=out.emit, stats=stats)
+    finally:
+        out.end()      # (a rank that fails still says that it is done: the merger must not wait for it)
+        if queue is not None:
+            queue.close()
+    if comm is not None:
+        comm.barrier()
     return queue
 
 
@@ -303,7 +327,9 @@ def rank_budget(args, local_rank, local_world):
     the slice, never from the node: eight ranks on 64 cores run 8 x 6 stitch threads, not 8 x 16.  Fills args.stitch_workers when the
     user left it open.  -> the plan (cpus, how, bound, numa_node, cores_for_threads)."""
     from . import hostbudget
-    budget = hostbudget.apply(local_rank, local_world, getattr(args, "cpu_affinity", "auto"))
+    # (RD_CLI_DEVICE puts every local rank on ONE device -- a rehearsal on a 1-GPU box: the ranks then share that GPU's NUMA node)
+    devices = [int(os.environ["RD_CLI_DEVICE"])] * local_world if "RD_CLI_DEVICE" in os.environ else None
+    budget = hostbudget.apply(local_rank, local_world, getattr(args, "cpu_affinity", "auto"), devices=devices)
     n_mine = len(budget["cpus"]) if (budget["bound"] or budget["how"] != "all") else max(1, len(budget["cpus"]) // max(1, local_world))
     budget["cores_for_threads"] = n_mine
     if args.stitch_workers is None and args.decode_type == "chunk":
@@ -360,5 +386,7 @@ def worker(scratch, argv):
 if __name__ == "__main__":
     if len(sys.argv) >= 4 and sys.argv[1] == "--worker":
         worker(sys.argv[2], sys.argv[4:])
+    elif len(sys.argv) >= 6 and sys.argv[1] == "--merge":     # --merge scratch world fasta_dir timeout: merge_watch as a process of its own
+        print(json.dumps(merge_watch(sys.argv[2], int(sys.argv[3]), sys.argv[4], float(sys.argv[5]))))
     else:
         raise SystemExit("internal entry point; use python -m radian_amd.basecall ... --gpus N")

@@ -297,6 +297,62 @@ def test_bench_self_launch_with_stub_ranks(tmp_path, capfd):
     assert set(glob.glob(os.path.join(tempfile.gettempdir(), "radian_bench_*"))) == before
 
 
+def test_bench_nrank_files_leg_with_stub_ranks(tmp_path, capfd, oracle):
+    """the N > 1 bench line carries a files -> FASTA leg through the multi-GPU route (FileReadQueue, native reader, per-rank
+    core slice, rank files, StreamMerger in a process of its own).  Three stub ranks (device calls by the test double): every rank's share,
+    rate and cores are reported, the merged FASTA holds every read once, in input order, and equals a single-process run of the same files;
+    a rank that fails inside the leg costs the leg ({"skipped": ...}), never the line."""
+    import hashlib
+    sys.path.insert(0, ROOT)
+    import bench
+    from radian_amd import basecall, fast5, weights
+    from _oracle_backend import OracleBackend
+    stub = os.path.join(ROOT, "tests", "_bench_files_leg_rank.py")
+    keep = str(tmp_path / "merged")
+    rc = bench.self_launch(3, [], worker_cmd=[sys.executable, stub, "ok", keep])
+    out = capfd.readouterr().out.strip().splitlines()
+    assert rc == 0 and len(out) == 1, out
+    leg = json.loads(out[0])["secondary_e2e_fast5_to_fasta"]
+    assert "skipped" not in leg, leg
+    assert leg["n_ranks"] == 3 and leg["reads"] == 120 and leg["records_written"] == 120 and leg["samples"] == 120 * 500
+    assert leg["value"] > 0 and leg["value_to_merged_fasta"] > 0 and leg["seconds_to_merged_fasta"] >= leg["seconds"] * 0.5
+    pr = leg["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1, 2] and sum(p["reads"] for p in pr) == 120 and all(p["cores"] >= 1 and p["value"] > 0 for p in pr)
+    if len(os.sched_getaffinity(0)) >= 3:
+        assert all(p["cpu_bound"] for p in pr) and not (set(pr[0]["cpus"]) & set(pr[1]["cpus"])) and not (set(pr[1]["cpus"]) & set(pr[2]["cpus"]))
+    assert leg["rccl_nranks"] == 3 and leg["startup_comm"] == "stub"
+    # the merged FASTA == one process over the same six files
+    in_dir, ref_dir = tmp_path / "in", tmp_path / "ref"
+    in_dir.mkdir()
+    ref_dir.mkdir()
+    for fi in range(6):
+        fast5.write_multi_fast5(str(in_dir / f"batch_{fi:04d}.fast5"), bench.files_leg_reads(fi, 20, 500))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _bench_files_leg_rank as stubmod
+    args = basecall.build_parser().parse_args([str(in_dir), str(ref_dir)] + stubmod.CLI)
+    args._lm_loaded = False
+    be = OracleBackend()
+    be.load_weights(weights.synthetic_weights(seed=5, dilations=(1, 2)), (1, 2))
+    w = basecall.FastaWriter(str(ref_dir))
+    import contextlib
+    assert sorted(leg["file_order"]) == [f"batch_{fi:04d}.fast5" for fi in range(6)]
+    with open(os.devnull, "w") as dn, contextlib.redirect_stdout(dn):     # (the files in the order the leg's directory enumerated them: rglob order is the filesystem's)
+        basecall.run(args, be, writer=w, sources=[fast5.Fast5Source(str(in_dir / name)) for name in leg["file_order"]])
+    w.close()
+    assert open(os.path.join(keep, "reads-0.fasta")).read() == open(ref_dir / "reads-0.fasta").read()
+    assert leg["fasta_sha256"] == hashlib.sha256(open(ref_dir / "reads-0.fasta", "rb").read()).hexdigest()
+    ids = [ln[1:].strip() for ln in open(os.path.join(keep, "reads-0.fasta")) if ln.startswith(">")]
+    assert ids == [rid for name in leg["file_order"] for rid in sorted(bench.files_leg_reads(int(name[6:10]), 20, 500))]
+    # a rank that fails inside the leg: the line still comes, the leg says why, nothing is left in /dev/shm
+    import glob
+    rc = bench.self_launch(3, [], worker_cmd=[sys.executable, stub, "fail1", str(tmp_path / "none")])
+    out = capfd.readouterr().out.strip().splitlines()
+    assert rc == 0 and len(out) == 1, out
+    line = json.loads(out[0])
+    assert line["value"] == 1.0 and "rank 1" in line["secondary_e2e_fast5_to_fasta"]["skipped"]
+    assert not glob.glob("/dev/shm/radian_bench_nrank_*") and not os.path.exists(str(tmp_path / "none"))
+
+
 def test_bench_parent_never_loads_the_hip_library(tmp_path):
     """The launcher process of `bench.py --gpus N` must not touch a GPU: it runs to completion (here: to the failure of its
     ranks, which have no GPU) without libradian_hip.so ever being mapped -- RADIAN_HIP_LIB points at a file that is not a

@@ -745,6 +745,14 @@ def test_host_budget_placement_rule(tmp_path):
     assert hb.plan(0, 1, usable=range(8))["how"] == "all"
     here = [hb.plan(r, 2) for r in range(2)]
     assert not set(here[0]["cpus"]) & set(here[1]["cpus"]) and here[0]["cpus"] and here[1]["cpus"]
+    # a launcher that narrows every process to its own device (HIP_VISIBLE_DEVICES=<r> per rank) leaves ONE visible GPU and
+    # eight local ranks -- nobody can see the peers' GPUs: the even split, not 1/8 of this GPU's node for everyone
+    plans = [hb.plan(r, 8, usable=range(64), gpu_nodes=[0 if r < 4 else 1], sysfs=str(sysfs)) for r in range(8)]
+    assert all(p["how"] == "even" and len(p["cpus"]) == 8 for p in plans) and sorted(c for p in plans for c in p["cpus"]) == list(range(64))
+    # ... while several ranks put on ONE device by an explicit list (RD_CLI_DEVICE / RD_BENCH_DEVICE rehearsals) share that GPU's node
+    plans = [hb.plan(r, 4, usable=range(64), gpu_nodes=[0, 0, 0, 0, 1, 1, 1, 1], devices=[5, 5, 5, 5], sysfs=str(sysfs)) for r in range(4)]
+    assert all(p["how"] == "numa" and p["numa_node"] == 1 and len(p["cpus"]) == 8 for p in plans)
+    assert sorted(c for p in plans for c in p["cpus"]) == list(range(32, 64))
     # HIP_VISIBLE_DEVICES re-orders the devices a rank sees
     import os
     old = os.environ.get("HIP_VISIBLE_DEVICES")
@@ -776,6 +784,15 @@ def test_apply_binds_a_child_rank_to_its_slice():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert not d["bound"] and d["after"] == d["before"]
+    # threads that exist BEFORE apply (a BLAS / OpenMP pool started at import) are bound too, not only the calling thread
+    code = ("import os, json, threading; from radian_amd import hostbudget as hb; ev = threading.Event(); "
+            "ts = [threading.Thread(target=ev.wait) for _ in range(3)]; [t.start() for t in ts]; p = hb.apply(0, 2); "
+            "masks = [sorted(os.sched_getaffinity(int(t))) for t in os.listdir('/proc/self/task')]; ev.set(); [t.join() for t in ts]; "
+            "print(json.dumps({'plan': p['cpus'], 'masks': masks, 'blas': os.environ.get('OPENBLAS_NUM_THREADS')}))")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert len(d["masks"]) >= 4 and all(m == d["plan"] for m in d["masks"]) and d["blas"] == "1"
 
 
 def _write_single_read_fast5(path, read_id, sig, group="Read_17", id_kind="nullterm", filters=()):
