@@ -69,6 +69,10 @@ int rd_pipe_stats(rd_ctx* ctx, int64_t* out, int n);
 #define RD_TIMER_IN 3     /* block-0 first conv (C_in = 1) */
 int rd_timer_enable(rd_ctx* ctx, int which, int max_launches); /* 0 disables */
 int rd_timer_read(rd_ctx* ctx, int which, double* total_ms, int* launches, double* flops, double* bytes);
+/* The recorded launches one by one (up to cap): duration, algorithmic FLOPs, and for RD_TIMER_CONV the epilogue variant -- 0 relu (a
+ * block's first conv), 1 res_ident (second conv, identity residual), 2 res_match (block 0's second conv: 1x1 match conv, and with
+ * rd_set_conv_fuse 1 the block's first conv inside) -- so that a roofline fraction can be stated per variant and launch-weighted. */
+int rd_timer_read_launches(rd_ctx* ctx, int which, int cap, float* ms_out, double* flops_out, int32_t* tag_out, int* n_out);
 
 #ifdef __cplusplus
 }

@@ -99,6 +99,7 @@ DIAG_SIGNATURES = {
     "rd_set_trie_budget": (c_i, [c_vp, c_i64]),
     "rd_timer_enable": (c_i, [c_vp, c_i, c_i]),
     "rd_timer_read": (c_i, [c_vp, c_i, c_dp, ctypes.POINTER(c_i), c_dp, c_dp]),
+    "rd_timer_read_launches": (c_i, [c_vp, c_i, c_i, c_vp, c_vp, c_vp, ctypes.POINTER(c_i)]),
 }
 
 _lib = None

@@ -550,6 +550,15 @@ class Backend:
         self._check(self._L.rd_timer_read(self._h, which, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by)))
         return {"total_ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
 
+    def timer_read_launches(self, which, cap=4096):
+        """the recorded launches one by one (rd_timer_read_launches): (ms float32[n], flops float64[n], tag int32[n])"""
+        ms = np.zeros(cap, dtype=np.float32)
+        fl = np.zeros(cap, dtype=np.float64)
+        tag = np.zeros(cap, dtype=np.int32)
+        n = ctypes.c_int()
+        self._check(self._L.rd_timer_read_launches(self._h, which, int(cap), _p(ms), _p(fl), _p(tag), ctypes.byref(n)))
+        return ms[: n.value], fl[: n.value], tag[: n.value]
+
     # ------------------------------------------------------------------ multi-GPU start-up
     def rccl_probe(self):
         """librccl loads in this process (no communicator, no bootstrap thread)."""

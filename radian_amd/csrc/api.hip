@@ -136,6 +136,8 @@ static void timer_free(KernelTimer& t)
     for (auto ev : t.stops) (void)hipEventDestroy(ev);
     t.starts.clear();
     t.stops.clear();
+    t.each_flops.clear();
+    t.each_tag.clear();
     t.used = 0;
     t.enabled = false;
 }
@@ -1768,6 +1770,24 @@ extern "C" int rd_timer_read(rd_ctx* ctx, int which, double* total_ms, int* laun
     if (launches) *launches = (int)t->used;
     if (flops) *flops = t->flops;
     if (bytes) *bytes = t->bytes;
+    return RD_OK;
+}
+
+extern "C" int rd_timer_read_launches(rd_ctx* ctx, int which, int cap, float* ms_out, double* flops_out, int32_t* tag_out, int* n_out)
+{
+    RD_REQUIRE(ctx && n_out, "rd_timer_read_launches: null argument");
+    KernelTimer* t = timer_of(ctx, which);
+    RD_REQUIRE(t, "rd_timer_read_launches: unknown timer %d", which);
+    RD_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t n = std::min(t->used, (size_t)std::max(0, cap));
+    for (size_t i = 0; i < n; i++) {
+        float f = 0.f;
+        RD_HIP(hipEventElapsedTime(&f, t->starts[i], t->stops[i]));
+        if (ms_out) ms_out[i] = f;
+        if (flops_out) flops_out[i] = i < t->each_flops.size() ? t->each_flops[i] : 0.0;
+        if (tag_out) tag_out[i] = i < t->each_tag.size() ? t->each_tag[i] : 0;
+    }
+    *n_out = (int)n;
     return RD_OK;
 }
 

@@ -123,6 +123,8 @@ struct KernelTimer {
     size_t used = 0;
     double flops = 0.0;  // algorithmic flops accumulated over recorded launches
     double bytes = 0.0;
+    std::vector<double> each_flops;   // per recorded launch (rd_timer_read_launches: the roofline by kernel variant)
+    std::vector<int> each_tag;        // conv: 0 relu (a block's first conv), 1 res_ident, 2 res_match (block 0's second conv); others 0
 };
 
 // One forward "lane": a stream with its own three activation tensors.  Lane 0 is the context's main stream; the

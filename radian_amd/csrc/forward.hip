@@ -1373,13 +1373,15 @@ int timer_begin(hipStream_t st, KernelTimer& tm)
     if (tm.enabled && tm.used < tm.starts.size()) RD_HIP(hipEventRecord(tm.starts[tm.used], st));
     return RD_OK;
 }
-int timer_end(hipStream_t st, KernelTimer& tm, double flops, double bytes)
+int timer_end(hipStream_t st, KernelTimer& tm, double flops, double bytes, int tag = 0)
 {
     if (tm.enabled && tm.used < tm.starts.size()) {
         RD_HIP(hipEventRecord(tm.stops[tm.used], st));
         tm.used++;
         tm.flops += flops;
         tm.bytes += bytes;
+        tm.each_flops.push_back(flops);
+        tm.each_tag.push_back(tag);
     }
     return RD_OK;
 }
@@ -1467,7 +1469,7 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
         else if (b == 0) hipLaunchKernelGGL((tcn_gemm_bf3_kernel<4, 3, EPI_RES_MATCH>), dim3(n / 2), dim3(512), 0, st, h);
         else hipLaunchKernelGGL((tcn_gemm_bf3_kernel<4, 3, EPI_RES_IDENT>), dim3(n / 2), dim3(512), 0, st, h);
         RD_HIP(hipGetLastError());
-        return timer_end(st, ctx->timer_conv, 2.0 * rows * RD_C * RD_C * RD_K, (kind == 2 && b > 0 ? 3.0 : 2.0) * rows * RD_C * 6.0);
+        return timer_end(st, ctx->timer_conv, 2.0 * rows * RD_C * RD_C * RD_K, (kind == 2 && b > 0 ? 3.0 : 2.0) * rows * RD_C * 6.0, kind == 1 ? 0 : b == 0 ? 2 : 1);
     }
     if (kind == 0) {
         if ((rc = timer_begin(st, ctx->timer_in))) return rc;
@@ -1569,7 +1571,7 @@ int launch_layer(rd_ctx* ctx, hipStream_t st, int b, int kind /*0 in, 1 conv0, 2
         else hipLaunchKernelGGL((tcn_gemm_kernel<4, 3, EPI_RES_IDENT>), dim3(n), dim3(256), 0, st, a);
     }
     RD_HIP(hipGetLastError());
-    return timer_end(st, ctx->timer_conv, 2.0 * rows * RD_C * RD_C * RD_K, (kind == 2 && b > 0 ? 3.0 : 2.0) * rows * RD_C * 4.0);
+    return timer_end(st, ctx->timer_conv, 2.0 * rows * RD_C * RD_C * RD_K, (kind == 2 && b > 0 ? 3.0 : 2.0) * rows * RD_C * 4.0, kind == 1 ? 0 : b == 0 ? 2 : 1);
 }
 
 }  // namespace

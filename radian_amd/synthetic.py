@@ -25,3 +25,16 @@ def reads_to_windows(reads, chunk_len=1024, step=512, clip=4):
         pads.append(pad)
     return (np.concatenate(wins, axis=0), np.concatenate(valid), np.asarray(offs, dtype=np.int32),
             np.asarray(pads, dtype=np.int32))
+
+
+def peaky_probs(n_windows, chunk_len=1024, seed=0, gain=4.0, blank_bias=2.0):
+    """SURVEY.md section 8d's decode-only benchmark rows: softmax(gain * N(0,1) + blank_bias on the blank class), float32
+    [n_windows, chunk_len, 5] -- peaked rows with the blank favoured, as a trained CTC model emits them (a base every few rows), unlike
+    the random-weight model's saturated rows (~5 bases per window) or the soft head's (~200)."""
+    rng = np.random.default_rng(seed)
+    z = rng.standard_normal((n_windows, chunk_len, 5), dtype=np.float32) * np.float32(gain)
+    z[..., 4] += np.float32(blank_bias)
+    z -= z.max(axis=-1, keepdims=True)
+    np.exp(z, out=z)
+    z /= z.sum(axis=-1, keepdims=True)
+    return z

@@ -40,7 +40,7 @@ def test_diag_header_holds_the_measurement_entry_points_and_the_product_header_n
     from radian_amd import _lib
     diag = declared_symbols("radian_hip_diag.h")
     prod = declared_symbols()
-    assert sorted(_lib.DIAG_SIGNATURES) == diag and len(diag) == 9
+    assert sorted(_lib.DIAG_SIGNATURES) == diag and len(diag) == 10
     assert not set(diag) & set(prod)
     for n in diag:
         assert hasattr(lib, n), f"libradian_hip.so does not export {n}"
@@ -50,7 +50,7 @@ def test_diag_header_holds_the_measurement_entry_points_and_the_product_header_n
     exported = sorted({ln.split()[-1] for ln in out.splitlines() if re.search(r"\s[TW]\s+rd_[a-z0-9_]+$", ln)})
     assert exported == sorted(prod + diag), sorted(set(exported) ^ set(prod + diag))
     # the command line's modules never reach a diagnostic wrapper of Backend
-    wrappers = ("set_conv_shape", "set_conv_fuse", "split3", "set_decode_form", "pipe_policy_read", "pipe_stats", "timer_enable", "timer_read", "set_trie_budget")
+    wrappers = ("set_conv_shape", "set_conv_fuse", "split3", "set_decode_form", "pipe_policy_read", "pipe_stats", "timer_enable", "timer_read", "timer_read_launches", "set_trie_budget")
     pkg = os.path.join(ROOT, "radian_amd")
     for f in sorted(os.listdir(pkg)):
         if f.endswith(".py") and f not in ("backend.py", "_lib.py"):

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Workload of tools/prof_decode.sh: a few beam-search launches over n windows x 1024 rows (bench weights or the soft head)."""
+"""Workload of tools/prof_decode.sh: a few beam-search launches over n windows x 1024 rows (soft = 0: bench weights, 1: the soft head,
+2: SURVEY 8d's peaky rows -- softmax(4 N(0,1), blank + 2), no model involved: bench.py's secondary_decode_only_peaky)."""
 import os, sys
 import numpy as np
 R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,7 +24,11 @@ win = np.ascontiguousarray(win, dtype=np.float32)
 d_w = be.dev_alloc(win.nbytes)
 be.h2d(d_w, win)
 d_p = be.dev_alloc(n * T * 5 * 4)
-be.forward_resident(d_w, n, T, d_p)
+if soft == 2:
+    be.h2d(d_p, synthetic.peaky_probs(n, T, seed=7))
+    valid = np.full(n, T, dtype=np.int32)
+else:
+    be.forward_resident(d_w, n, T, d_p)
 valid = np.ascontiguousarray(valid, dtype=np.int32)
 labels = np.zeros((n, T), np.uint8)
 lens = np.zeros(n, np.int32)
