@@ -329,6 +329,19 @@ def global_leg(device, batches_host, read_off, reads_per_batch, steps, W, table,
                              "next group's forwards; two_contexts_unpipelined = round 2's scheme (two contexts on two host threads)"}
 
 
+def cpulist(cpus):
+    """[0, 1, 2, 3, 8, 10, 11] -> '0-3,8,10-11' (the kernel's cpulist form: a 64-core slice is one short string in the JSON line)"""
+    out, cpus = [], sorted(int(c) for c in cpus)
+    i = 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
+
+
 def files_leg_reads(file_index, reads_per_file, read_len, seed=70003):
     """the reads of one input file of the N-rank leg: seeded by the file's index, so any process can regenerate any file"""
     rng = np.random.default_rng([seed, file_index])
@@ -411,7 +424,7 @@ def files_leg(rank, world, be_src, host_budget, rdv_dir, cli, device=0, files_pe
         with open(os.devnull, "w") as dn, contextlib.redirect_stdout(dn):
             launch.run_rank(args, bes[0], None, os.path.join(root, "scratch"), sources, rank, world, backends=bes, stats=stats)
         mine["t1"] = time.time()
-        mine.update(reads=stats.get("reads", 0), samples=stats.get("samples", 0), cores=len(host_budget["cpus"]), cpus=host_budget["cpus"],
+        mine.update(reads=stats.get("reads", 0), samples=stats.get("samples", 0), cores=len(host_budget["cpus"]), cpus=cpulist(host_budget["cpus"]),
                     cpu_split=host_budget.get("how"), cpu_bound=host_budget.get("bound"), numa_node=host_budget.get("numa_node"),
                     stitch_threads=args.stitch_workers, device_contexts=len(bes))
     except BaseException as e:   # noqa: BLE001 -- nothing of this leg may cost the headline
@@ -916,9 +929,9 @@ def main():
                     instr = {}
             leg = {"rows": "softmax(4 * N(0,1) + 2 on the blank), float32, 4096 windows x 1024 rows resident in HBM (synthetic.peaky_probs seed 7)",
                    "arithmetic": args.decode_math, "by_width": {},
-                   "issue_frac_is": "instructions issued per time step (SQ_INSTS_VALU + SALU + LDS + the rest = SQ_ACTIVE_INST_ANY x 4 / 4, offline rocprofv3 --pmc pass of "
-                                    "this leg: profiles/decode_peaky_instr.json) x time steps/s / (1024 SIMDs x 2.4 GHz: one instruction per SIMD per cycle); "
-                                    "null when that file is absent"}
+                   "valu_issue_frac_is": "vector-ALU issue cycles / SIMD cycles of the chip: VALU instructions per time step (offline rocprofv3 --pmc pass of this leg, "
+                                         "profiles/decode_peaky_instr.json) x 4 cycles (a wave64 instruction on a 16-lane SIMD) x time steps/s / (1024 SIMDs x 2.4 GHz); "
+                                         "the rest of a step is LDS round trips, scalar work and waits inside one wave's serial chain; null when that file is absent"}
             for Wd in (6, 10, 25):
                 be.decode_resident(d_pk, n_dw, CHUNK, v_pk, Wd, lab_pk, len_pk)
                 n_l = 3
@@ -929,10 +942,10 @@ def main():
                 tdp = be.timer_read(RD_TIMER_DECODE)
                 be.timer_enable(RD_TIMER_DECODE, 0)
                 sps = n_dw * CHUNK * tdp["launches"] / (tdp["total_ms"] * 1e-3)
-                ips = (instr.get("instructions_per_step") or {}).get(str(Wd))
+                per = {k: (instr.get(k + "_per_step") or {}).get(str(Wd)) for k in ("valu", "salu", "lds")}
                 leg["by_width"][str(Wd)] = {"timesteps_per_s": sps, "ms_per_launch": tdp["total_ms"] / max(1, tdp["launches"]),
-                                            "mean_bases_per_window": float(len_pk.mean()),
-                                            "instructions_per_step": ips, "issue_frac": (sps * ips / (1024 * 2.4e9)) if ips else None}
+                                            "mean_bases_per_window": float(len_pk.mean()), "instructions_per_step": per if per["valu"] else None,
+                                            "valu_issue_frac": (sps * per["valu"] * 4.0 / (1024 * 2.4e9)) if per["valu"] else None}
             be.dev_free(d_pk)
             sec["secondary_decode_only_peaky"] = leg
         except Exception as e:

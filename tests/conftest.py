@@ -12,6 +12,20 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if getattr(config.option, "durations", None) is None:
+        config.option.durations = 10          # every run prints its ten slowest tests: the GPU suite has a 900-s budget on the driver's box
+
+
+# GPU files that measure (throughput ratios, self-measured policy figures), rehearse multi-process start-up or replay fuzz slices run AFTER
+# the parity files: under the driver's `pytest -x` a noisy measurement can then no longer hide a parity result.
+_LATE = ("test_gpu_two_ranks", "test_gpu_standin_rccl", "test_gpu_fuzz", "test_gpu_policy")
+
+
+def pytest_collection_modifyitems(config, items):
+    def rank(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _LATE.index(mod) + 1 if mod in _LATE else 0
+    items.sort(key=rank)          # (stable: files and tests keep their order inside each class)
 
 
 @pytest.fixture(scope="session")

@@ -319,7 +319,10 @@ def test_bench_nrank_files_leg_with_stub_ranks(tmp_path, capfd, oracle):
     pr = leg["per_rank"]
     assert [p["rank"] for p in pr] == [0, 1, 2] and sum(p["reads"] for p in pr) == 120 and all(p["cores"] >= 1 and p["value"] > 0 for p in pr)
     if len(os.sched_getaffinity(0)) >= 3:
-        assert all(p["cpu_bound"] for p in pr) and not (set(pr[0]["cpus"]) & set(pr[1]["cpus"])) and not (set(pr[1]["cpus"]) & set(pr[2]["cpus"]))
+        from radian_amd.hostbudget import parse_cpulist
+        sets = [set(parse_cpulist(p["cpus"])) for p in pr]
+        assert all(p["cpu_bound"] for p in pr) and not (sets[0] & sets[1]) and not (sets[1] & sets[2]) and all(len(x) == p["cores"] for x, p in zip(sets, pr))
+        assert bench.cpulist([0, 1, 2, 3, 8, 10, 11]) == "0-3,8,10-11"
     assert leg["rccl_nranks"] == 3 and leg["startup_comm"] == "stub"
     # the merged FASTA == one process over the same six files
     in_dir, ref_dir = tmp_path / "in", tmp_path / "ref"

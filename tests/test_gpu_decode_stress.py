@@ -207,7 +207,8 @@ def test_rows_that_are_not_probabilities_do_not_derail_the_search(be, oracle):
             if i % 2 == 0:
                 seg[:] = np.nan                      # a whole sequence of NaN
         for W in (1, 6, 10, 13, 25, 40):
-            for form in ("auto", "two", "one", "waves", "lanes"):
+            # (round 6, suite budget: a pinned form only at the widths it changes -- "two" / "one" up to 12, "waves" / "lanes" above)
+            for form in ("auto",) + (("two", "one") if W <= 12 else ("waves", "lanes")):
                 for lm in (False, True):
                     be.set_decode_form(form)
                     be.load_lm(table if lm else None, k if lm else 0)

@@ -39,24 +39,35 @@ def _check_figures(d, factor=2.0):
     assert all(_within(x, ind["us_per_step"], factor) for x in paces), ("chain pace", paces, ind["us_per_step"])
 
 
+BAR = 0.8
+
+
 def _probe(prec, W, load):
-    """one probe; a throughput ratio below the bar is measured once more before it counts (a shared box, streams of a few seconds each:
-    one slow repetition in twenty is noise, two in a row are a finding) -- both results are printed"""
+    """One probe.  A throughput ratio below the bar WARNS and is measured a second time (a shared box, streams of a few seconds each: one slow
+    repetition in twenty is noise); it only counts as a finding when it reproduces -- the second measurement AND the mean of the two must
+    clear the bar (best-of-two would let a regression that fails half the time pass most runs).  Both values are printed and
+    attached to the result."""
+    import warnings
     import policy_probe
     d = policy_probe.probe(prec, W, load=load)
     print({k: v for k, v in d.items() if not k.startswith("policy")})
-    if d["alternating_over_steady"] < 0.8:
+    d["ratio_runs"] = [d["alternating_over_steady"]]
+    if d["alternating_over_steady"] < BAR:
+        warnings.warn(f"alternating / steady = {d['alternating_over_steady']:.3f} < {BAR} ({prec}, W = {W}, load = {load}): measuring once more")
         d2 = policy_probe.probe(prec, W, load=load)
         print("second measurement:", {k: v for k, v in d2.items() if not k.startswith("policy")})
-        if d2["alternating_over_steady"] > d["alternating_over_steady"]:
-            d = d2
+        runs = [d["alternating_over_steady"], d2["alternating_over_steady"]]
+        d = d2
+        d["ratio_runs"] = runs
+        # what the assertion below sees: the second run, capped by the mean of the two
+        d["alternating_over_steady"] = min(runs[1], sum(runs) / 2.0)
     return d
 
 
 def test_policy_figures_and_alternating_stream_fp32_beam10():
     d = _probe("fp32", 10, False)
     _check_figures(d)
-    assert d["alternating_over_steady"] >= 0.8, d["alternating_over_steady"]
+    assert d["alternating_over_steady"] >= BAR, d["ratio_runs"]
     assert min(d["samples_per_s_short"], d["samples_per_s_long"], d["samples_per_s_alternating"]) > 12e6      # (nothing collapsed: ~20-28 M each)
 
 
@@ -69,10 +80,10 @@ def test_policy_follows_a_gpu_shared_with_another_process():
     # (idle figures would be 1.7 us per step and 28 ns per row against 4.5-5.1 and 42-50 measured here: 2.6x and 1.7x off.  The chain pace
     # of a lone wave came out at 2.2 against 4.5 us in one of six runs -- a window in which the other process was between launches)
     _check_figures(d, factor=2.5)
-    assert d["alternating_over_steady"] >= 0.8, d["alternating_over_steady"]
+    assert d["alternating_over_steady"] >= BAR, d["ratio_runs"]
 
 
 def test_alternating_stream_wide_beam_bf16x3():
     d = _probe("bf16x3", 25, False)
     _check_figures(d, factor=2.5)       # (W = 25: three chains per SIMD step at 4.3-5.8 us against a lone chain's 2.5)
-    assert d["alternating_over_steady"] >= 0.8, d["alternating_over_steady"]
+    assert d["alternating_over_steady"] >= BAR, d["ratio_runs"]
