@@ -49,7 +49,7 @@ const char* rd_last_error(void);
 int rd_version(void);                 /* ABI version, currently 1 */
 int rd_device_count(int* n);          /* number of visible HIP devices */
 int rd_decode_max_width(void);        /* largest supported --beam-width (1024; radian/decode.py:145 slices with any width) */
-int rd_decode_lane_width(void);       /* widths up to this (64) run on the wave-per-sequence kernels, wider ones on the general kernel */
+int rd_decode_lane_width(void);       /* widths up to this (128) run on the wave-per-sequence kernels, wider ones on the general kernel */
 
 /* ---- context ------------------------------------------------------------------------------- */
 int rd_create(int device_id, rd_ctx** out);

@@ -232,7 +232,9 @@ void rd_rpipe_destroy(rd_ctx* ctx);
 inline bool rd_decode_len_ok(int W, int64_t rows) { return 1 + (int64_t)W * rows < ((int64_t)1 << 29); }
 
 extern "C" int rd_decode_max_width(void);
-// decode_wide.hip: beam widths above the wave-per-sequence kernels' 51, up to RD_WIDE_MAX_W (40 W bytes of LDS for the ranking keys)
+constexpr int RD_LANE_MAX_W = 128;     // decode.hip: the wave-per-sequence kernels' widest beam (rd_decode_lane_width)
+constexpr int RD_HASHED_MAX_W = 64;    // ... and the widest one with hashed long contexts (rd_load_lm_hashed)
+// decode_wide.hip: beam widths above RD_LANE_MAX_W, up to RD_WIDE_MAX_W (40 W bytes of LDS for the ranking keys)
 constexpr int RD_WIDE_MAX_W = 1024;
 int rd_decode_wide_launch(rd_ctx* ctx, hipStream_t st, const void* decode_args, int ptype, int n_seq, int64_t total_nodes, bool lm);
 
@@ -258,8 +260,8 @@ struct TrieRun {
 template <typename LenOf>
 inline void rd_plan_trie_runs(const rd_ctx* ctx, int W, int k_begin, int k_end, LenOf len_of, int64_t* node_off, std::vector<TrieRun>& runs)
 {
-    const int64_t per_node = W > 64 ? 24 : 20;
-    const int64_t per_seq = W > 64 ? (int64_t)rd_wide_scratch_bytes(W) : 0;
+    const int64_t per_node = W > RD_LANE_MAX_W ? 24 : 20;
+    const int64_t per_seq = W > RD_LANE_MAX_W ? (int64_t)rd_wide_scratch_bytes(W) : 0;
     int64_t nodes = 0, bytes = 0;
     int k0 = k_begin;
     for (int k = k_begin; k < k_end; k++) {
@@ -279,6 +281,5 @@ inline void rd_plan_trie_runs(const rd_ctx* ctx, int W, int k_begin, int k_end, 
 // Hashed long contexts (rd_load_lm_hashed) exist in the lane kernels only: refused where the arguments are checked, not when a group
 // of batches is launched after earlier reads were written
 #define RD_REQUIRE_WIDTH_LM(ctx, W, use_lm)                                                                                     \
-    RD_REQUIRE(!((use_lm) && (ctx)->lm.loaded && (ctx)->lm.hashed && (W) > 64),                                                  \
-               "beam width %d with a hashed long-context RNA model (rd_load_lm_hashed): widths above 64 run on the general kernel, " \
-               "which has no hashed contexts", (W))
+    RD_REQUIRE(!((use_lm) && (ctx)->lm.loaded && (ctx)->lm.hashed && (W) > RD_HASHED_MAX_W),                                     \
+               "beam width %d with a hashed long-context RNA model (rd_load_lm_hashed): hashed contexts exist for widths up to 64", (W))

@@ -59,6 +59,9 @@ template <>
 struct Cfg<2, 4> {
     static constexpr int WM = 64;
 };
+// five waves, two candidates per lane: 640 candidates = 128 beams (round 6: widths 65 ... 128, until then decode_wide.hip's at 7x the step
+// time).  The per-beam work that the shapes above do with "lane = beam" runs here over TWO halves of the beam set (beam = lane + 64 h):
+// the table self-check and the claim check on every wave, the trie phase on wave 0 one half after the other.
 
 
 // Hand-off between the waves of a sequence's workgroup.  One wave: see wave_sync.  Several waves: the LDS operations of
@@ -98,9 +101,11 @@ __device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int 
     // R > 1 form is for (many sequences)
     constexpr int KG = R == 1 ? 16 : 4;
     constexpr int SEG = 64 + KG;        // doubles per segment: 64 keys + the padding of the last group
-    constexpr int LOG_TN = R * NW <= 2 ? 9 : 10;
-    constexpr int TN = 1 << LOG_TN;     // (LDS per sequence bounds the resident waves: 2 KiB / 4 KiB)
-    static_assert(WM <= 64, "the kept beams fit the lanes of one wave");
+    constexpr int HB = (WM + 63) / 64;  // halves of the beam set: per-beam lanes handle beam lane + 64 h
+    constexpr int LOG_TN = WM > 64 ? 11 : R * NW <= 2 ? 9 : 10;
+    constexpr int TN = 1 << LOG_TN;     // (LDS per sequence bounds the resident waves: 2 KiB / 4 KiB; 8 KiB for 128 beams)
+    static_assert(WM <= 64 * HB && HB <= 2, "the kept beams fit the lanes of one wave, once or twice");
+    static_assert(HB == 1 || !HC, "hashed contexts exist for up to 64 beams");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -230,7 +235,13 @@ __device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int 
             bool s_open = false;
             if constexpr (LM) s_open = __builtin_amdgcn_readfirstlane((int)(sent[tt] > a.s_thr)) != 0;
             const double ptot_last = os[nb - 1].ptot;
-            const int myn = os[lane < nb ? lane : 0].node;
+            int myn[HB];
+            if constexpr (HB == 1) {
+                myn[0] = os[lane < nb ? lane : 0].node;
+            } else {
+#pragma unroll
+                for (int h = 0; h < HB; h++) myn[h] = os[lane + 64 * h < nb ? lane + 64 * h : 0].node;
+            }
             double2 pp[R];
             double pnb_i[R];
             int2 ll[R];
@@ -258,7 +269,13 @@ __device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int 
             if (tid < W) claims[tid] = 0u;
             // batch 2: log p(label), the id-table probe of the extension's child id, and every kept beam looks itself up: the
             // table resolves all kept beams iff each finds itself (every wave checks all beams)
-            const unsigned my_e = tab[myn & (TN - 1)];
+            unsigned my_e[HB];
+            if constexpr (HB == 1) {
+                my_e[0] = tab[myn[0] & (TN - 1)];
+            } else {
+#pragma unroll
+                for (int h = 0; h < HB; h++) my_e[h] = tab[myn[h] & (TN - 1)];
+            }
             double lpc[R];
             unsigned p_e[R];
 #pragma unroll
@@ -270,7 +287,15 @@ __device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int 
                 xch[s] = x;
                 p_e[s] = tab[x & (TN - 1)];
             }
-            const bool tab_ok = !__any((lane < nb) & (my_e != ((((unsigned)myn >> LOG_TN) << 8) | (unsigned)lane)));
+            bool tab_ok;
+            if constexpr (HB == 1) {
+                tab_ok = !__any((lane < nb) & (my_e[0] != ((((unsigned)myn[0] >> LOG_TN) << 8) | (unsigned)lane)));
+            } else {
+                bool tab_bad = false;
+#pragma unroll
+                for (int h = 0; h < HB; h++) tab_bad |= (lane + 64 * h < nb) & (my_e[h] != ((((unsigned)myn[h] >> LOG_TN) << 8) | (unsigned)(lane + 64 * h)));
+                tab_ok = !__any(tab_bad);
+            }
 #pragma unroll
             for (int s = 0; s < R; s++) {
                 const int i = bi[s], k = kk[s];
@@ -496,12 +521,30 @@ __device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int 
             scatter();
             seq_sync<NW>();
             // one batch: the claim counts, Phase F's input, and what an old beam needs to know to leave the id table
-            const unsigned n_claims = claims[lane < nb_new ? lane : 0];
-            int sel = d_sel[lane < nb_new ? lane : 0];
-            int my_newslot = newslot[lane < nb ? lane : 0];
-            unsigned my_tn2 = tab[myn & (TN - 1)];
-            asm volatile("" : "+v"(sel), "+v"(my_newslot), "+v"(my_tn2));   // (all four requested before the tie branch)
-            if (__any((lane < nb_new) & (n_claims != 1u))) {      // (every wave looks at all slots: workgroup-uniform)
+            unsigned n_claims[HB], my_tn2[HB];
+            int sel[HB], my_newslot[HB];
+            bool claim_bad;
+            if constexpr (HB == 1) {
+                n_claims[0] = claims[lane < nb_new ? lane : 0];
+                sel[0] = d_sel[lane < nb_new ? lane : 0];
+                my_newslot[0] = newslot[lane < nb ? lane : 0];
+                my_tn2[0] = tab[myn[0] & (TN - 1)];
+                asm volatile("" : "+v"(sel[0]), "+v"(my_newslot[0]), "+v"(my_tn2[0]));   // (all four requested before the tie branch)
+                claim_bad = (lane < nb_new) & (n_claims[0] != 1u);
+            } else {
+                claim_bad = false;
+#pragma unroll
+                for (int h = 0; h < HB; h++) {
+                    const int bl = lane + 64 * h;
+                    n_claims[h] = claims[bl < nb_new ? bl : 0];
+                    sel[h] = d_sel[bl < nb_new ? bl : 0];
+                    my_newslot[h] = newslot[bl < nb ? bl : 0];
+                    my_tn2[h] = tab[myn[h] & (TN - 1)];
+                    asm volatile("" : "+v"(sel[h]), "+v"(my_newslot[h]), "+v"(my_tn2[h]));
+                    claim_bad |= (bl < nb_new) & (n_claims[h] != 1u);
+                }
+            }
+            if (__any(claim_bad)) {      // (every wave looks at all slots: workgroup-uniform)
 #pragma unroll
                 for (int s = 0; s < R; s++) rank[s] = 0;
 #pragma unroll
@@ -521,8 +564,11 @@ __device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int 
                 if constexpr (NW > 1) seq_sync<NW>();
                 scatter();
                 seq_sync<NW>();
-                sel = d_sel[lane < nb_new ? lane : 0];
-                my_newslot = newslot[lane < nb ? lane : 0];
+#pragma unroll
+                for (int h = 0; h < HB; h++) {
+                    sel[h] = d_sel[lane + 64 * h < nb_new ? lane + 64 * h : 0];
+                    my_newslot[h] = newslot[lane + 64 * h < nb ? lane + 64 * h : 0];
+                }
             }
 
             // ---------------- Phase F: the new beam set: trie ids, labeling state (wave 0) ----------------------
@@ -530,11 +576,12 @@ __device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int 
             // appends its label and gets its canonical id: the parent's child id if that child was ever created (its own
             // child ids then come back from the HBM trie), else a fresh id.  A fresh id is also patched into the parent's
             // NEW record when the parent is kept (newslot), so that child ids stay canonical.
+            if constexpr (HB == 1) {
             if (NW == 1 || wv == 0) {
                 const bool act = lane < nb_new;
-                const int j = act ? (sel & 0xff) : 0;                // copied beam (0xff: none)
-                const int par = act ? (sel >> 8) & 0xff : 0;
-                const int cl = act ? (sel >> 16) - 1 : 0;
+                const int j = act ? (sel[0] & 0xff) : 0;                // copied beam (0xff: none)
+                const int par = act ? (sel[0] >> 8) & 0xff : 0;
+                const int cl = act ? (sel[0] >> 16) - 1 : 0;
                 const bool is_ext = act && j == 0xff;
                 const int src = is_ext ? par : j;
                 // one batch: the source record and the parent's new slot (for the patch at the end)
@@ -544,7 +591,7 @@ __device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int 
                 const int nid_old = os[src].child[cl & 3];           // (extensions: cl = the appended label)
                 const int ps = newslot[par];
                 // a labeling that is not kept leaves the id table (before the new beams enter theirs: in-order LDS)
-                if ((lane < nb) & (my_newslot < 0) & ((my_tn2 >> 8) == ((unsigned)myn >> LOG_TN))) tab[myn & (TN - 1)] = 0xffffffffu;
+                if ((lane < nb) & (my_newslot[0] < 0) & ((my_tn2[0] >> 8) == ((unsigned)myn[0] >> LOG_TN))) tab[myn[0] & (TN - 1)] = 0xffffffffu;
                 const bool fresh = is_ext && nid_old == 0;
                 const bool reload = is_ext && nid_old != 0;
                 const unsigned long long fmask = __ballot(fresh);
@@ -608,6 +655,76 @@ __device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int 
                 }
                 // (after the record writes above in program order: LDS operations of a wave execute in order)
                 if (fresh && ps >= 0) ns[ps].child[cl] = my_node;
+            }
+            } else {
+                // 65 ... 128 beams: wave 0 builds the new beam set one half after the other (lane r of half h builds beam r + 64 h).  Same
+                // order of LDS operations as above where it matters: labelings that are not kept leave the id table before ANY new beam
+                // enters; a fresh child id is patched into its parent's new record after EVERY record has been written.
+                if (wv == 0) {
+#pragma unroll
+                    for (int h = 0; h < HB; h++)
+                        if ((lane + 64 * h < nb) & (my_newslot[h] < 0) & ((my_tn2[h] >> 8) == ((unsigned)myn[h] >> LOG_TN))) tab[myn[h] & (TN - 1)] = 0xffffffffu;
+                    bool fresh_h[HB];
+                    int ps_h[HB], cl_h[HB], node_h[HB];
+#pragma unroll
+                    for (int h = 0; h < HB; h++) {
+                        const int bl = lane + 64 * h;
+                        const bool act = bl < nb_new;
+                        const int j = act ? (sel[h] & 0xff) : 0;                // copied beam (0xff: none)
+                        const int par = act ? (sel[h] >> 8) & 0xff : 0;
+                        const int cl = act ? (sel[h] >> 16) - 1 : 0;
+                        const bool is_ext = act && j == 0xff;
+                        const int src = is_ext ? par : j;
+                        const int4 meta = *(const int4*)&os[src].node;       // node, hist, pad, pad
+                        const int2 sl2 = *(const int2*)&os[src].last;        // last, len
+                        const int4 chs = *(const int4*)&os[src].child[0];
+                        const int nid_old = os[src].child[cl & 3];           // (extensions: cl = the appended label)
+                        const int ps = newslot[par];
+                        const bool fresh = is_ext && nid_old == 0;
+                        const bool reload = is_ext && nid_old != 0;
+                        const unsigned long long fmask = __ballot(fresh);
+                        const int my_node = fresh ? next_id + __popcll(fmask & ((1ull << lane) - 1ull)) : nid_old;
+                        if (fresh) {
+                            backptr[my_node] = (meta.x << 2) | cl;
+                            ((int*)&childtab[meta.x])[cl] = my_node;
+                            childtab[my_node] = make_int4(0, 0, 0, 0);
+                        }
+                        next_id += __popcll(fmask);
+                        int4 ch = make_int4(0, 0, 0, 0);
+                        if (__any(reload)) {
+                            __builtin_amdgcn_s_waitcnt(0);
+                            if (reload) {
+                                const int* cp = (const int*)&childtab[my_node];
+                                ch.x = __hip_atomic_load(cp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                ch.y = __hip_atomic_load(cp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                ch.z = __hip_atomic_load(cp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                ch.w = __hip_atomic_load(cp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ch.x), "+v"(ch.y), "+v"(ch.z), "+v"(ch.w));
+                        }
+                        if (act) {
+                            const int new_node = is_ext ? my_node : meta.x;
+                            *(int2*)&ns[bl].last = make_int2(is_ext ? cl : sl2.x, is_ext ? sl2.y + 1 : sl2.y);
+                            const unsigned h_new = ((unsigned)meta.y << 2) | (unsigned)cl;
+                            if constexpr (LM) {
+                                if (a.lm_missing && is_ext && sl2.y + 1 >= a.k && t0 + tt + 1 < T) {
+                                    const unsigned cx = h_new & ctx_mask;
+                                    missed |= ((a.lm_missing[cx >> 5] >> (cx & 31)) & 1u) != 0u;
+                                }
+                            }
+                            *(int4*)&ns[bl].node = make_int4(new_node, is_ext ? (int)h_new : meta.y, meta.z, 0);
+                            *(int4*)&ns[bl].child[0] = make_int4(is_ext ? ch.x : chs.x, is_ext ? ch.y : chs.y, is_ext ? ch.z : chs.z, is_ext ? ch.w : chs.w);
+                            tab[new_node & (TN - 1)] = (((unsigned)new_node >> LOG_TN) << 8) | (unsigned)bl;
+                        }
+                        fresh_h[h] = fresh;
+                        ps_h[h] = ps;
+                        cl_h[h] = cl;
+                        node_h[h] = my_node;
+                    }
+#pragma unroll
+                    for (int h = 0; h < HB; h++)
+                        if (fresh_h[h] && ps_h[h] >= 0) ns[ps_h[h]].child[cl_h[h]] = node_h[h];
+                }
             }
             nb = nb_new;
             cur ^= 1;
@@ -1156,6 +1273,8 @@ __global__ __launch_bounds__(64) void beam_search2_kernel(DecodeArgs a, int n_se
 constexpr int kMaxW = Cfg<1, 4>::WM;
 static_assert(Cfg<2, 2>::WM == kMaxW, "both forms cover the same widths");
 constexpr int kMaxW2 = Cfg<2, 4>::WM;   // 64: widths 52 ... 64 on four waves with two candidates per lane
+constexpr int kMaxW3 = Cfg<2, 5>::WM;   // 128: widths 65 ... 128 on five waves with two candidates per lane, the beam set in two halves (round 6)
+static_assert(kMaxW3 == RD_LANE_MAX_W && kMaxW2 == RD_HASHED_MAX_W, "common.h's figures are this file's");
 
 template <typename PT, int R, int NW, bool GX>
 int launch_g(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
@@ -1212,9 +1331,29 @@ int launch_two(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
     return RD_OK;
 }
 
+// 65 ... 128 beams: no hashed contexts (refused where the arguments are checked: RD_REQUIRE_WIDTH_LM)
+template <typename PT>
+int launch_128(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
+{
+    constexpr int NW = 5;
+    if (lm) {
+        if (a.glibc_math) hipLaunchKernelGGL((beam_search_kernel<PT, 2, NW, true, false, true>), dim3(n_seq), dim3(64 * NW), 0, st, a);
+        else hipLaunchKernelGGL((beam_search_kernel<PT, 2, NW, true, false, false>), dim3(n_seq), dim3(64 * NW), 0, st, a);
+    } else {
+        if (a.glibc_math) hipLaunchKernelGGL((beam_search_kernel<PT, 2, NW, false, false, true>), dim3(n_seq), dim3(64 * NW), 0, st, a);
+        else hipLaunchKernelGGL((beam_search_kernel<PT, 2, NW, false, false, false>), dim3(n_seq), dim3(64 * NW), 0, st, a);
+    }
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
 template <typename PT>
 int launch_pt(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm, int n_simd, int form)
 {
+    if (a.W > kMaxW2) {
+        RD_REQUIRE(!(lm && a.hashed), "beam widths above %d do not combine with hashed long contexts (rd_load_lm_hashed)", kMaxW2);
+        return launch_128<PT>(st, a, n_seq, lm);
+    }
     // W <= 6: two sequences per wave.  Measured (tools/decode_bench.py, 1024-row windows, W = 6): 4096 windows 1.23 -> 1.80 G time
     // steps/s (glibc arithmetic 1.10 -> 1.55 G, soft rows 0.94 -> 1.32 G); 512 windows -- lone waves, the latency case -- 1.58 vs
     // 1.60 ms per launch: a step of the two-sequence wave is as short as the one-sequence wave's, so there is no case for the
@@ -1252,7 +1391,7 @@ __global__ void lm_gate_kernel(const double* __restrict__ entropy, size_t n, dou
 }  // namespace
 
 extern "C" int rd_decode_max_width(void) { return RD_WIDE_MAX_W; }
-extern "C" int rd_decode_lane_width(void) { return kMaxW2; }
+extern "C" int rd_decode_lane_width(void) { return kMaxW3; }
 
 // Per-context gate bits: bit = (entropy(lm[ctx]) < r_threshold)   decode.py:85-93.
 // The entropies were computed once at rd_load_lm (glibc log, like the reference's math.log) and live in HBM.
@@ -1329,7 +1468,7 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_
              : ptype == 2 ? launch_queue_pt<_Float16>(st, a, n_seq, use_lm != 0, queue_wave_slots, counter)
                           : launch_queue_pt<float>(st, a, n_seq, use_lm != 0, queue_wave_slots, counter);
     } else
-    rc = W > kMaxW2 ? rd_decode_wide_launch(ctx, st, &a, ptype, n_seq, total_nodes, use_lm != 0)   // (decode_wide.hip: any wider beam)
+    rc = W > kMaxW3 ? rd_decode_wide_launch(ctx, st, &a, ptype, n_seq, total_nodes, use_lm != 0)   // (decode_wide.hip: any wider beam)
              : ptype == 1 ? launch_pt<double>(st, a, n_seq, use_lm != 0, n_simd, ctx->decode_form)
              : ptype == 2 ? launch_pt<_Float16>(st, a, n_seq, use_lm != 0, n_simd, ctx->decode_form) : launch_pt<float>(st, a, n_seq, use_lm != 0, n_simd, ctx->decode_form);
     if (rc) return rc;

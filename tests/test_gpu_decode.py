@@ -480,7 +480,7 @@ def test_wide_beams_vs_oracle(be, oracle):
     """Widths above the wave-per-sequence kernels' 51 (decode_wide.hip; the reference slices with any --beam-width, decode.py:145):
     batches with empty / one-row / ragged sequences, float32 and float64 rows, exact-0 probabilities (ties), with a 3-mer LM (dense
     and sparse), both arithmetics, against the oracle; the width where the two kernels meet (51 | 52) included."""
-    assert be._L.rd_decode_lane_width() == 64 and be.max_beam_width >= 1024
+    assert be._L.rd_decode_lane_width() == 128 and be.max_beam_width >= 1024
     rng = np.random.default_rng(2026)
     lens = [300, 0, 1, 64, 65, 129, 512, 7]
     rows = []
@@ -498,15 +498,15 @@ def test_wide_beams_vs_oracle(be, oracle):
         be.set_decode_math(math)
         for dtype in (np.float32, np.float64):
             mats = np.concatenate(rows, axis=0).astype(dtype)
-            for W in (51, 52, 63, 64, 65, 100, 257, 1024):       # (52 ... 64: four waves, two candidates per lane; above: decode_wide.hip)
-                if math == "fast" and W not in (52, 64, 100):
+            for W in (51, 52, 63, 64, 65, 100, 127, 128, 129, 257, 1024):       # (52 ... 64: four waves, two candidates per lane; 65 ... 128: five waves, the beam set in two halves -- round 6; above: decode_wide.hip)
+                if math == "fast" and W not in (52, 64, 100, 128):
                     continue
                 be.load_lm(None, 0)
                 got = be.decode_batch(mats, off, lens, W)
                 exp = oracle.beam_search_batch(mats, off, lens, W)
                 for i in range(len(lens)):
                     assert np.array_equal(got[i], exp[i]), (math, dtype, W, i, "no LM")
-                if W in (52, 64, 100):
+                if W in (52, 64, 100, 128, 129):
                     for tb in (table, sparse):
                         be.load_lm(tb, 3)
                         got = be.decode_batch(mats, off, lens, W, use_lm=True, s_threshold=0.5, r_threshold=0.9)

@@ -62,6 +62,7 @@ def test_bench_four_ranks_broadcast_through_the_collective_seam(standin_env):
     hb = d["host_budget_rank0"]      # every rank bound itself to its share of the cores before its first GPU call (radian_amd/hostbudget.py)
     usable = len(os.sched_getaffinity(0))
     assert hb["split"] in ("numa", "even") and (not hb["bound"] or hb["cores"] <= max(1, usable // WORLD + 1)), (hb, usable)
+    assert abs(d["ms_per_step"] - max(d["ms_per_step_per_rank"])) < 1e-6        # (the reported region's own per-rank clocks)
     assert d["value"] > 0 and d["scaling"] == "weak" and len(d["value_runs"]) == 2 and min(d["value_runs"]) <= d["value"] <= max(d["value_runs"])
     # round 6: the N > 1 line carries the files -> FASTA leg through the multi-GPU route (work queue, native reader, per-rank core slice,
     # rank files, merger process), every rank's share and rate in it

@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_launches_two_ranks_itself():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--preheat-ms", "0"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--preheat-ms", "0", "--regions", "2",
+                        "--nrank-files-per-rank", "1"],
                        env=dict(os.environ, RD_BENCH_DEVICE="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
@@ -26,7 +27,9 @@ def test_bench_launches_two_ranks_itself():
     assert d["startup_comm"] in ("file-fallback", "rccl") and d["rccl_nranks"] == 2
     assert len(d["ms_per_step_per_rank"]) == 2 and all(x > 0 for x in d["ms_per_step_per_rank"])
     assert abs(d["ms_per_step"] - max(d["ms_per_step_per_rank"])) < 1e-6      # the line's time is the slowest rank's
-    assert d["config"]["launcher"] == "bench.py (own)" and d["value"] > 0
+    assert d["config"]["launcher"] == "bench.py (own)" and d["value"] > 0 and len(d["value_runs"]) == 2
+    leg = d["secondary_e2e_fast5_to_fasta"]      # round 6: the files -> FASTA leg of the N > 1 line, here on the file transport
+    assert "skipped" not in leg and leg["n_ranks"] == 2 and leg["records_written"] == 2 * 4096 and len(leg["per_rank"]) == 2, leg
 
 
 @pytest.mark.parametrize("mode", ["chunk", "global"])
