@@ -395,20 +395,23 @@ def test_cli_context_len_mismatch_fails_lazily_like_the_reference(tmp_path, gold
         assert _read_fasta(str(out)) == exp[:first_bad]
 
 
-@pytest.mark.parametrize("W", [64, 100])
+@pytest.mark.parametrize("W", [100, 130])
 def test_cli_beam_width_above_the_lane_kernels(tmp_path, golden_dir, oracle, W):
-    """--beam-width 64 / 100 (the reference slices `sort_labelings()[:beam_width]` with any width, decode.py:145): the five reads of
-    data/reads.fast5 through the CLI in both decode types -- the pipeline's groups launch the lane kernels' widest form (W = 64) and
-    csrc/decode_wide.hip (W = 100) -- equal to the oracle's decode of the GPU's own probabilities."""
+    """--beam-width 100 / 130 (the reference slices `sort_labelings()[:beam_width]` with any width, decode.py:145): the five reads of
+    data/reads.fast5 through the CLI -- the pipeline's groups launch the lane kernels' widest form (65 ... 128 beams: five waves, the beam
+    set in two halves; round 6) and csrc/decode_wide.hip (W = 130; chunk mode only: the oracle's side of a global run at that width is
+    most of the test's time) -- equal to the oracle's decode of the GPU's own probabilities."""
     from radian_amd import Backend, basecall, weights, lm
     ids, sig, in_dir, lm_path = _make_inputs(tmp_path, golden_dir, k=3)
     table, k = lm.load_json(lm_path)
     be = Backend(0)
     be.load_weights(weights.synthetic_weights(seed=1234))
     exp_chunk = _expected(be, oracle, ids, sig, 1024, 512, W, "chunk")
-    exp_global = _expected(be, oracle, ids, sig, 1024, 512, W, "global", table, k)
+    exp_global = _expected(be, oracle, ids, sig, 1024, 512, W, "global", table, k) if W <= 128 else None
     be.close()
     for mode, exp, extra in (("chunk", exp_chunk, ["--rna-model", "None"]), ("global", exp_global, ["--rna-model", lm_path, "--context-len", "3"])):
+        if exp is None:
+            continue
         out = tmp_path / f"w{W}_{mode}"
         out.mkdir()
         basecall.main([in_dir, str(out), "--decode-type", mode, "--beam-width", str(W), "--step-size", "512", "--sig-model", "synthetic:1234",
