@@ -387,7 +387,14 @@ def files_leg(rank, world, be_src, host_budget, rdv_dir, cli, device=0, files_pe
     try:
         # ---- a directory every rank can see: rank 0 makes it, the others learn its name
         if rank == 0:
-            base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+            need = 3 * world * files_per_rank * reads_per_file * (2 * read_len + 512)      # the fast5 shards, with room for the rank files and the FASTA
+            base = None
+            try:     # memory-backed when /dev/shm has the room (a container's default /dev/shm holds 64 MB), else the temporary directory
+                st = os.statvfs("/dev/shm")
+                if os.access("/dev/shm", os.W_OK) and st.f_bavail * st.f_frsize > need:
+                    base = "/dev/shm"
+            except OSError:
+                pass
             root = tempfile.mkdtemp(prefix="radian_bench_nrank_", dir=base)
             for d in ("in", "out", "scratch"):
                 os.mkdir(os.path.join(root, d))
@@ -497,7 +504,7 @@ def files_leg(rank, world, be_src, host_budget, rdv_dir, cli, device=0, files_pe
                                   "cpu_bound": n["cpu_bound"], "numa_node": n["numa_node"], "stitch_threads": n["stitch_threads"],
                                   "device_contexts": n["device_contexts"]} for n in notes],
                     "startup_comm": (comm_info or {}).get("startup_comm"), "rccl_nranks": (comm_info or {}).get("rccl_nranks"),
-                    "leg_seconds_incl_input_files_and_warmup": time.time() - t_enter,
+                    "leg_seconds_incl_input_files_and_warmup": time.time() - t_enter, "input_directory": "memory-backed (/dev/shm)" if root.startswith("/dev/shm") else "temporary directory (disk)",
                     "path": "BASELINE configs[2] from a fast5 directory to FASTA files at N ranks: " + str(n_files) + " multi-read fast5 files (" + str(reads_per_file)
                             + " reads each, written by the ranks before the clock starts, memory-backed) -> per-node FileReadQueue (blocks of 256 reads) -> native "
                               "reader (csrc/fast5.hip) on each rank's read-ahead thread -> H2D -> on-device mad_normalise -> streamed forward -> beam search -> "
