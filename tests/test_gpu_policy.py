@@ -27,22 +27,34 @@ def _within(a, b, factor):
     return a > 0 and b > 0 and a <= factor * b and b <= factor * a
 
 
-def _check_figures(d, factor=2.0):
+def _figures_ok(d, factor=2.0):
+    """-> (ok, what): the policy's own figures against the independent ones.  Forward pace within `factor`; the chain pace at m waves per
+    SIMD of the partition between the lone chain's pace / factor and factor x (1 + (m - 1) / 2) x that pace -- a chain that shares its SIMD
+    with one or two other chains steps up to two or three times slower than alone (measured: W = 25, bf16x3, m = 3: 4.3 ... 10 us against a lone
+    chain's 2.5), and the independent figure is the lone chain's."""
     ind = d["independent_long"]
     pol = d["policy_after_alternating"]
     ns = pol[1]["ns_per_row"]
     # (the policy keeps the smallest of its last five windows: on the low side of the blocking calls' figure by design)
-    assert _within(ns, ind["ns_per_row"], factor), ("forward pace", ns, ind["ns_per_row"])
-    paces = [pol[m]["us_per_step"] for m in (1, 2, 3) if pol[m]["us_per_step"] > 0]
-    assert paces, "no chain pace was measured on the partition"
-    # (a chain beside two other waves on its SIMD steps slower than a lone one: the independent figure is the lone chain's)
-    assert all(_within(x, ind["us_per_step"], factor) for x in paces), ("chain pace", paces, ind["us_per_step"])
+    if not _within(ns, ind["ns_per_row"], factor):
+        return False, ("forward pace", ns, ind["ns_per_row"])
+    paces = {m: pol[m]["us_per_step"] for m in (1, 2, 3) if pol[m]["us_per_step"] > 0}
+    if not paces:
+        return False, "no chain pace was measured on the partition"
+    lone = ind["us_per_step"]
+    bad = {m: x for m, x in paces.items() if not (lone / factor <= x <= factor * (1.0 + 0.5 * (m - 1)) * lone)}
+    return (not bad), ("chain pace by waves per SIMD", paces, "lone chain", lone, "outside", bad)
+
+
+def _check_figures(d, factor=2.0):
+    ok, what = d.get("figures", _figures_ok(d, factor))
+    assert ok, what
 
 
 BAR = 0.8
 
 
-def _probe(prec, W, load):
+def _probe(prec, W, load, factor=2.0):
     """One probe.  A throughput ratio below the bar WARNS and is measured a second time (a shared box, streams of a few seconds each: one slow
     repetition in twenty is noise); it only counts as a finding when it reproduces -- the second measurement AND the mean of the two must
     clear the bar (best-of-two would let a regression that fails half the time pass most runs).  Both values are printed and
@@ -52,15 +64,21 @@ def _probe(prec, W, load):
     d = policy_probe.probe(prec, W, load=load)
     print({k: v for k, v in d.items() if not k.startswith("policy")})
     d["ratio_runs"] = [d["alternating_over_steady"]]
-    if d["alternating_over_steady"] < BAR:
-        warnings.warn(f"alternating / steady = {d['alternating_over_steady']:.3f} < {BAR} ({prec}, W = {W}, load = {load}): measuring once more")
+    d["ragged_runs"] = [d["ragged_over_steady"]]
+    d["figures"] = _figures_ok(d, factor)
+    if d["alternating_over_steady"] < BAR or d["ragged_over_steady"] < BAR or not d["figures"][0]:
+        warnings.warn(f"alternating / steady = {d['alternating_over_steady']:.3f}, ragged / steady = {d['ragged_over_steady']:.3f}, bar {BAR}; figures "
+                      f"{d['figures']} ({prec}, W = {W}, load = {load}): measuring once more")
         d2 = policy_probe.probe(prec, W, load=load)
         print("second measurement:", {k: v for k, v in d2.items() if not k.startswith("policy")})
         runs = [d["alternating_over_steady"], d2["alternating_over_steady"]]
+        rruns = [d["ragged_over_steady"], d2["ragged_over_steady"]]
         d = d2
-        d["ratio_runs"] = runs
-        # what the assertion below sees: the second run, capped by the mean of the two
+        d["ratio_runs"], d["ragged_runs"] = runs, rruns
+        # what the assertions below see: the second run, capped by the mean of the two
         d["alternating_over_steady"] = min(runs[1], sum(runs) / 2.0)
+        d["ragged_over_steady"] = min(rruns[1], sum(rruns) / 2.0)
+        d["figures"] = _figures_ok(d, factor)      # (the figures of the second measurement: a miss has to reproduce to count)
     return d
 
 
@@ -68,13 +86,16 @@ def test_policy_figures_and_alternating_stream_fp32_beam10():
     d = _probe("fp32", 10, False)
     _check_figures(d)
     assert d["alternating_over_steady"] >= BAR, d["ratio_runs"]
-    assert min(d["samples_per_s_short"], d["samples_per_s_long"], d["samples_per_s_alternating"]) > 12e6      # (nothing collapsed: ~20-28 M each)
+    # round 6, a third stream shape the constants were not tuned on: ragged batches (log-normal read lengths, every batch another longest read,
+    # read count and plan) keep up with the steady state too
+    assert d["ragged_over_steady"] >= BAR, d["ragged_runs"]
+    assert min(d["samples_per_s_short"], d["samples_per_s_long"], d["samples_per_s_alternating"], d["samples_per_s_ragged"]) > 12e6      # (nothing collapsed: ~20-28 M each)
 
 
 def test_policy_follows_a_gpu_shared_with_another_process():
     import policy_probe
     try:
-        d = _probe("fp32", 10, True)
+        d = _probe("fp32", 10, True, factor=2.5)
     except policy_probe.LoadWorkerFailed as e:       # (the box would not start a second GPU process: nothing to measure against)
         pytest.skip(str(e))
     # (idle figures would be 1.7 us per step and 28 ns per row against 4.5-5.1 and 42-50 measured here: 2.6x and 1.7x off.  The chain pace
@@ -84,6 +105,7 @@ def test_policy_follows_a_gpu_shared_with_another_process():
 
 
 def test_alternating_stream_wide_beam_bf16x3():
-    d = _probe("bf16x3", 25, False)
+    d = _probe("bf16x3", 25, False, factor=2.5)
     _check_figures(d, factor=2.5)       # (W = 25: three chains per SIMD step at 4.3-5.8 us against a lone chain's 2.5)
     assert d["alternating_over_steady"] >= BAR, d["ratio_runs"]
+    assert d["ragged_over_steady"] >= BAR, d["ragged_runs"]

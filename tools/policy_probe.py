@@ -7,8 +7,9 @@ For a precision mode / beam width, optionally with a second PROCESS keeping the 
                evaluated; chain pace = the beam-search timer of a blocking decode of the same reads / the longest read's rows
   policy       what rd_pipe_policy_read reports after a stream of rd_pipe_submit_raw_global batches (ns per forward row, all lanes
                together; us per time step of a group's longest chain on the decode partition under the next group's forwards)
-  throughput   samples/s of uniform streams (all reads 4096 samples; all reads 40960) and of a stream whose batches ALTERNATE
-               between the two (the longest read jumps 10x from one batch to the next), same samples per batch
+  throughput   samples/s of uniform streams (all reads 4096 samples; all reads 40960), of a stream whose batches ALTERNATE
+               between the two (the longest read jumps 10x from one batch to the next), same samples per batch, and (round 6) of a stream
+               of RAGGED batches (seeded log-normal read lengths 1.5 k ... 60 k: every batch another longest read, read count and plan)
 usage: policy_probe.py [fp32|bf16x3|f16x3] [W=10] [load=0|1]      ->  one JSON line
        policy_probe.py --load-worker SECONDS                      (internal: the background process)"""
 import json, os, subprocess, sys, time
@@ -25,6 +26,22 @@ class LoadWorkerFailed(RuntimeError):
 def reads_of(n, length, seed):
     rng = np.random.default_rng(seed)
     return [np.round(rng.normal(500, 80, size=length)).astype(np.int16) for _ in range(n)]
+
+
+def ragged_batches(n_batches, samples_per_batch, seed, lo=1500, hi=60000, median=9000.0, sigma=0.8):
+    """batches of seeded log-normal read lengths (dRNA reads are heavy-tailed), each filled up to samples_per_batch: every batch has another
+    longest read, another read count and another plan -- the third stream shape of the policy test (round 6)"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_batches):
+        lens, total = [], 0
+        while total < samples_per_batch:
+            n = int(np.clip(np.exp(rng.normal(np.log(median), sigma)), lo, hi))
+            n = min(n, max(lo, samples_per_batch - total))
+            lens.append(n)
+            total += n
+        out.append([np.round(rng.normal(500, 80, size=n)).astype(np.int16) for n in lens])
+    return out
 
 
 def load_worker(seconds):
@@ -112,9 +129,13 @@ def probe(prec="fp32", W=10, load=False, quick=False):
         pol_l = {m: be.pipe_policy(W, m) for m in (0, 1, 2, 3)}
         out["samples_per_s_alternating"] = stream(be, [short, long_], W, n)
         pol_a = {m: be.pipe_policy(W, m) for m in (0, 1, 2, 3)}
+        rag = ragged_batches(12, 262144, 7)
+        out["samples_per_s_ragged"] = stream(be, rag, W, n) * 1.0
+        out["ragged_reads_per_batch"] = [len(b) for b in rag]
         out["policy_after_short"], out["policy_after_long"], out["policy_after_alternating"] = pol_s, pol_l, pol_a
         hs = 2.0 / (1.0 / out["samples_per_s_short"] + 1.0 / out["samples_per_s_long"])     # equal samples per batch: harmonic mean
         out["alternating_over_steady"] = out["samples_per_s_alternating"] / hs
+        out["ragged_over_steady"] = out["samples_per_s_ragged"] / hs
         return out
     finally:
         be.close()
