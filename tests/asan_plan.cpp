@@ -68,10 +68,50 @@ static int check_plan(const rdi::ReadsPlan& P, int64_t n_samples, bool chunk_mod
     return 0;
 }
 
+// rd_plan_trie_runs (common.h, round 6): a launch's sequences cut into runs whose beam-search workspace fits the context's budget.
+// Properties: the runs tile [k_begin, k_end) in order; node offsets restart at 0 in every run and are the running sum of 1 + W * len inside
+// it; a run's nodes are that sum; a run of more than one sequence fits the budget (a single sequence may exceed it: it cannot be split).
+static int check_trie_runs(std::mt19937_64& rng, int it)
+{
+    rd_ctx ctx;
+    const int W = (int[]){1, 6, 10, 25, 64, 65, 100, 128, 129, 1024}[rng() % 10];
+    ctx.trie_budget = (int64_t)1 << (14 + rng() % 22);
+    const int n = (int)(rng() % 300), k_begin = n ? (int)(rng() % (n + 1)) : 0;
+    std::vector<int32_t> len(n);
+    for (int& x : len) x = (int)(rng() % (rng() % 5 ? 1100 : 60000));
+    std::vector<int64_t> off(n, -7);
+    std::vector<TrieRun> runs;
+    rd_plan_trie_runs(&ctx, W, k_begin, n, [&](int k) { return (int64_t)len[k]; }, off.data(), runs);
+    const int64_t per_node = W > RD_LANE_MAX_W ? 24 : 20, per_seq = W > RD_LANE_MAX_W ? (int64_t)rd_wide_scratch_bytes(W) : 0;
+    int next = k_begin;
+    for (const TrieRun& r : runs) {
+        CHECK(r.k0 == next && r.k1 > r.k0 && r.k1 <= n, "it %d: run [%d, %d) after %d of %d", it, r.k0, r.k1, next, n);
+        int64_t nodes = 0;
+        for (int k = r.k0; k < r.k1; k++) {
+            CHECK(off[k] == nodes, "it %d: node offset %lld of sequence %d, expected %lld", it, (long long)off[k], k, (long long)nodes);
+            nodes += 1 + (int64_t)W * len[k];
+        }
+        CHECK(nodes == r.nodes, "it %d: run nodes %lld, expected %lld", it, (long long)r.nodes, (long long)nodes);
+        const int64_t bytes = nodes * per_node + (int64_t)(r.k1 - r.k0) * per_seq;
+        CHECK(r.k1 - r.k0 == 1 || bytes <= ctx.trie_budget, "it %d: run of %d sequences needs %lld bytes, budget %lld", it, r.k1 - r.k0, (long long)bytes, (long long)ctx.trie_budget);
+        // (greedy: the next sequence would not have fitted)
+        if (r.k1 < n) {
+            const int64_t more = (1 + (int64_t)W * len[r.k1]) * per_node + per_seq;
+            CHECK(bytes + more > ctx.trie_budget, "it %d: run [%d, %d) ends early", it, r.k0, r.k1);
+        }
+        next = r.k1;
+    }
+    CHECK(next == n || (runs.empty() && k_begin == n), "it %d: runs end at %d of %d", it, next, n);
+    for (int k = 0; k < k_begin; k++) CHECK(off[k] == -7, "it %d: offset %d outside the range was written", it, k);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     const int iters = argc > 1 ? atoi(argv[1]) : 20000;
     std::mt19937_64 rng(17);
+    for (int it = 0; it < 4 * iters; it++)
+        if (check_trie_runs(rng, it)) return 1;
     long tiles = 0;
     for (int it = 0; it < iters; it++) {
         Model m;

@@ -686,7 +686,9 @@ def test_tile_planner_properties_under_address_sanitizer(tmp_path):
     """csrc/plan.hip -- the host code whose tile descriptors every forward kernel indexes HBM with -- compiled for the CPU with
     -fsanitize=address,undefined and checked on 2500 random (model, read set, chunk, step) geometries: every sub-tile inside its segment,
     every write inside the activation tensor and no row written twice within a layer, every sample / stream row a sub-tile reads existing,
-    every decoded sequence's rows inside the tensor (tests/asan_plan.cpp).  A violated property would be an out-of-bounds access on the GPU."""
+    every decoded sequence's rows inside the tensor (tests/asan_plan.cpp).  A violated property would be an out-of-bounds access on the GPU.
+    Round 6: the same harness checks rd_plan_trie_runs (common.h) on 10 000 random launches -- the runs tile the launch in order, node offsets
+    restart per run, every run of more than one sequence fits the workspace budget, no run ends early."""
     import shutil
     import subprocess
     if shutil.which("g++") is None:
