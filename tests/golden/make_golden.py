@@ -749,6 +749,49 @@ def gen_pipeline_baseline():
     print("pipeline_baseline:", len(cases), "cases")
 
 
+# ----------------------------------------------------------------------------------------------
+# 10. beam widths 65 ... 128 (round 6: the wave-per-sequence kernels' five-wave shape, the beam set in two halves): the reference's own
+#     beam_search at W = 65 / 90 / 127 / 128 -- without an LM on float32 rows (chunk-mode semantics, final scores captured) and with a
+#     3-mer LM on float64 rows.  A file of its own, so that the round-5 fixtures stay byte for byte what they were.
+# ----------------------------------------------------------------------------------------------
+def gen_beam_wide128():
+    import time
+    t_start = time.time()
+    rng = np.random.default_rng(20261106)
+    arrays, cases = {}, []
+    lm3, table3 = make_lm(rng, 3)
+    arrays["lm_k3"] = table3
+    cid = 0
+    for T in (8, 64, 300):
+        for kind in ("flat", "peaky", "hard"):
+            if T == 300 and kind == "hard":
+                continue
+            mat = make_matrix(rng, T, kind, np.float32)
+            name = f"x{cid}"
+            cid += 1
+            arrays[name] = mat
+            for W in (65, 90, 127, 128):
+                seq, final = run_beam(mat, W, capture=True)
+                cases.append({"group": "wide128_nolm", "mat": name, "T": T, "kind": kind, "W": W, "seq": seq, "final": _final_json(final[:8])})
+        print(f"  wide128 no LM T={T}: {time.time() - t_start:.0f}s", flush=True)
+    for T, kind in ((64, "flat"), (64, "peaky"), (200, "peaky")):
+        mat = make_matrix(rng, T, kind, np.float64)
+        name = f"x{cid}"
+        cid += 1
+        arrays[name] = mat
+        for W in (65, 100, 128):
+            for (s_thr, r_thr) in ((0.5, 0.5), (0.0, math.inf)):
+                seq, final = run_beam(mat, W, lm3, s_thr, r_thr, 3, capture=True)
+                cases.append({"group": "wide128_lm", "mat": name, "lm": "lm_k3", "k": 3, "T": T, "kind": kind, "W": W, "s_thr": fenc(s_thr), "r_thr": fenc(r_thr),
+                              "seq": seq, "final": _final_json(final[:8])})
+        print(f"  wide128 LM T={T} {kind}: {time.time() - t_start:.0f}s", flush=True)
+    np.savez_compressed(os.path.join(HERE, "beam_wide128_mats.npz"), **arrays)
+    with open(os.path.join(HERE, "beam_wide128_cases.json"), "w") as f:
+        json.dump({"source": "radian/decode.py:100-212 (beam_search) at beam widths 65 / 90 / 100 / 127 / 128 on seeded synthetic matrices; final = the first entries of the "
+                             "reference's last sorted beam list (labeling, pr_total, pr_blank, pr_non_blank)", "numpy": np.__version__, "cases": cases}, f, indent=0)
+    print("beam_wide128:", len(cases), "cases", f"{time.time() - t_start:.0f}s")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:       # regenerate single fixture sets: make_golden.py gen_seq_assembly_random ...
         for name in sys.argv[1:]:
@@ -765,5 +808,6 @@ if __name__ == "__main__":
     gen_pipeline()
     gen_beam_baseline()
     gen_pipeline_baseline()
+    gen_beam_wide128()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE))
     print("total bytes in tests/golden:", tot)

@@ -450,6 +450,40 @@ def test_baseline_wide_beams_vs_reference(be, golden_dir):
         be.load_lm(None, 0)
 
 
+def test_wide128_beams_vs_reference(be, golden_dir):
+    """Round 6: the five-wave shape (65 ... 128 beams, the beam set in two halves) against the imported reference's own beam_search at
+    W = 65 / 90 / 100 / 127 / 128: every labeling, and the winner's pr_total bit for bit in glibc arithmetic; one sequence per launch and
+    all cases of a width in one launch (neighbouring workgroups)."""
+    g = json.load(open(os.path.join(golden_dir, "beam_wide128_cases.json")))
+    arr = np.load(os.path.join(golden_dir, "beam_wide128_mats.npz"))
+    be.set_decode_math("glibc")
+    try:
+        n = 0
+        for c in g["cases"]:
+            m = arr[c["mat"]]
+            if "lm" in c:
+                be.load_lm(arr[c["lm"]], c["k"])
+                (lab,), sc = be.decode_batch(m, [0], [m.shape[0]], c["W"], use_lm=True, s_threshold=fdec(c["s_thr"]), r_threshold=fdec(c["r_thr"]), with_scores=True)
+            else:
+                be.load_lm(None, 0)
+                (lab,), sc = be.decode_batch(m, [0], [m.shape[0]], c["W"], with_scores=True)
+            assert s_of(lab) == c["seq"], (c["group"], c["mat"], c["W"])
+            exp = fdec(c["final"][0]["pr_total"])
+            assert sc[0] == exp or (np.isnan(exp) and np.isnan(sc[0])), (c["group"], c["mat"], c["W"], float(sc[0]).hex(), c["final"][0]["pr_total"])
+            n += 1
+        assert n == 50
+        be.load_lm(None, 0)
+        for W in (65, 90, 127, 128):
+            cs = [c for c in g["cases"] if c["W"] == W and "lm" not in c]
+            rows = np.concatenate([arr[c["mat"]].reshape(-1, 5) for c in cs])
+            lens = np.array([arr[c["mat"]].shape[0] for c in cs], dtype=np.int32)
+            off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+            got = be.decode_batch(rows, off, lens, W)
+            assert [s_of(x) for x in got] == [c["seq"] for c in cs], W
+    finally:
+        be.load_lm(None, 0)
+
+
 def test_baseline_single_window_float32_lm_vs_reference(be, golden_dir):
     """Reads shorter than one chunk in global mode (float32 matrix + LM), k = 3 and k = 11; cases are numpy-version-independent
     (tests/golden/make_golden.py gen_beam_baseline, group single_window_f32_lm)."""

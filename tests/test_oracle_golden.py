@@ -287,6 +287,21 @@ def test_baseline_wide_beams(oracle, golden_dir):
             _check_final(final, c["final"], tag)
 
 
+def test_wide128_beams_against_the_reference(oracle, golden_dir):
+    """Round 6: beam widths 65 / 90 / 100 / 127 / 128 from the imported reference (tests/golden/make_golden.py gen_beam_wide128) -- the widths the
+    wave-per-sequence kernels took over from the general kernel: labelings and the final beam's scores, bit for bit."""
+    g = _load(golden_dir, "beam_wide128_cases.json")
+    arr = np.load(os.path.join(golden_dir, "beam_wide128_mats.npz"))
+    assert len(g["cases"]) == 50 and {c["W"] for c in g["cases"]} == {65, 90, 100, 127, 128}
+    for c in g["cases"]:
+        lm = arr[c["lm"]] if "lm" in c else None
+        labels, final = oracle.beam_search_labels(arr[c["mat"]], c["W"], lm, fdec(c["s_thr"]) if lm is not None else 0.0,
+                                                  fdec(c["r_thr"]) if lm is not None else 0.0, c.get("k", 0), max_final=8)
+        tag = (c["group"], c["mat"], c["W"])
+        assert "".join(BASES[x] for x in labels) == c["seq"], tag
+        _check_final(final, c["final"], tag)
+
+
 def test_baseline_single_window_float32_with_lm(oracle, golden_dir):
     """A read shorter than one chunk in global mode: the decoded matrix stays float32.  The cases keep every row's entropy at least
     `entropy_margin` from s_thr, so the pinned numpy 1.19 (float64 entropies; what the oracle follows) and numpy 2.x (float32) decide the
