@@ -1308,9 +1308,13 @@ int launch_qg(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm, int slots
 template <typename PT>
 int launch_queue_pt(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm, int wave_slots, int* counter)
 {
-    // one workgroup = 1 / 2 / 4 waves for W <= 12 / 25 / 51 (the shapes part_seq_limit counts with)
-    const int nw = a.W <= Cfg<1, 1>::WM ? 1 : a.W <= Cfg<1, 2>::WM ? 2 : 4;
+    // one workgroup = 1 / 2 / 4 waves for W <= 12 / 25 / 51 (the shapes part_seq_limit counts with); round 6: 4 waves with two candidates per
+    // lane up to 64, 5 waves up to 128 (a global-mode stream at W = 100 whose groups could not go through the queue fell to 2.9 M samples/s
+    // on alternating read lengths: the groups closed at the partition's sequence limit, covered or not)
+    const int nw = a.W <= Cfg<1, 1>::WM ? 1 : a.W <= Cfg<1, 2>::WM ? 2 : a.W <= kMaxW2 ? 4 : 5;
     const int slots = std::max(1, std::min(n_seq, wave_slots / nw));
+    if (a.W > kMaxW2) return a.glibc_math ? launch_qg<PT, 2, 5, true>(st, a, n_seq, lm, slots, counter) : launch_qg<PT, 2, 5, false>(st, a, n_seq, lm, slots, counter);
+    if (a.W > kMaxW) return a.glibc_math ? launch_qg<PT, 2, 4, true>(st, a, n_seq, lm, slots, counter) : launch_qg<PT, 2, 4, false>(st, a, n_seq, lm, slots, counter);
     if (nw == 1) return a.glibc_math ? launch_qg<PT, 1, 1, true>(st, a, n_seq, lm, slots, counter) : launch_qg<PT, 1, 1, false>(st, a, n_seq, lm, slots, counter);
     if (nw == 2) return a.glibc_math ? launch_qg<PT, 1, 2, true>(st, a, n_seq, lm, slots, counter) : launch_qg<PT, 1, 2, false>(st, a, n_seq, lm, slots, counter);
     return a.glibc_math ? launch_qg<PT, 1, 4, true>(st, a, n_seq, lm, slots, counter) : launch_qg<PT, 1, 4, false>(st, a, n_seq, lm, slots, counter);
@@ -1459,7 +1463,7 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_
     if (tm.enabled && tm.used < tm.starts.size()) RD_HIP(hipEventRecord(tm.starts[tm.used], st));
     int rc;
     if (ctx->decode_form == 5 && queue_wave_slots == 0) queue_wave_slots = 16;   // rd_set_decode_form 5 (tests): every launch through the work queue, few slots
-    if (queue_wave_slots > 0 && W <= kMaxW && !(use_lm && a.hashed)) {
+    if (queue_wave_slots > 0 && W <= kMaxW3 && !(use_lm && a.hashed)) {
         // more sequences than the CUs of this stream keep resident: resident workgroups + a work queue (beam_search_queue_kernel)
         if (ctx->ws_queue.reserve(256)) return RD_ERR_NOMEM;
         RD_HIP(hipMemsetAsync(ctx->ws_queue.p, 0, 4, st));

@@ -135,7 +135,7 @@ struct Calib {
 inline int part_waves_per_simd(int part_cus, int W, int64_t n_seq)
 {
     const int64_t simds = (int64_t)RD_XCDS * part_cus * 4;
-    const int64_t waves = W <= 6 ? (n_seq + 1) / 2 : W <= 12 ? n_seq : W <= 25 ? 2 * n_seq : 4 * n_seq;
+    const int64_t waves = W <= 6 ? (n_seq + 1) / 2 : W <= 12 ? n_seq : W <= 25 ? 2 * n_seq : W <= 64 ? 4 * n_seq : 5 * n_seq;
     const int64_t m = (waves + simds - 1) / simds;
     return (int)(m < 1 ? 1 : m);
 }
@@ -268,14 +268,14 @@ int64_t chain_rows(const rd_ctx* ctx, Calib& c, int W, int m, int use_lm)
 inline int part_seq_limit(int part_cus, int W)
 {
     const int waves3 = RD_XCDS * part_cus * 4 * 3;      // three waves per SIMD
-    return W <= 6 ? 2 * waves3 : W <= 12 ? waves3 : W <= 25 ? waves3 / 2 : waves3 / 4;   // (W <= 6: two sequences per wave)
+    return W <= 6 ? 2 * waves3 : W <= 12 ? waves3 : W <= 25 ? waves3 / 2 : W <= 64 ? waves3 / 4 : waves3 / 5;   // (W <= 6: two sequences per wave; 65 ... 128: five waves, 43 KB of LDS: three per CU)
 }
 // sequences the work-queue search of an oversubscribed partition keeps resident: its workgroups are one sequence each (1 / 2 / 4 waves for
 // W <= 12 / 25 / 51 -- no two-sequences-per-wave form), three waves per SIMD
 inline int queue_resident_seqs(int part_cus, int W)
 {
     const int waves3 = RD_XCDS * part_cus * 4 * 3;
-    return W <= 12 ? waves3 : W <= 25 ? waves3 / 2 : waves3 / 4;
+    return W <= 12 ? waves3 : W <= 25 ? waves3 / 2 : W <= 64 ? waves3 / 4 : waves3 / 5;
 }
 constexpr int64_t kGroupRowsCap = 96ll << 20;   // rows a group may gather while it waits for coverage (~6 GB of probabilities + matrix)
 // CUs per XCD of the decode partition for a beam width (rd_set_decode_partition -1).  ALWAYS A MULTIPLE OF FOUR: a CU-masked
@@ -790,7 +790,7 @@ int submit(rd_ctx* ctx, int mode, const float* d_signal, const int16_t* raw, int
             // measurements last saw, alternated between 36 and 24 M samples/s on this rule alone: 11 of 37 groups closed here uncovered.)
             const int64_t chain_need = chain_rows(ctx, p->calib, W, 3, use_lm) * std::max<int64_t>(g.longest, longest_b);
             const bool uncovered = g.rows + P.total_rows < chain_need;
-            if ((work_ms <= 1.25 * fwd_ms || uncovered) && W <= 51 /* (the work-queue kernel's shapes) */ && !(use_lm && ctx->lm.hashed)) g.oversub = true;
+            if ((work_ms <= 1.25 * fwd_ms || uncovered) && W <= RD_LANE_MAX_W /* (the work-queue kernel's shapes) */ && !(use_lm && ctx->lm.hashed)) g.oversub = true;
             else {
                 p->limit_closes++;
                 if ((rc = close_group(ctx, p))) return rc;
