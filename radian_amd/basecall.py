@@ -73,7 +73,7 @@ def build_parser():
                              "search)")
     parser.add_argument("--decode-partition", default=-1, type=int,
                         help="global mode, pipelined: CUs of each XCD kept free of forward workgroups for the beam search (a read's "
-                             "search is one serial chain; beside conv waves a step runs ~8x slower).  -1: by beam width (4, 8 above W = 25: multiples of four -- a masked queue is dealt over four shader engines), 0: off")
+                             "search is one serial chain; beside conv waves a step runs ~8x slower).  -1: by beam width (4, 8 above W = 25, 12 above W = 64: multiples of four -- a masked queue is dealt over four shader engines), 0: off")
     parser.add_argument("--lm-hashed-context", action="store_true",
                         help="global mode: accept a --context-len longer than the RNA model's k-mers (up to 256) by addressing the model's "
                              "table with a hash of the context (a synthetic long-context LM: no reference behaviour -- the reference raises "

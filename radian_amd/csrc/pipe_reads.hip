@@ -285,7 +285,10 @@ constexpr int64_t kGroupRowsCap = 96ll << 20;   // rows a group may gather while
 // 9.16, 9.17 | 5, 6, 7, 8: 10.58, 10.62, 10.61, 10.63 -- the fourth CU of a group of four is free, the fifth costs as much as
 // the eighth.  (Rounds 2-3 used 3 / 5 / 8; 5 was the worst choice on the table.)  32 CUs = 128 SIMDs step ~0.45 M
 // sequence-steps/s each at W = 10 (twice the forward's ~29 M rows/s) and keep up at W = 25; wider beams take a second four.
-inline int auto_part_cus(int W) { return W <= 25 ? 4 : 8; }
+// Round 6: widths 65 ... 128 (five waves per sequence, 13-15 us per step) take a third four: at 8 the partition's 153 resident sequences deliver ~11 M
+// steps/s against a forward of 21 M rows/s; at 12, 230 sequences and 15-16 M against 18 M (tools/policy_probe.py fp32 100 0 <part>: short / long /
+// alternating / ragged streams 10.7 / 9.6 / 11.5 / 9.2 M samples/s at 8, 15.3 / 8.6 / 16.2 / 13.0 at 12, 16.4 / 13.6 / 14.9 / 10.2 at 16).
+inline int auto_part_cus(int W) { return W <= 25 ? 4 : W <= 64 ? 8 : 12; }
 
 struct RSub {                 // one submitted batch inside a group
     int n_seq = 0, seq0 = 0;  // its decoded sequences (global: reads; chunk: windows) = [seq0, seq0 + n_seq) of the group

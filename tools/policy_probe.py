@@ -10,7 +10,7 @@ For a precision mode / beam width, optionally with a second PROCESS keeping the 
   throughput   samples/s of uniform streams (all reads 4096 samples; all reads 40960), of a stream whose batches ALTERNATE
                between the two (the longest read jumps 10x from one batch to the next), same samples per batch, and (round 6) of a stream
                of RAGGED batches (seeded log-normal read lengths 1.5 k ... 60 k: every batch another longest read, read count and plan)
-usage: policy_probe.py [fp32|bf16x3|f16x3] [W=10] [load=0|1]      ->  one JSON line
+usage: policy_probe.py [fp32|bf16x3|f16x3] [W=10] [load=0|1] [partition CUs per XCD = -1: by width]      ->  one JSON line
        policy_probe.py --load-worker SECONDS                      (internal: the background process)"""
 import json, os, subprocess, sys, time
 import numpy as np
@@ -102,7 +102,7 @@ def stream(be, batches, W, n_submits, window_rows=32 << 20):
     return samples / (time.perf_counter() - t0)
 
 
-def probe(prec="fp32", W=10, load=False, quick=False):
+def probe(prec="fp32", W=10, load=False, quick=False, part=-1):
     from radian_amd import Backend, weights
     bg = None
     if load:
@@ -116,6 +116,7 @@ def probe(prec="fp32", W=10, load=False, quick=False):
         be.load_weights(weights.synthetic_weights(seed=1234))
         be.set_precision(prec)
         be.set_decode_math("glibc")
+        be.set_decode_partition(part)            # (-1: the library's choice by beam width)
         short = reads_of(64, 4096, 1)            # 262 144 samples per batch either way
         long_ = reads_of(6, 40960, 2) + reads_of(4, 4096, 3)
         out = {"precision": prec, "W": W, "background_load": bool(load)}
@@ -149,4 +150,4 @@ if __name__ == "__main__":
     if a and a[0] == "--load-worker":
         load_worker(float(a[1]))
     else:
-        print(json.dumps(probe(a[0] if a else "fp32", int(a[1]) if len(a) > 1 else 10, bool(int(a[2])) if len(a) > 2 else False)))
+        print(json.dumps(probe(a[0] if a else "fp32", int(a[1]) if len(a) > 1 else 10, bool(int(a[2])) if len(a) > 2 else False, part=int(a[3]) if len(a) > 3 else -1)))
