@@ -408,9 +408,11 @@ def files_leg(rank, world, be_src, host_budget, rdv_dir, cli, device=0, files_pe
         n_mine = len(host_budget["cpus"]) if (host_budget.get("bound") or host_budget.get("how") != "all") else max(1, len(host_budget["cpus"]) // max(1, world))
         if args.stitch_workers is None and args.decode_type == "chunk":
             args.stitch_workers = hostbudget.threads_for(n_mine, "chunk")["stitch_threads"]
-        make = backend_factory or (lambda: __import__("radian_amd").Backend(device))
+        if backend_factory is None:
+            from radian_amd import Backend
+            backend_factory = lambda: Backend(device)      # noqa: E731 -- (tests pass a device-less stand-in)
         for i in range(basecall.n_contexts(args)):
-            b = make()
+            b = backend_factory()
             bes.append(b)
             basecall.apply_artifacts(args, b, None, clone_from=be_src)
         args._lm_loaded = False
