@@ -379,7 +379,9 @@ def files_leg(rank, world, be_src, host_budget, rdv_dir, cli, device=0, files_pe
     def meet(phase, value="ok"):
         """all ranks reach `phase`, or everyone learns at once that one of them cannot (no waiting for the deadline)"""
         met.add(phase)
+        t_meet = time.time()
         vals = rdv.gather(phase, value)
+        mine.setdefault("waits", {})[phase] = round(time.time() - t_meet, 3)      # (how long this rank stood at the meeting point)
         bad = [f"rank {r}: {v[7:]}" for r, v in enumerate(vals) if v.startswith("failed:")]
         if bad:
             raise RuntimeError("; ".join(bad))
@@ -504,7 +506,7 @@ def files_leg(rank, world, be_src, host_budget, rdv_dir, cli, device=0, files_pe
                     "per_rank": [{"rank": n["rank"], "reads": n["reads"], "samples": n["samples"], "seconds": n["t1"] - n["t0"],
                                   "value": n["samples"] / max(1e-9, n["t1"] - n["t0"]), "cores": n["cores"], "cpus": n["cpus"], "cpu_split": n["cpu_split"],
                                   "cpu_bound": n["cpu_bound"], "numa_node": n["numa_node"], "stitch_threads": n["stitch_threads"],
-                                  "device_contexts": n["device_contexts"]} for n in notes],
+                                  "device_contexts": n["device_contexts"], "waits_s": n.get("waits")} for n in notes],
                     "startup_comm": (comm_info or {}).get("startup_comm"), "rccl_nranks": (comm_info or {}).get("rccl_nranks"),
                     "leg_seconds_incl_input_files_and_warmup": time.time() - t_enter, "input_directory": "memory-backed (/dev/shm)" if root.startswith("/dev/shm") else "temporary directory (disk)",
                     "path": "BASELINE configs[2] from a fast5 directory to FASTA files at N ranks: " + str(n_files) + " multi-read fast5 files (" + str(reads_per_file)
