@@ -354,7 +354,7 @@ def files_leg_reads(file_index, reads_per_file, read_len, seed=70003):
 
 
 def files_leg(rank, world, be_src, host_budget, rdv_dir, cli, device=0, files_per_rank=4, reads_per_file=4096, read_len=READ_LEN,
-              warm_reads=1536, timeout=60.0, backend_factory=None, comm_info=None, keep=None):
+              warm_reads=1536, timeout=60.0, backend_factory=None, comm_info=None, keep=None, lm=None, tag="chunk", what="BASELINE configs[2]"):
     """secondary_e2e_fast5_to_fasta at N > 1 -- the whole job as `radian_amd.basecall ... --gpus N` runs it, inside the bench's ranks:
     a memory-backed directory of multi-read fast5 shards -> per-node FileReadQueue (blocks of 256 reads, file by file) -> native reader ->
     H2D -> mad_normalise -> streamed forward -> beam search -> labels -> strings (chunk mode: native stitch on the rank's host threads) ->
@@ -371,7 +371,7 @@ def files_leg(rank, world, be_src, host_budget, rdv_dir, cli, device=0, files_pe
     import tempfile
     from radian_amd import basecall, dist, fast5, hostbudget, launch
     t_enter = time.time()
-    rdv = dist.Rendezvous(os.path.join(rdv_dir, "files_leg"), rank, world, timeout=timeout)
+    rdv = dist.Rendezvous(os.path.join(rdv_dir, "files_leg_" + tag), rank, world, timeout=timeout)
     root, bes, merger, result = None, [], None, None
     mine = {"rank": rank, "error": None}
     met = set()
@@ -417,7 +417,9 @@ def files_leg(rank, world, be_src, host_budget, rdv_dir, cli, device=0, files_pe
             b = backend_factory()
             bes.append(b)
             basecall.apply_artifacts(args, b, None, clone_from=be_src)
-        args._lm_loaded = False
+            if lm is not None:
+                b.load_lm(lm[0], lm[1])      # (every rank builds the same seeded table: the leg's own model, outside the job's broadcast)
+        args._lm_loaded = lm is not None
         if warm_reads:
             warm = [_MemRead(f"w{i}", r) for i, r in enumerate(list(files_leg_reads(10 ** 6 + rank, min(warm_reads, reads_per_file), read_len).values()))]
             with open(os.devnull, "w") as dn, contextlib.redirect_stdout(dn):
@@ -509,10 +511,10 @@ def files_leg(rank, world, be_src, host_budget, rdv_dir, cli, device=0, files_pe
                                   "device_contexts": n["device_contexts"], "waits_s": n.get("waits")} for n in notes],
                     "startup_comm": (comm_info or {}).get("startup_comm"), "rccl_nranks": (comm_info or {}).get("rccl_nranks"),
                     "leg_seconds_incl_input_files_and_warmup": time.time() - t_enter, "input_directory": "memory-backed (/dev/shm)" if root.startswith("/dev/shm") else "temporary directory (disk)",
-                    "path": "BASELINE configs[2] from a fast5 directory to FASTA files at N ranks: " + str(n_files) + " multi-read fast5 files (" + str(reads_per_file)
+                    "path": what + " from a fast5 directory to FASTA files at N ranks: " + str(n_files) + " multi-read fast5 files (" + str(reads_per_file)
                             + " reads each, written by the ranks before the clock starts, memory-backed) -> per-node FileReadQueue (blocks of 256 reads) -> native "
                               "reader (csrc/fast5.hip) on each rank's read-ahead thread -> H2D -> on-device mad_normalise -> streamed forward -> beam search -> "
-                              "labels D2H -> native stitch on the rank's host threads -> rank files -> StreamMerger in a child process of rank 0 (no GPU; it shares "
+                              "labels D2H -> strings (chunk mode: native stitch on the rank's host threads) -> rank files -> StreamMerger in a child process of rank 0 (no GPU; it shares "
                               "rank 0's core slice) -> reads-<n>.fasta; value = samples / (last rank's end - first rank's start), value_to_merged_fasta = until the "
                               "merged FASTA is closed and renamed into place; ranks synchronise through files, no collective inside the leg",
                 }
@@ -525,7 +527,7 @@ def files_leg(rank, world, be_src, host_budget, rdv_dir, cli, device=0, files_pe
                 merger.kill()
             if root and root != "-":
                 shutil.rmtree(root, ignore_errors=True)
-            shutil.rmtree(os.path.join(rdv_dir, "files_leg"), ignore_errors=True)
+            shutil.rmtree(os.path.join(rdv_dir, "files_leg_" + tag), ignore_errors=True)
     return result
 
 
@@ -586,6 +588,8 @@ def main():
     ap.add_argument("--nrank-files-per-rank", type=int, default=4,
                     help="N > 1: multi-read fast5 files (4096 reads x 4096 samples each) per rank in the files -> FASTA leg through the multi-GPU "
                          "route (secondary_e2e_fast5_to_fasta; ~3 s of basecalling per rank at the default); 0 = no such leg")
+    ap.add_argument("--no-nrank-global-leg", dest="nrank_global_leg", action="store_false",
+                    help="N > 1: skip the second files -> FASTA leg (configs[3]'s geometry: global decode with the 12-mer LM)")
     ap.add_argument("--e2e-reads", type=int, default=32768,
                     help="reads of the raw end-to-end secondary leg (the other driver legs take a half or a sixteenth of it): jobs of a few "
                          "seconds each, so that the fill and drain of the beam-search groups are a few per cent of a leg, as in a real run")
@@ -1066,6 +1070,19 @@ def main():
                 sec["secondary_e2e_fast5_to_fasta"] = leg
                 note(f"  {leg['value'] / 1e6:.2f} M samples/s over {world} ranks ({leg['seconds']:.2f} s; merged FASTA after {leg['seconds_to_merged_fasta']:.2f} s)"
                      if leg and "value" in leg else f"  skipped: {leg}")
+            # ... and BASELINE configs[3]'s geometry, the one its scaling curve is quoted on: --decode-type global (assembly + one LM-gated beam search per
+            # read), beam 10, the 12-mer RNA model (4^11-row table, Dirichlet(0.3) seed 0, built by every rank), thresholds 0.5 / 0.5 -- same files route
+            if args.nrank_global_leg:
+                note(f"rank {rank}: secondary_e2e_fast5_to_fasta_global_lm at {world} ranks")
+                table = np.random.default_rng(0).dirichlet([0.3] * 4, size=4 ** 11)
+                leg_g = files_leg(rank, world, be, host_budget, leg_dir,
+                                  ["--decode-type", "global", "--step-size", str(STEP), "--chunk-len", str(CHUNK), "--beam-width", str(BEAM), "--rna-model", "None"],
+                                  device=device, files_per_rank=args.nrank_files_per_rank, comm_info={"startup_comm": comm_kind, "rccl_nranks": rccl_nranks},
+                                  lm=(table, 11), tag="global", what="BASELINE configs[3]'s geometry (global decode, beam 10, 12-mer LM 0.5 / 0.5)")
+                del table
+                if rank == 0:
+                    sec["secondary_e2e_fast5_to_fasta_global_lm"] = leg_g
+                    note(f"  {leg_g['value'] / 1e6:.2f} M samples/s over {world} ranks ({leg_g['seconds']:.2f} s)" if leg_g and "value" in leg_g else f"  skipped: {leg_g}")
                 if "RD_BENCH_RDV" not in os.environ:
                     try:
                         os.rmdir(leg_dir)

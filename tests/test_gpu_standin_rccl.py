@@ -72,6 +72,10 @@ def test_bench_four_ranks_broadcast_through_the_collective_seam(standin_env):
     assert leg["value"] > 1e6 and leg["value_to_merged_fasta"] > 1e6 and leg["rccl_nranks"] == WORLD and leg["startup_comm"] == "rccl"
     assert [p["rank"] for p in leg["per_rank"]] == list(range(WORLD)) and sum(p["reads"] for p in leg["per_rank"]) == WORLD * 4096
     assert all(p["reads"] > 0 and p["value"] > 0 and p["cores"] >= 1 for p in leg["per_rank"])
+    # ... and the same route at configs[3]'s geometry (global decode, 12-mer LM): the configuration BASELINE.json quotes its scaling curve on
+    leg_g = d["secondary_e2e_fast5_to_fasta_global_lm"]
+    assert "skipped" not in leg_g, leg_g
+    assert leg_g["n_ranks"] == WORLD and leg_g["records_written"] == WORLD * 4096 and leg_g["value"] > 1e6 and "--decode-type global" in leg_g["cli"]
 
 
 @pytest.mark.parametrize("mode,model", [("chunk", "none"), ("global", "dense"), ("global", "sparse")])
