@@ -588,8 +588,9 @@ def main():
     ap.add_argument("--nrank-files-per-rank", type=int, default=4,
                     help="N > 1: multi-read fast5 files (4096 reads x 4096 samples each) per rank in the files -> FASTA leg through the multi-GPU "
                          "route (secondary_e2e_fast5_to_fasta; ~3 s of basecalling per rank at the default); 0 = no such leg")
-    ap.add_argument("--no-nrank-global-leg", dest="nrank_global_leg", action="store_false",
-                    help="N > 1: skip the second files -> FASTA leg (configs[3]'s geometry: global decode with the 12-mer LM)")
+    ap.add_argument("--nrank-legs", default="chunk,global",
+                    help="N > 1: which files -> FASTA legs run through the multi-GPU route: chunk (configs[2]), global (configs[3]'s geometry: global decode "
+                         "with the 12-mer LM), or both (default)")
     ap.add_argument("--e2e-reads", type=int, default=32768,
                     help="reads of the raw end-to-end secondary leg (the other driver legs take a half or a sixteenth of it): jobs of a few "
                          "seconds each, so that the fill and drain of the beam-search groups are a few per cent of a leg, as in a real run")
@@ -1054,7 +1055,8 @@ def main():
                 except Exception as e:
                     print(f"[bench] {key} failed: {e}", file=sys.stderr)
         del table
-    if world > 1 and args.precision == "fp32" and not args.no_secondary and not args.windowed and args.nrank_files_per_rank > 0:
+    nrank_legs = [x for x in args.nrank_legs.split(",") if x in ("chunk", "global")]
+    if world > 1 and args.precision == "fp32" and not args.no_secondary and not args.windowed and args.nrank_files_per_rank > 0 and nrank_legs:
         # The one leg of the N > 1 line: the job from a fast5 directory to FASTA files through the product's multi-GPU
         # route, every rank on its own core slice -- the host feed SURVEY 8e names as the scaling limit.  Every rank takes part; the
         # ranks meet through files (own launcher: its rendezvous directory; foreign launcher: a directory named after its pid).
@@ -1063,16 +1065,18 @@ def main():
             from radian_amd import dist as _dist
             leg_dir = os.environ.get("RD_BENCH_RDV") or (_dist.uid_path() + "_legs")
             os.makedirs(leg_dir, exist_ok=True)
-            leg = files_leg(rank, world, be, host_budget, leg_dir,
-                            ["--decode-type", "chunk", "--step-size", str(STEP), "--chunk-len", str(CHUNK), "--beam-width", str(BEAM), "--rna-model", "None"],
-                            device=device, files_per_rank=args.nrank_files_per_rank, comm_info={"startup_comm": comm_kind, "rccl_nranks": rccl_nranks})
-            if rank == 0:
+            leg = None
+            if "chunk" in nrank_legs:
+                leg = files_leg(rank, world, be, host_budget, leg_dir,
+                                ["--decode-type", "chunk", "--step-size", str(STEP), "--chunk-len", str(CHUNK), "--beam-width", str(BEAM), "--rna-model", "None"],
+                                device=device, files_per_rank=args.nrank_files_per_rank, comm_info={"startup_comm": comm_kind, "rccl_nranks": rccl_nranks})
+            if rank == 0 and "chunk" in nrank_legs:
                 sec["secondary_e2e_fast5_to_fasta"] = leg
                 note(f"  {leg['value'] / 1e6:.2f} M samples/s over {world} ranks ({leg['seconds']:.2f} s; merged FASTA after {leg['seconds_to_merged_fasta']:.2f} s)"
                      if leg and "value" in leg else f"  skipped: {leg}")
             # ... and BASELINE configs[3]'s geometry, the one its scaling curve is quoted on: --decode-type global (assembly + one LM-gated beam search per
             # read), beam 10, the 12-mer RNA model (4^11-row table, Dirichlet(0.3) seed 0, built by every rank), thresholds 0.5 / 0.5 -- same files route
-            if args.nrank_global_leg:
+            if "global" in nrank_legs:
                 note(f"rank {rank}: secondary_e2e_fast5_to_fasta_global_lm at {world} ranks")
                 table = np.random.default_rng(0).dirichlet([0.3] * 4, size=4 ** 11)
                 leg_g = files_leg(rank, world, be, host_budget, leg_dir,
@@ -1083,14 +1087,16 @@ def main():
                 if rank == 0:
                     sec["secondary_e2e_fast5_to_fasta_global_lm"] = leg_g
                     note(f"  {leg_g['value'] / 1e6:.2f} M samples/s over {world} ranks ({leg_g['seconds']:.2f} s)" if leg_g and "value" in leg_g else f"  skipped: {leg_g}")
-                if "RD_BENCH_RDV" not in os.environ:
-                    try:
-                        os.rmdir(leg_dir)
-                    except OSError:
-                        pass
+            if rank == 0 and "RD_BENCH_RDV" not in os.environ:
+                try:
+                    os.rmdir(leg_dir)
+                except OSError:
+                    pass
         except BaseException as e:   # noqa: BLE001 -- never at the headline's cost
             if rank == 0:
-                sec["secondary_e2e_fast5_to_fasta"] = {"skipped": f"{type(e).__name__}: {e}", "n_ranks": world}
+                for name, key in (("chunk", "secondary_e2e_fast5_to_fasta"), ("global", "secondary_e2e_fast5_to_fasta_global_lm")):
+                    if name in nrank_legs and key not in sec:
+                        sec[key] = {"skipped": f"{type(e).__name__}: {e}", "n_ranks": world}
     if stitch_pool is not None:
         stitch_pool.shutdown()
     halo = 252

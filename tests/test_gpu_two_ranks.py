@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_launches_two_ranks_itself():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--preheat-ms", "0", "--regions", "2",
-                        "--nrank-files-per-rank", "1", "--no-nrank-global-leg"],
+                        "--nrank-files-per-rank", "1", "--nrank-legs", "chunk"],
                        env=dict(os.environ, RD_BENCH_DEVICE="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
