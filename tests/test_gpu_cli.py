@@ -327,10 +327,13 @@ def test_cli_sparse_rna_model_fails_like_the_reference(tmp_path, golden_dir, ora
         be.load_lm(t, k)
         labs, status = be.basecall_raw_global(raws, 4, 1024, 512, 6, True, 0.0, 9.0)
         bad = [i for i, l in enumerate(labs) if l is None]
-        # the oracle agrees read by read on the GPU's own probabilities
-        for i, mat in enumerate(omats):
-            exp = oracle.beam_search_batch(mat, [0], [mat.shape[0]], 6, t, 0.0, 9.0, k)[0]
-            assert (exp is None) == (labs[i] is None) and (exp is None or np.array_equal(exp, labs[i])), (c, i)
+        splits = bool(bad) and bad[0] >= 1 and (len(bad) < len(ids) or c >= 12)
+        # the oracle agrees read by read on the GPU's own probabilities (checked for the first two contexts and for the one the test goes on
+        # with -- round 6, suite budget: the oracle's five searches per context were most of this test's 29 s)
+        if c < 2 or splits:
+            for i, mat in enumerate(omats):
+                exp = oracle.beam_search_batch(mat, [0], [mat.shape[0]], 6, t, 0.0, 9.0, k)[0]
+                assert (exp is None) == (labs[i] is None) and (exp is None or np.array_equal(exp, labs[i])), (c, i)
         if bad and bad[0] >= 1 and len(bad) < len(ids):
             assert all(labs[i] is None or np.array_equal(labs[i], full[i]) for i in range(len(ids)))
             found = (c, bad)
