@@ -16,6 +16,13 @@ GPU), stops the job when one of them fails, and forwards rank 0's single JSON li
 variables itself (e.g. `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) is honoured too: then
 the ranks find each other through a directory named after that launcher's pid.  No PyTorch in any bench process: the
 128-byte RCCL id travels through the rendezvous directory, barrier and max-over-ranks through RCCL (rd_rccl_*).
+
+The line: `value` = the median of --regions (3) timed regions of K steps each (`value_runs`: all of them); `roofline` = the dominant
+kernel against the fp32-MFMA peak from live HIP events, launch-weighted, with `by_variant`; `cpu_baseline` = the oracle port on the host's
+cores.  N = 1 adds secondary legs (other precisions, forward only, the literal windowed job, peaky decode-only, global + LM, heads of other
+base densities, raw and files -> FASTA end to end); N > 1 adds the files -> FASTA legs through the multi-GPU route inside the ranks
+(files_leg: work queue, native reader, per-rank core slice, rank files, merger process) -- the host feed that SURVEY 8e names as the
+scaling limit, which the HBM-resident headline cannot see.
 """
 import argparse
 import json
