@@ -94,7 +94,16 @@ def test_policy_figures_and_alternating_stream_fp32_beam10():
     assert min(d["samples_per_s_short"], d["samples_per_s_long"], d["samples_per_s_alternating"], d["samples_per_s_ragged"]) > 12e6      # (nothing collapsed: ~20-28 M each)
 
 
+def test_alternating_stream_wide_beam_bf16x3():
+    d = _probe("bf16x3", 25, False, factor=2.5)
+    _check_figures(d, factor=2.5)       # (W = 25: three chains per SIMD step at 4.3-5.8 us against a lone chain's 2.5)
+    assert d["alternating_over_steady"] >= BAR, d["ratio_runs"]
+    assert d["ragged_over_steady"] >= BAR, d["ragged_runs"]
+
+
 def test_policy_follows_a_gpu_shared_with_another_process():
+    # (the last test of the file: the GPU work its background process had queued drains for a moment after the process is gone, and a probe that
+    # starts right behind it measured its first figures at half pace -- forward 57 ns per row against 27 -- and had to measure again)
     import policy_probe
     try:
         d = _probe("fp32", 10, True, factor=2.5)
@@ -104,10 +113,3 @@ def test_policy_follows_a_gpu_shared_with_another_process():
     # of a lone wave came out at 2.2 against 4.5 us in one of six runs -- a window in which the other process was between launches)
     _check_figures(d, factor=2.5)
     assert d["alternating_over_steady"] >= BAR, d["ratio_runs"]
-
-
-def test_alternating_stream_wide_beam_bf16x3():
-    d = _probe("bf16x3", 25, False, factor=2.5)
-    _check_figures(d, factor=2.5)       # (W = 25: three chains per SIMD step at 4.3-5.8 us against a lone chain's 2.5)
-    assert d["alternating_over_steady"] >= BAR, d["ratio_runs"]
-    assert d["ragged_over_steady"] >= BAR, d["ragged_runs"]
