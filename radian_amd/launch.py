@@ -238,6 +238,15 @@ def run_ranks(world, cmd, env_extra=None, capture_rank0=False, on_poll=None):
     return rcs, b"".join(chunks).decode("utf-8", "replace")
 
 
+def package_env():
+    """PYTHONPATH for child processes that must import this package whatever the working directory is: the reference is run from the directory
+    that holds models/ (basecall.py:28-30), the top-level basecall.py finds the package beside itself through sys.path -- which a child process
+    started with `python -m radian_amd.launch` does not inherit."""
+    parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    old = os.environ.get("PYTHONPATH", "")
+    return {"PYTHONPATH": parent + (os.pathsep + old if old else "")}
+
+
 def run_multi_gpu(args, argv):
     from . import fast5
     from .basecall import load_artifacts, save_artifacts
@@ -252,7 +261,7 @@ def run_multi_gpu(args, argv):
             json.dump(fast5.list_files(args.fast5_dir), f)   # one enumeration: every rank sees the same file order
         merger = StreamMerger(scratch, world, args.fasta_dir)
         cmd = [sys.executable, "-m", "radian_amd.launch", "--worker", scratch, "--"] + list(argv)
-        rcs, _ = run_ranks(world, cmd, on_poll=merger.poll)   # the FASTA grows while the ranks work
+        rcs, _ = run_ranks(world, cmd, env_extra=package_env(), on_poll=merger.poll)   # the FASTA grows while the ranks work
         if any(rcs):
             raise SystemExit(f"multi-GPU run failed: worker exit codes {rcs}")
         n = merger.finish()

@@ -356,6 +356,22 @@ def test_bench_nrank_files_leg_with_stub_ranks(tmp_path, capfd, oracle):
     assert not glob.glob("/dev/shm/radian_bench_nrank_*") and not os.path.exists(str(tmp_path / "none"))
 
 
+def test_workers_find_the_package_from_a_foreign_working_directory(tmp_path):
+    """`python3 /path/to/repo/basecall.py in out --gpus N` from the directory that holds models/ (the reference's way, basecall.py:28-30): the
+    parent finds the package beside the script, but its rank processes are `python -m radian_amd.launch --worker ...` children that inherit
+    neither sys.path nor the cwd's luck -- launch.package_env() puts the package's parent on their PYTHONPATH (round 6: they failed with
+    ModuleNotFoundError before)."""
+    from radian_amd import launch
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    code = ("import os, sys; from radian_amd import launch; os.chdir(sys.argv[1]); "
+            "rcs, _ = launch.run_ranks(2, [sys.executable, '-c', 'import radian_amd.launch, radian_amd.basecall'], env_extra=launch.package_env()); "
+            "bad, _ = launch.run_ranks(2, [sys.executable, '-c', 'import radian_amd.launch']); print(rcs, bad)")
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == "[0, 0] [1, 1]", (r.stdout, r.stderr[-500:])
+    assert launch.package_env()["PYTHONPATH"].split(os.pathsep)[0] == ROOT
+
+
 def test_bench_parent_never_loads_the_hip_library(tmp_path):
     """The launcher process of `bench.py --gpus N` must not touch a GPU: it runs to completion (here: to the failure of its
     ranks, which have no GPU) without libradian_hip.so ever being mapped -- RADIAN_HIP_LIB points at a file that is not a

@@ -49,7 +49,14 @@ def test_cli_two_ranks_equal_single_process(tmp_path, mode):
         cmd = [sys.executable, "-m", "radian_amd.basecall", str(in_dir), str(out), "--decode-type", mode, "--step-size", "512", "--beam-width", "6",
                "--sig-model", "synthetic:1234", "--sig-config", "none", "--rna-model", "None", "--gpus", str(g), "--queue-block", "16",
                "--gpu-batch-windows", "64"]
-        r = subprocess.run(cmd, env=dict(os.environ, RD_CLI_DEVICE="0", PYTHONPATH=ROOT), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        env, cwd = dict(os.environ, RD_CLI_DEVICE="0", PYTHONPATH=ROOT), ROOT
+        if g == 2 and mode == "global":
+            # round 6: the two-rank run through the reference's literal entry point from a foreign working directory, nothing on PYTHONPATH -- the
+            # rank processes must find the package by themselves (launch.package_env)
+            cmd[1:3] = [os.path.join(ROOT, "basecall.py")]
+            env = {k: v for k, v in env.items() if k != "PYTHONPATH"}
+            cwd = str(tmp_path)
+        r = subprocess.run(cmd, env=env, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         outs[g] = open(out / "reads-0.fasta").read()
     assert outs[1] == outs[2] and outs[1].count(">") == 150
