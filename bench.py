@@ -1061,6 +1061,15 @@ def main():
                         "BASELINE configs[2] from a fast5 directory to FASTA files"), files=filters)
                 except Exception as e:
                     print(f"[bench] {key} failed: {e}", file=sys.stderr)
+            # ... and at configs[3]'s geometry (global decode, beam 10, the 12-mer LM): the N = 1 point of the N-rank leg of the same name
+            note("secondary_e2e_fast5_to_fasta_global_lm")
+            try:
+                sec["secondary_e2e_fast5_to_fasta_global_lm"] = driver_leg(
+                    device, stitch_pool, ["--decode-type", "global", "--step-size", str(STEP), "--chunk-len", str(CHUNK), "--beam-width", str(BEAM), "--rna-model", "None"],
+                    np.full(args.e2e_reads // 2, READ_LEN, dtype=np.int64), 70003, w0, lm=(table, 11),
+                    desc="BASELINE configs[3]'s geometry (global decode, beam 10, 12-mer LM 0.5 / 0.5) from a fast5 directory to FASTA files", files=())
+            except Exception as e:
+                print(f"[bench] secondary_e2e_fast5_to_fasta_global_lm failed: {e}", file=sys.stderr)
         del table
     nrank_legs = [x for x in args.nrank_legs.split(",") if x in ("chunk", "global")]
     if world > 1 and args.precision == "fp32" and not args.no_secondary and not args.windowed and args.nrank_files_per_rank > 0 and nrank_legs:
