@@ -67,13 +67,21 @@ def _probe(prec, W, load, factor=2.0):
     d.setdefault("ragged_over_steady", 1.0)
     d["ragged_runs"] = [d["ragged_over_steady"]]
     d["figures"] = _figures_ok(d, factor)
-    if d["alternating_over_steady"] < BAR or d["ragged_over_steady"] < BAR or not d["figures"][0]:
+    if d["alternating_over_steady"] >= BAR and d["ragged_over_steady"] >= BAR and not d["figures"][0] and not load:
+        # only the independent figures missed (in the full suite the first blocking calls of a bf16x3 context have come out at 57-70 ns per row
+        # against 27 alone): measure THEM again, in a fresh context, and judge the policy's figures -- which stand -- against the new ones
+        warnings.warn(f"figures {d['figures']} ({prec}, W = {W}): measuring the independent figures once more")
+        d["independent_long_first"] = d["independent_long"]
+        d["independent_long"] = policy_probe.independent_only(prec, W)
+        print("independent figures, second measurement:", d["independent_long"])
+        d["figures"] = _figures_ok(d, factor)
+    elif d["alternating_over_steady"] < BAR or d["ragged_over_steady"] < BAR or not d["figures"][0]:
         warnings.warn(f"alternating / steady = {d['alternating_over_steady']:.3f}, ragged / steady = {d['ragged_over_steady']:.3f}, bar {BAR}; figures "
                       f"{d['figures']} ({prec}, W = {W}, load = {load}): measuring once more")
         d2 = policy_probe.probe(prec, W, load=load, ragged=not load)
         print("second measurement:", {k: v for k, v in d2.items() if not k.startswith("policy")})
-        runs = [d["alternating_over_steady"], d2["alternating_over_steady"]]
         d2.setdefault("ragged_over_steady", 1.0)
+        runs = [d["alternating_over_steady"], d2["alternating_over_steady"]]
         rruns = [d["ragged_over_steady"], d2["ragged_over_steady"]]
         d = d2
         d["ratio_runs"], d["ragged_runs"] = runs, rruns

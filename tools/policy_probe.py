@@ -102,6 +102,20 @@ def stream(be, batches, W, n_submits, window_rows=32 << 20):
     return samples / (time.perf_counter() - t0)
 
 
+def independent_only(prec="fp32", W=10):
+    """the independent figures alone (a fresh context, the long batch): what tests/test_gpu_policy.py measures again when a probe's figures
+    -- not its throughput ratios -- missed"""
+    from radian_amd import Backend, weights
+    be = Backend(0)
+    try:
+        be.load_weights(weights.synthetic_weights(seed=1234))
+        be.set_precision(prec)
+        be.set_decode_math("glibc")
+        return independent(be, reads_of(6, 40960, 2) + reads_of(4, 4096, 3), W)
+    finally:
+        be.close()
+
+
 def probe(prec="fp32", W=10, load=False, quick=False, part=-1, ragged=True):
     from radian_amd import Backend, weights
     bg = None
