@@ -372,6 +372,48 @@ def test_workers_find_the_package_from_a_foreign_working_directory(tmp_path):
     assert launch.package_env()["PYTHONPATH"].split(os.pathsep)[0] == ROOT
 
 
+def test_merge_watch_ends_with_the_ranks_or_at_its_deadline(tmp_path):
+    """launch.merge_watch (round 6: the merging half of the multi-GPU route as a process of its own, bench.py's N-rank legs): merges while the rank
+    files grow, returns when every rank has written its end mark; a rank that never ends makes it raise TimeoutError with no partial FASTA left
+    behind (the hidden directory is removed)."""
+    import threading
+    import time
+    from radian_amd import launch
+    scratch, out = tmp_path / "s", tmp_path / "o"
+    scratch.mkdir()
+    out.mkdir()
+
+    def rank(r, n, end=True, delay=0.0):
+        f = launch._RankFile(str(scratch / f"rank{r}.jsonl"))
+        f.claim(r, 0, n)
+        for i in range(n):
+            f.emit((r, i), f"read-{r}-{i}", "ACGT" * (i + 1))
+            time.sleep(delay)
+        if end:
+            f.end()
+        else:
+            f.f.flush()
+    ths = [threading.Thread(target=rank, args=(r, 30, True, 0.002)) for r in range(3)]
+    for t in ths:
+        t.start()
+    res = launch.merge_watch(str(scratch), 3, str(out), timeout=30.0)
+    for t in ths:
+        t.join()
+    assert res["records"] == 90 and sorted(os.listdir(out)) == ["reads-0.fasta"]
+    ids = [ln[1:].strip() for ln in open(out / "reads-0.fasta") if ln.startswith(">")]
+    assert ids == [f"read-{r}-{i}" for r in range(3) for i in range(30)]
+    # a rank that never writes its end mark: TimeoutError, nothing left in the output directory
+    for f in os.listdir(scratch):
+        os.remove(scratch / f)
+    os.remove(out / "reads-0.fasta")
+    rank(0, 5, end=True)
+    rank(1, 5, end=False)
+    t0 = time.time()
+    with pytest.raises(TimeoutError, match=r"ranks \[1\]"):
+        launch.merge_watch(str(scratch), 2, str(out), timeout=1.0)
+    assert time.time() - t0 < 10 and os.listdir(out) == []
+
+
 def test_bench_parent_never_loads_the_hip_library(tmp_path):
     """The launcher process of `bench.py --gpus N` must not touch a GPU: it runs to completion (here: to the failure of its
     ranks, which have no GPU) without libradian_hip.so ever being mapped -- RADIAN_HIP_LIB points at a file that is not a
