@@ -477,6 +477,10 @@ def files_leg(rank, world, be_src, host_budget, rdv_dir, cli, device=0, files_pe
     except Exception as e:
         notes = None
         mine["error"] = mine["error"] or f"{type(e).__name__}: {e}"
+    try:
+        rdv.publish("bye", "1")      # (this rank has read what it needs: rank 0 removes the meeting directory only when everyone has said so --
+    except OSError:                  # it used to remove it right after its own "done", under the feet of a rank still polling for rank 0's note,
+        pass                         # which then sat out the whole deadline)
     if rank == 0:
         try:
             merged = None
@@ -532,6 +536,9 @@ def files_leg(rank, world, be_src, host_budget, rdv_dir, cli, device=0, files_pe
         finally:
             if merger is not None and merger.poll() is None:
                 merger.kill()
+            t_bye = time.time()
+            while len(rdv.peek("bye")) < world and time.time() - t_bye < 15.0:
+                time.sleep(0.005)
             if root and root != "-":
                 shutil.rmtree(root, ignore_errors=True)
             shutil.rmtree(os.path.join(rdv_dir, "files_leg_" + tag), ignore_errors=True)
