@@ -49,7 +49,7 @@ const char* rd_last_error(void);
 int rd_version(void);                 /* ABI version, currently 1 */
 int rd_device_count(int* n);          /* number of visible HIP devices */
 int rd_decode_max_width(void);        /* largest supported --beam-width (1024; radian/decode.py:145 slices with any width) */
-int rd_decode_lane_width(void);       /* widths up to this (128) run on the wave-per-sequence kernels, wider ones on the general kernel */
+int rd_decode_lane_width(void);       /* widths up to this (256) run on the wave-per-sequence kernels, wider ones on the general kernel */
 
 /* ---- context ------------------------------------------------------------------------------- */
 int rd_create(int device_id, rd_ctx** out);
@@ -116,7 +116,7 @@ int rd_set_logits(rd_ctx* ctx, int mode);
  * pipeline's forward streams are CU-masked to the others) and run the beam search.  A read's search is one serial chain of
  * a time step per sample; a beam-search wave that shares its SIMD with conv waves issuing MFMAs back to back gets about one
  * instruction issue per MFMA (17 us per step measured instead of 2).  -1 (default) = by beam width (4 CUs per XCD, 8 above
- * W = 25, 12 above W = 64: 12.5, 25 or 37.5 % of the chip; a masked queue's CUs are dealt over the four shader engines of an XCD and the forward
+ * W = 25, 12 above W = 64, 16 above W = 128: 12.5 ... 50 % of the chip; a masked queue's CUs are dealt over the four shader engines of an XCD and the forward
  * runs at the pace of the engine left with the fewest, so only multiples of four are worth setting), 0 = off (groups then
  * grow until their forward rows cover the slow chain). */
 int rd_set_decode_partition(rd_ctx* ctx, int cus_per_xcd);

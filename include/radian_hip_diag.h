@@ -30,7 +30,7 @@ int rd_set_conv_fuse(rd_ctx* ctx, int on);
  * Widths up to 6 (the reference's default, basecall.py:32) run two sequences per wave (one candidate per lane of a half-wave);
  * widths 7..12 run ONE sequence per wave under form 0 -- two per wave (two candidates per lane) exists and measured slower, so
  * only form 3 selects it; 3 = two per wave whenever the width allows (up to 12), 4 = always one per wave.  Widths above
- * rd_decode_lane_width() run on the general kernel whatever the form.  5 = every launch (widths up to 128, no hashed
+ * rd_decode_lane_width() run on the general kernel whatever the form.  5 = every launch (widths up to 256, no hashed
  * contexts) through the work-queue kernel with 16 waves' worth of workgroups: the form the reads pipeline uses, with the partition's
  * resident count, for a group that holds more sequences than its decode partition.  For tests and measurements. */
 int rd_set_decode_form(rd_ctx* ctx, int form);

@@ -73,7 +73,7 @@ def build_parser():
                              "search)")
     parser.add_argument("--decode-partition", default=-1, type=int,
                         help="global mode, pipelined: CUs of each XCD kept free of forward workgroups for the beam search (a read's "
-                             "search is one serial chain; beside conv waves a step runs ~8x slower).  -1: by beam width (4, 8 above W = 25, 12 above W = 64: multiples of four -- a masked queue is dealt over four shader engines), 0: off -- on steady exact-fp32 jobs at beam <= 25 the search "
+                             "search is one serial chain; beside conv waves a step runs ~8x slower).  -1: by beam width (4, 8 above W = 25, 12 above W = 64, 16 above W = 128: multiples of four -- a masked queue is dealt over four shader engines), 0: off -- on steady exact-fp32 jobs at beam <= 25 the search "
                              "then runs on every CU beside the forward and the job 3-8 %% faster (measured, profiles/r06_policy_probe.txt), but long-read jobs with an RNA "
                              "model and the f16x3 / bf16x3 modes lose: not the default")
     parser.add_argument("--lm-hashed-context", action="store_true",

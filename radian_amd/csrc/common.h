@@ -232,7 +232,7 @@ void rd_rpipe_destroy(rd_ctx* ctx);
 inline bool rd_decode_len_ok(int W, int64_t rows) { return 1 + (int64_t)W * rows < ((int64_t)1 << 29); }
 
 extern "C" int rd_decode_max_width(void);
-constexpr int RD_LANE_MAX_W = 128;     // decode.hip: the wave-per-sequence kernels' widest beam (rd_decode_lane_width)
+constexpr int RD_LANE_MAX_W = 256;     // decode.hip: the wave-per-sequence kernels' widest beam (rd_decode_lane_width)
 constexpr int RD_HASHED_MAX_W = 64;    // ... and the widest one with hashed long contexts (rd_load_lm_hashed)
 // decode_wide.hip: beam widths above RD_LANE_MAX_W, up to RD_WIDE_MAX_W (40 W bytes of LDS for the ranking keys)
 constexpr int RD_WIDE_MAX_W = 1024;

@@ -101,10 +101,12 @@ __device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int 
     // R > 1 form is for (many sequences)
     constexpr int KG = R == 1 ? 16 : 4;
     constexpr int SEG = 64 + KG;        // doubles per segment: 64 keys + the padding of the last group
-    constexpr int HB = (WM + 63) / 64;  // halves of the beam set: per-beam lanes handle beam lane + 64 h
-    constexpr int LOG_TN = WM > 64 ? 11 : R * NW <= 2 ? 9 : 10;
-    constexpr int TN = 1 << LOG_TN;     // (LDS per sequence bounds the resident waves: 2 KiB / 4 KiB; 8 KiB for 128 beams)
-    static_assert(WM <= 64 * HB && HB <= 2, "the kept beams fit the lanes of one wave, once or twice");
+    constexpr int HB = (WM + 63) / 64;  // 64-beam parts of the beam set: per-beam lanes handle beam lane + 64 h
+    constexpr int LOG_TN = WM > 128 ? 12 : WM > 64 ? 11 : R * NW <= 2 ? 9 : 10;
+    constexpr int TN = 1 << LOG_TN;     // (LDS per sequence bounds the resident waves: 2 KiB / 4 KiB; 8 / 16 KiB for 128 / 256 beams)
+    constexpr int SB = WM > 128 ? 9 : 8;            // bits of a beam index inside d_sel (all ones = none)
+    constexpr int SMASK = (1 << SB) - 1;
+    static_assert(WM <= 64 * HB && HB <= 4 && WM <= 256, "the kept beams fit the lanes of one wave, up to four times; a table entry holds a slot in 8 bits");
     static_assert(HB == 1 || !HC, "hashed contexts exist for up to 64 beams");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -132,7 +134,7 @@ __device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int 
     double* const mQ = dbuf + 4 * WM;
     double* const keyC = NW == 1 ? dbuf : dbuf + SCR + (SCR & 1);   // 16-B aligned: keys of the ranking's survivors, compacted per segment
     __shared__ int mb_q[WM];
-    __shared__ int d_sel[WM], newslot[WM];   // d_sel: who fills new slot r = (copied beam or 0xff) | parent beam << 8 | (1 + label) << 16
+    __shared__ int d_sel[WM], newslot[WM];   // d_sel: who fills new slot r = (copied beam or all ones) | parent beam << SB | (1 + label) << 2 SB  (SB = 8; 9 for 256 beams)
     __shared__ unsigned claims[WM];
     __shared__ double lp[64][5];
     __shared__ double praw[LM ? 64 : 1][5];
@@ -512,7 +514,7 @@ __device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int 
                         const int r = rank[s];
                         *(double2*)&ns[r].ptot = make_double2(c_ptot[s], c_pb[s]);
                         ns[r].pnb = c_pnb[s];
-                        d_sel[r] = (dcopy[s] & 0xff) | (bi[s] << 8) | (kk[s] << 16);
+                        d_sel[r] = (dcopy[s] & SMASK) | (bi[s] << SB) | (kk[s] << (2 * SB));
                         atomicAdd(&claims[r], 1u);
                         if (dcopy[s] >= 0) newslot[dcopy[s]] = r;
                     }
@@ -670,10 +672,10 @@ __device__ __forceinline__ void beam_search_body(const DecodeArgs& a, const int 
                     for (int h = 0; h < HB; h++) {
                         const int bl = lane + 64 * h;
                         const bool act = bl < nb_new;
-                        const int j = act ? (sel[h] & 0xff) : 0;                // copied beam (0xff: none)
-                        const int par = act ? (sel[h] >> 8) & 0xff : 0;
-                        const int cl = act ? (sel[h] >> 16) - 1 : 0;
-                        const bool is_ext = act && j == 0xff;
+                        const int j = act ? (sel[h] & SMASK) : 0;               // copied beam (all ones: none)
+                        const int par = act ? (sel[h] >> SB) & SMASK : 0;
+                        const int cl = act ? (sel[h] >> (2 * SB)) - 1 : 0;
+                        const bool is_ext = act && j == SMASK;
                         const int src = is_ext ? par : j;
                         const int4 meta = *(const int4*)&os[src].node;       // node, hist, pad, pad
                         const int2 sl2 = *(const int2*)&os[src].last;        // last, len
@@ -1274,7 +1276,8 @@ constexpr int kMaxW = Cfg<1, 4>::WM;
 static_assert(Cfg<2, 2>::WM == kMaxW, "both forms cover the same widths");
 constexpr int kMaxW2 = Cfg<2, 4>::WM;   // 64: widths 52 ... 64 on four waves with two candidates per lane
 constexpr int kMaxW3 = Cfg<2, 5>::WM;   // 128: widths 65 ... 128 on five waves with two candidates per lane, the beam set in two halves (round 6)
-static_assert(kMaxW3 == RD_LANE_MAX_W && kMaxW2 == RD_HASHED_MAX_W, "common.h's figures are this file's");
+constexpr int kMaxW4 = Cfg<2, 10>::WM;  // 256: widths 129 ... 256 on ten waves, the beam set in four parts (one workgroup per CU: 81 KB of LDS)
+static_assert(kMaxW4 == RD_LANE_MAX_W && kMaxW2 == RD_HASHED_MAX_W, "common.h's figures are this file's");
 
 template <typename PT, int R, int NW, bool GX>
 int launch_g(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
@@ -1311,8 +1314,9 @@ int launch_queue_pt(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm, int
     // one workgroup = 1 / 2 / 4 waves for W <= 12 / 25 / 51 (the shapes part_seq_limit counts with); round 6: 4 waves with two candidates per
     // lane up to 64, 5 waves up to 128 (a global-mode stream at W = 100 whose groups could not go through the queue fell to 2.9 M samples/s
     // on alternating read lengths: the groups closed at the partition's sequence limit, covered or not)
-    const int nw = a.W <= Cfg<1, 1>::WM ? 1 : a.W <= Cfg<1, 2>::WM ? 2 : a.W <= kMaxW2 ? 4 : 5;
+    const int nw = a.W <= Cfg<1, 1>::WM ? 1 : a.W <= Cfg<1, 2>::WM ? 2 : a.W <= kMaxW2 ? 4 : a.W <= kMaxW3 ? 5 : 10;
     const int slots = std::max(1, std::min(n_seq, wave_slots / nw));
+    if (a.W > kMaxW3) return a.glibc_math ? launch_qg<PT, 2, 10, true>(st, a, n_seq, lm, slots, counter) : launch_qg<PT, 2, 10, false>(st, a, n_seq, lm, slots, counter);
     if (a.W > kMaxW2) return a.glibc_math ? launch_qg<PT, 2, 5, true>(st, a, n_seq, lm, slots, counter) : launch_qg<PT, 2, 5, false>(st, a, n_seq, lm, slots, counter);
     if (a.W > kMaxW) return a.glibc_math ? launch_qg<PT, 2, 4, true>(st, a, n_seq, lm, slots, counter) : launch_qg<PT, 2, 4, false>(st, a, n_seq, lm, slots, counter);
     if (nw == 1) return a.glibc_math ? launch_qg<PT, 1, 1, true>(st, a, n_seq, lm, slots, counter) : launch_qg<PT, 1, 1, false>(st, a, n_seq, lm, slots, counter);
@@ -1336,10 +1340,9 @@ int launch_two(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
 }
 
 // 65 ... 128 beams: no hashed contexts (refused where the arguments are checked: RD_REQUIRE_WIDTH_LM)
-template <typename PT>
+template <typename PT, int NW>
 int launch_128(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm)
 {
-    constexpr int NW = 5;
     if (lm) {
         if (a.glibc_math) hipLaunchKernelGGL((beam_search_kernel<PT, 2, NW, true, false, true>), dim3(n_seq), dim3(64 * NW), 0, st, a);
         else hipLaunchKernelGGL((beam_search_kernel<PT, 2, NW, true, false, false>), dim3(n_seq), dim3(64 * NW), 0, st, a);
@@ -1356,7 +1359,7 @@ int launch_pt(hipStream_t st, const DecodeArgs& a, int n_seq, bool lm, int n_sim
 {
     if (a.W > kMaxW2) {
         RD_REQUIRE(!(lm && a.hashed), "beam widths above %d do not combine with hashed long contexts (rd_load_lm_hashed)", kMaxW2);
-        return launch_128<PT>(st, a, n_seq, lm);
+        return a.W > kMaxW3 ? launch_128<PT, 10>(st, a, n_seq, lm) : launch_128<PT, 5>(st, a, n_seq, lm);
     }
     // W <= 6: two sequences per wave.  Measured (tools/decode_bench.py, 1024-row windows, W = 6): 4096 windows 1.23 -> 1.80 G time
     // steps/s (glibc arithmetic 1.10 -> 1.55 G, soft rows 0.94 -> 1.32 G); 512 windows -- lone waves, the latency case -- 1.58 vs
@@ -1395,7 +1398,7 @@ __global__ void lm_gate_kernel(const double* __restrict__ entropy, size_t n, dou
 }  // namespace
 
 extern "C" int rd_decode_max_width(void) { return RD_WIDE_MAX_W; }
-extern "C" int rd_decode_lane_width(void) { return kMaxW3; }
+extern "C" int rd_decode_lane_width(void) { return kMaxW4; }
 
 // Per-context gate bits: bit = (entropy(lm[ctx]) < r_threshold)   decode.py:85-93.
 // The entropies were computed once at rd_load_lm (glibc log, like the reference's math.log) and live in HBM.
@@ -1463,7 +1466,7 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_
     if (tm.enabled && tm.used < tm.starts.size()) RD_HIP(hipEventRecord(tm.starts[tm.used], st));
     int rc;
     if (ctx->decode_form == 5 && queue_wave_slots == 0) queue_wave_slots = 16;   // rd_set_decode_form 5 (tests): every launch through the work queue, few slots
-    if (queue_wave_slots > 0 && W <= kMaxW3 && !(use_lm && a.hashed)) {
+    if (queue_wave_slots > 0 && W <= kMaxW4 && !(use_lm && a.hashed)) {
         // more sequences than the CUs of this stream keep resident: resident workgroups + a work queue (beam_search_queue_kernel)
         if (ctx->ws_queue.reserve(256)) return RD_ERR_NOMEM;
         RD_HIP(hipMemsetAsync(ctx->ws_queue.p, 0, 4, st));
@@ -1472,7 +1475,7 @@ int rd_decode_dev(rd_ctx* ctx, const void* d_probs, int ptype, const int64_t* d_
              : ptype == 2 ? launch_queue_pt<_Float16>(st, a, n_seq, use_lm != 0, queue_wave_slots, counter)
                           : launch_queue_pt<float>(st, a, n_seq, use_lm != 0, queue_wave_slots, counter);
     } else
-    rc = W > kMaxW3 ? rd_decode_wide_launch(ctx, st, &a, ptype, n_seq, total_nodes, use_lm != 0)   // (decode_wide.hip: any wider beam)
+    rc = W > kMaxW4 ? rd_decode_wide_launch(ctx, st, &a, ptype, n_seq, total_nodes, use_lm != 0)   // (decode_wide.hip: any wider beam)
              : ptype == 1 ? launch_pt<double>(st, a, n_seq, use_lm != 0, n_simd, ctx->decode_form)
              : ptype == 2 ? launch_pt<_Float16>(st, a, n_seq, use_lm != 0, n_simd, ctx->decode_form) : launch_pt<float>(st, a, n_seq, use_lm != 0, n_simd, ctx->decode_form);
     if (rc) return rc;

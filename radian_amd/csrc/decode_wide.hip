@@ -1,8 +1,8 @@
-// decode_wide.hip -- CTC prefix beam search for beam widths above the wave-per-sequence kernels' 128 (decode.hip; 64 until round 6).
+// decode_wide.hip -- CTC prefix beam search for beam widths above the wave-per-sequence kernels' 256 (decode.hip; 64 until round 6).
 //
 // radian/decode.py:145 slices `sort_labelings()[:beam_width]` with whatever --beam-width the user gave (basecall.py:32), so
 // a width of 64 or 100 or 500 is a valid run of the reference.  decode.hip keeps a sequence's whole beam set in the lanes and LDS of
-// one to five waves, which ends at 128 beams (a beam set is built by the lanes of one wave, in at most two halves); this kernel is the general form: one workgroup of four waves per sequence, the
+// one to ten waves, which ends at 256 beams (a beam set is built by the lanes of one wave, in at most four parts); this kernel is the general form: one workgroup of four waves per sequence, the
 // kept beams and the 5 W candidates of a time step in an HBM scratch block per sequence (L2-resident: <= 300 W bytes), only
 // the ranking keys in LDS (40 W bytes).  Same semantics, phase for phase, as beam_search_kernel:
 //   A  candidate q = 5 i + k (k = 0: the copy of kept beam i, decode.py:150-175; k = 1..4: its extension by label k - 1,

@@ -135,7 +135,7 @@ struct Calib {
 inline int part_waves_per_simd(int part_cus, int W, int64_t n_seq)
 {
     const int64_t simds = (int64_t)RD_XCDS * part_cus * 4;
-    const int64_t waves = W <= 6 ? (n_seq + 1) / 2 : W <= 12 ? n_seq : W <= 25 ? 2 * n_seq : W <= 64 ? 4 * n_seq : 5 * n_seq;
+    const int64_t waves = W <= 6 ? (n_seq + 1) / 2 : W <= 12 ? n_seq : W <= 25 ? 2 * n_seq : W <= 64 ? 4 * n_seq : W <= 128 ? 5 * n_seq : 10 * n_seq;
     const int64_t m = (waves + simds - 1) / simds;
     return (int)(m < 1 ? 1 : m);
 }
@@ -268,14 +268,14 @@ int64_t chain_rows(const rd_ctx* ctx, Calib& c, int W, int m, int use_lm)
 inline int part_seq_limit(int part_cus, int W)
 {
     const int waves3 = RD_XCDS * part_cus * 4 * 3;      // three waves per SIMD
-    return W <= 6 ? 2 * waves3 : W <= 12 ? waves3 : W <= 25 ? waves3 / 2 : W <= 64 ? waves3 / 4 : waves3 / 5;   // (W <= 6: two sequences per wave; 65 ... 128: five waves, 43 KB of LDS: three per CU)
+    return W <= 6 ? 2 * waves3 : W <= 12 ? waves3 : W <= 25 ? waves3 / 2 : W <= 64 ? waves3 / 4 : W <= 128 ? waves3 / 5 : waves3 / 10;   // (W <= 6: two sequences per wave; 65 ... 128: five waves, 43 KB of LDS: three per CU; 129 ... 256: ten waves, 80 KB: two per CU)
 }
 // sequences the work-queue search of an oversubscribed partition keeps resident: its workgroups are one sequence each (1 / 2 / 4 waves for
 // W <= 12 / 25 / 51 -- no two-sequences-per-wave form), three waves per SIMD
 inline int queue_resident_seqs(int part_cus, int W)
 {
     const int waves3 = RD_XCDS * part_cus * 4 * 3;
-    return W <= 12 ? waves3 : W <= 25 ? waves3 / 2 : W <= 64 ? waves3 / 4 : waves3 / 5;
+    return W <= 12 ? waves3 : W <= 25 ? waves3 / 2 : W <= 64 ? waves3 / 4 : W <= 128 ? waves3 / 5 : waves3 / 10;
 }
 constexpr int64_t kGroupRowsCap = 96ll << 20;   // rows a group may gather while it waits for coverage (~6 GB of probabilities + matrix)
 // CUs per XCD of the decode partition for a beam width (rd_set_decode_partition -1).  ALWAYS A MULTIPLE OF FOUR: a CU-masked
@@ -288,7 +288,7 @@ constexpr int64_t kGroupRowsCap = 96ll << 20;   // rows a group may gather while
 // Round 6: widths 65 ... 128 (five waves per sequence, 13-15 us per step) take a third four: at 8 the partition's 153 resident sequences deliver ~11 M
 // steps/s against a forward of 21 M rows/s; at 12, 230 sequences and 15-16 M against 18 M (tools/policy_probe.py fp32 100 0 <part>: short / long /
 // alternating / ragged streams 10.7 / 9.6 / 11.5 / 9.2 M samples/s at 8, 15.3 / 8.6 / 16.2 / 13.0 at 12, 16.4 / 13.6 / 14.9 / 10.2 at 16).
-inline int auto_part_cus(int W) { return W <= 25 ? 4 : W <= 64 ? 8 : 12; }
+inline int auto_part_cus(int W) { return W <= 25 ? 4 : W <= 64 ? 8 : W <= 128 ? 12 : 16; }
 
 struct RSub {                 // one submitted batch inside a group
     int n_seq = 0, seq0 = 0;  // its decoded sequences (global: reads; chunk: windows) = [seq0, seq0 + n_seq) of the group

@@ -29,7 +29,7 @@ def run(rounds=20, seed=0, tmax=400, nseq=800, be=None, log=print):
             table = rng.dirichlet([0.2] * 4, size=4 ** k) if use_lm else None
             be.load_lm(table, k if use_lm else 0)
             mats, off, lens = _mats(rng, nseq, tmax, kind, dtype)
-            W = int(rng.choice([1, 2, 5, 6, 7, 9, 10, 12, 13, 25, 26, 40, 51, 52, 64, 65, 90, 100, 127, 128, 129, 160]))   # (65 ... 128: the five-wave shape of round 6; above: decode_wide.hip)
+            W = int(rng.choice([1, 2, 5, 6, 7, 9, 10, 12, 13, 25, 26, 40, 51, 52, 64, 65, 90, 100, 127, 128, 129, 160, 200, 256, 257]))   # (65 ... 128: the five-wave shape of round 6; above: decode_wide.hip)
             s_thr, r_thr = float(rng.choice([0.0, 0.5, 0.8])), float(rng.choice([0.5, 0.9, 2.0]))
             form = str(rng.choice(["auto", "waves", "lanes", "two", "one", "queue"]))     # launch shape (rd_set_decode_form): waves / lanes for W > 12, two / one for W <= 12, queue: the work-queue kernel
             be.set_decode_form(form)

@@ -53,7 +53,7 @@ def run(rounds=100, seed=0, max_len=9000, max_reads=30, log=print):
             mode = "chunk" if rng.random() < 0.4 else "global"
             step = int(rng.choice([chunk, chunk // 2, chunk // 4, max(1, chunk - 252), max(1, chunk - 253), int(rng.integers(chunk // 8, chunk + 1))]))
             # (mostly the lane kernels' common widths; now and then their upper forms -- W 26..51, 52..64 -- and the general kernel above 64)
-            W = int(rng.choice([1, 3, 6, 7, 10, 12, 13, 25])) if rng.random() < 0.9 else int(rng.choice([40, 52, 64, 65, 100, 128, 130]))
+            W = int(rng.choice([1, 3, 6, 7, 10, 12, 13, 25])) if rng.random() < 0.9 else int(rng.choice([40, 52, 64, 65, 100, 128, 130, 256, 260]))
             lm = bool(mode == "global" and rng.random() < 0.5)
             thr = (float(rng.choice([0.0, 0.3, 0.6])), float(rng.choice([0.2, 0.9, 5.0])))
             plan.append((mode, step, W, lm, thr, read_set(chunk, step)))

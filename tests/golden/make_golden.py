@@ -792,6 +792,47 @@ def gen_beam_wide128():
     print("beam_wide128:", len(cases), "cases", f"{time.time() - t_start:.0f}s")
 
 
+# ----------------------------------------------------------------------------------------------
+# 11. beam widths 129 ... 256 (round 6, last hours: the ten-wave shape, the beam set in four parts)
+# ----------------------------------------------------------------------------------------------
+def gen_beam_wide256():
+    import time
+    t_start = time.time()
+    rng = np.random.default_rng(20261107)
+    arrays, cases = {}, []
+    lm3, table3 = make_lm(rng, 3)
+    arrays["lm_k3"] = table3
+    cid = 0
+    for T in (8, 64, 200):
+        for kind in ("flat", "peaky", "hard"):
+            if T == 200 and kind == "hard":
+                continue
+            mat = make_matrix(rng, T, kind, np.float32)
+            name = f"y{cid}"
+            cid += 1
+            arrays[name] = mat
+            for W in (129, 200, 255, 256):
+                seq, final = run_beam(mat, W, capture=True)
+                cases.append({"group": "wide256_nolm", "mat": name, "T": T, "kind": kind, "W": W, "seq": seq, "final": _final_json(final[:8])})
+        print(f"  wide256 no LM T={T}: {time.time() - t_start:.0f}s", flush=True)
+    for T, kind in ((64, "flat"), (150, "peaky")):
+        mat = make_matrix(rng, T, kind, np.float64)
+        name = f"y{cid}"
+        cid += 1
+        arrays[name] = mat
+        for W in (129, 256):
+            for (s_thr, r_thr) in ((0.5, 0.5), (0.0, math.inf)):
+                seq, final = run_beam(mat, W, lm3, s_thr, r_thr, 3, capture=True)
+                cases.append({"group": "wide256_lm", "mat": name, "lm": "lm_k3", "k": 3, "T": T, "kind": kind, "W": W, "s_thr": fenc(s_thr), "r_thr": fenc(r_thr),
+                              "seq": seq, "final": _final_json(final[:8])})
+        print(f"  wide256 LM T={T} {kind}: {time.time() - t_start:.0f}s", flush=True)
+    np.savez_compressed(os.path.join(HERE, "beam_wide256_mats.npz"), **arrays)
+    with open(os.path.join(HERE, "beam_wide256_cases.json"), "w") as f:
+        json.dump({"source": "radian/decode.py:100-212 (beam_search) at beam widths 129 / 200 / 255 / 256 on seeded synthetic matrices; final = the first entries of the "
+                             "reference's last sorted beam list", "numpy": np.__version__, "cases": cases}, f, indent=0)
+    print("beam_wide256:", len(cases), "cases", f"{time.time() - t_start:.0f}s")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:       # regenerate single fixture sets: make_golden.py gen_seq_assembly_random ...
         for name in sys.argv[1:]:
@@ -809,5 +850,6 @@ if __name__ == "__main__":
     gen_beam_baseline()
     gen_pipeline_baseline()
     gen_beam_wide128()
+    gen_beam_wide256()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE))
     print("total bytes in tests/golden:", tot)

@@ -450,12 +450,13 @@ def test_baseline_wide_beams_vs_reference(be, golden_dir):
         be.load_lm(None, 0)
 
 
-def test_wide128_beams_vs_reference(be, golden_dir):
-    """Round 6: the five-wave shape (65 ... 128 beams, the beam set in two halves) against the imported reference's own beam_search at
-    W = 65 / 90 / 100 / 127 / 128: every labeling, and the winner's pr_total bit for bit in glibc arithmetic; one sequence per launch and
-    all cases of a width in one launch (neighbouring workgroups)."""
-    g = json.load(open(os.path.join(golden_dir, "beam_wide128_cases.json")))
-    arr = np.load(os.path.join(golden_dir, "beam_wide128_mats.npz"))
+@pytest.mark.parametrize("name,n_cases,widths", [("beam_wide128", 50, (65, 90, 127, 128)), ("beam_wide256", 40, (129, 200, 255, 256))])
+def test_wide128_beams_vs_reference(be, golden_dir, name, n_cases, widths):
+    """Round 6: the five-wave shape (65 ... 128 beams, the beam set in two halves) and the ten-wave shape (129 ... 256, four parts) against the imported
+    reference's own beam_search at W = 65 / 90 / 100 / 127 / 128 and 129 / 200 / 255 / 256: every labeling, and the winner's pr_total bit for bit in
+    glibc arithmetic; one sequence per launch and all cases of a width in one launch (neighbouring workgroups)."""
+    g = json.load(open(os.path.join(golden_dir, name + "_cases.json")))
+    arr = np.load(os.path.join(golden_dir, name + "_mats.npz"))
     be.set_decode_math("glibc")
     try:
         n = 0
@@ -471,9 +472,9 @@ def test_wide128_beams_vs_reference(be, golden_dir):
             exp = fdec(c["final"][0]["pr_total"])
             assert sc[0] == exp or (np.isnan(exp) and np.isnan(sc[0])), (c["group"], c["mat"], c["W"], float(sc[0]).hex(), c["final"][0]["pr_total"])
             n += 1
-        assert n == 50
+        assert n == n_cases
         be.load_lm(None, 0)
-        for W in (65, 90, 127, 128):
+        for W in widths:
             cs = [c for c in g["cases"] if c["W"] == W and "lm" not in c]
             rows = np.concatenate([arr[c["mat"]].reshape(-1, 5) for c in cs])
             lens = np.array([arr[c["mat"]].shape[0] for c in cs], dtype=np.int32)
@@ -514,7 +515,7 @@ def test_wide_beams_vs_oracle(be, oracle):
     """Widths above the wave-per-sequence kernels' 51 (decode_wide.hip; the reference slices with any --beam-width, decode.py:145):
     batches with empty / one-row / ragged sequences, float32 and float64 rows, exact-0 probabilities (ties), with a 3-mer LM (dense
     and sparse), both arithmetics, against the oracle; the width where the two kernels meet (51 | 52) included."""
-    assert be._L.rd_decode_lane_width() == 128 and be.max_beam_width >= 1024
+    assert be._L.rd_decode_lane_width() == 256 and be.max_beam_width >= 1024
     rng = np.random.default_rng(2026)
     lens = [300, 0, 1, 64, 65, 129, 512, 7]
     rows = []
@@ -532,15 +533,15 @@ def test_wide_beams_vs_oracle(be, oracle):
         be.set_decode_math(math)
         for dtype in (np.float32, np.float64):
             mats = np.concatenate(rows, axis=0).astype(dtype)
-            for W in (51, 52, 63, 64, 65, 100, 127, 128, 129, 257, 1024):       # (52 ... 64: four waves, two candidates per lane; 65 ... 128: five waves, the beam set in two halves -- round 6; above: decode_wide.hip)
-                if math == "fast" and W not in (52, 64, 100, 128):
+            for W in (51, 52, 63, 64, 65, 100, 127, 128, 129, 200, 256, 257, 1024):       # (52 ... 64: four waves, two candidates per lane; 65 ... 128: five waves, the beam set in two halves -- round 6; above: decode_wide.hip)
+                if math == "fast" and W not in (52, 64, 100, 128, 256):
                     continue
                 be.load_lm(None, 0)
                 got = be.decode_batch(mats, off, lens, W)
                 exp = oracle.beam_search_batch(mats, off, lens, W)
                 for i in range(len(lens)):
                     assert np.array_equal(got[i], exp[i]), (math, dtype, W, i, "no LM")
-                if W in (52, 64, 100, 128, 129):
+                if W in (52, 64, 100, 128, 129, 256, 257):
                     for tb in (table, sparse):
                         be.load_lm(tb, 3)
                         got = be.decode_batch(mats, off, lens, W, use_lm=True, s_threshold=0.5, r_threshold=0.9)

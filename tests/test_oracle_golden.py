@@ -287,12 +287,13 @@ def test_baseline_wide_beams(oracle, golden_dir):
             _check_final(final, c["final"], tag)
 
 
-def test_wide128_beams_against_the_reference(oracle, golden_dir):
-    """Round 6: beam widths 65 / 90 / 100 / 127 / 128 from the imported reference (tests/golden/make_golden.py gen_beam_wide128) -- the widths the
-    wave-per-sequence kernels took over from the general kernel: labelings and the final beam's scores, bit for bit."""
-    g = _load(golden_dir, "beam_wide128_cases.json")
-    arr = np.load(os.path.join(golden_dir, "beam_wide128_mats.npz"))
-    assert len(g["cases"]) == 50 and {c["W"] for c in g["cases"]} == {65, 90, 100, 127, 128}
+@pytest.mark.parametrize("name,n,widths", [("beam_wide128", 50, {65, 90, 100, 127, 128}), ("beam_wide256", 40, {129, 200, 255, 256})])
+def test_wide128_beams_against_the_reference(oracle, golden_dir, name, n, widths):
+    """Round 6: beam widths 65 ... 128 and 129 ... 256 from the imported reference (tests/golden/make_golden.py gen_beam_wide128 / gen_beam_wide256) -- the
+    widths the wave-per-sequence kernels took over from the general kernel: labelings and the final beam's scores, bit for bit."""
+    g = _load(golden_dir, name + "_cases.json")
+    arr = np.load(os.path.join(golden_dir, name + "_mats.npz"))
+    assert len(g["cases"]) == n and {c["W"] for c in g["cases"]} == widths
     for c in g["cases"]:
         lm = arr[c["lm"]] if "lm" in c else None
         labels, final = oracle.beam_search_labels(arr[c["mat"]], c["W"], lm, fdec(c["s_thr"]) if lm is not None else 0.0,
