@@ -317,7 +317,10 @@ def test_bench_nrank_files_leg_with_stub_ranks(tmp_path, capfd, oracle):
     assert leg["n_ranks"] == 3 and leg["reads"] == 120 and leg["records_written"] == 120 and leg["samples"] == 120 * 500
     assert leg["value"] > 0 and leg["value_to_merged_fasta"] > 0 and leg["seconds_to_merged_fasta"] >= leg["seconds"] * 0.5
     pr = leg["per_rank"]
-    assert [p["rank"] for p in pr] == [0, 1, 2] and sum(p["reads"] for p in pr) == 120 and all(p["cores"] >= 1 and p["value"] > 0 for p in pr)
+    # (the work queue deals 18 blocks of <= 7 reads to whoever asks first: with stub ranks whose warm-up takes a different time each, one rank may
+    # find it empty -- a rank without reads reports 0 reads and a rate of 0, it does not fail the leg)
+    assert [p["rank"] for p in pr] == [0, 1, 2] and sum(p["reads"] for p in pr) == 120 and all(p["cores"] >= 1 and p["value"] >= 0 for p in pr)
+    assert sum(1 for p in pr if p["reads"] > 0 and p["value"] > 0) >= 2
     if len(os.sched_getaffinity(0)) >= 3:
         from radian_amd.hostbudget import parse_cpulist
         sets = [set(parse_cpulist(p["cpus"])) for p in pr]
