@@ -11,11 +11,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_fuzz_decode_bounded():
-    """beam search vs the oracle: 40 rounds (60 until round 6: the suite's budget) of random width (1..160: the two-sequences-per-wave widths, the wave-per-sequence kernels, the
+    """beam search vs the oracle: 30 rounds (60 until round 6: the suite's budget, and the width list now reaches 257, where the oracle's side is slow) of random width (1..160: the two-sequences-per-wave widths, the wave-per-sequence kernels, the
     general kernel above 51), launch form (incl. the work queue), arithmetic, row type and LM order; every labeling identical"""
     import fuzz_decode
-    total, bad = fuzz_decode.run(rounds=40, seed=404, tmax=300, nseq=400)
-    assert total == 40 * 400 and bad == 0
+    total, bad = fuzz_decode.run(rounds=30, seed=404, tmax=300, nseq=400)
+    assert total == 30 * 400 and bad == 0
 
 
 def test_fuzz_reads_bounded():
@@ -27,8 +27,8 @@ def test_fuzz_reads_bounded():
 
 
 def test_fuzz_pipe_bounded():
-    """the in-context pipeline vs the blocking entry points: 100 rounds (150 until round 6) of random submit sequences on one context (decode type, geometry,
+    """the in-context pipeline vs the blocking entry points: 80 rounds (150 until round 6) of random submit sequences on one context (decode type, geometry,
     width, LM, thresholds, logits, precision, lanes, group size, partition changing between rounds; progress polled at random)"""
     import fuzz_pipe
-    n, bad = fuzz_pipe.run(rounds=100, seed=404, max_len=5000, max_reads=16)
-    assert n >= 200 and bad == 0
+    n, bad = fuzz_pipe.run(rounds=80, seed=404, max_len=5000, max_reads=16)
+    assert n >= 160 and bad == 0
