@@ -1,4 +1,4 @@
-// decode.hip -- CTC prefix beam search with the k-mer RNA-LM gate, one workgroup of 1-4 wavefronts per sequence.
+// decode.hip -- CTC prefix beam search with the k-mer RNA-LM gate, one workgroup of 1-10 wavefronts per sequence (beam widths up to 256).
 //
 // Replaces radian/decode.py:100-212 (beam_search) and :42-96 (LM gate) of the reference.
 //
@@ -62,6 +62,7 @@ struct Cfg<2, 4> {
 // five waves, two candidates per lane: 640 candidates = 128 beams (round 6: widths 65 ... 128, until then decode_wide.hip's at 7x the step
 // time).  The per-beam work that the shapes above do with "lane = beam" runs here over TWO halves of the beam set (beam = lane + 64 h):
 // the table self-check and the claim check on every wave, the trie phase on wave 0 one half after the other.
+// Ten waves carry 256 beams the same way in four parts (Cfg<2, 10>: 1280 candidates; beam indices in the scatter word take 9 bits there).
 
 
 // Hand-off between the waves of a sequence's workgroup.  One wave: see wave_sync.  Several waves: the LDS operations of
