@@ -165,5 +165,13 @@ if __name__ == "__main__":
     a = sys.argv[1:]
     if a and a[0] == "--load-worker":
         load_worker(float(a[1]))
+    elif a and a[0] == "--independent":        # --independent prec W: the independent figures alone, one JSON line
+        print(json.dumps(independent_only(a[1], int(a[2]))))
+    elif len(a) > 4:                           # prec W load partition ragged: every argument given (tests/test_gpu_policy.py); exit code 3 = no load worker
+        try:
+            print(json.dumps(probe(a[0], int(a[1]), bool(int(a[2])), part=int(a[3]), ragged=bool(int(a[4])))))
+        except LoadWorkerFailed as e:
+            print(str(e), file=sys.stderr)
+            sys.exit(3)
     else:
         print(json.dumps(probe(a[0] if a else "fp32", int(a[1]) if len(a) > 1 else 10, bool(int(a[2])) if len(a) > 2 else False, part=int(a[3]) if len(a) > 3 else -1)))
